@@ -1,0 +1,48 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_fixture(name):
+    """Returns (meta dict, npz mapping) of a golden fixture written by tests/golden/make_golden.py."""
+    with open(os.path.join(GOLDEN, name + '.json')) as f:
+        meta = json.load(f)
+    data = np.load(os.path.join(GOLDEN, name + '.npz'))
+    return meta, data
+
+
+def fixture_params(data, prefix):
+    """Oracle-style parameter dict from a fixture: tensors by state_dict name + '<layer>.c' floats."""
+    out = {}
+    pre = prefix + '/'
+    for k in data.files:
+        if k.startswith(pre):
+            name = k[len(pre):]
+            v = data[k]
+            out[name] = float(v) if name.endswith('.c') else torch.from_numpy(v.copy())
+    return out
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(-1)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    from oracle import pggan_cpu
+    return pggan_cpu

@@ -1,0 +1,445 @@
+"""Generate the golden fixtures in this directory from the reference itself.
+
+CONTAINER-ONLY TOOL: imports /root/reference (read-only) with the shims of SURVEY.md §8c and
+runs the reference's own Generator / Discriminator / wgan_gp_*_loss / Trainer / DepthManager /
+LRScheduler on the CPU (torch 2.10).  Writes only data (inputs + expected outputs) as
+.npz / .json next to this file.  Nothing here travels to, or is needed on, the GPU box.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+
+# ---- shims --------------------------------------------------------------
+sys.path.insert(0, REF)
+torch.nn.Module.cuda = lambda self, *a, **k: self
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.cuda.FloatTensor = torch.FloatTensor
+
+
+class _Plugin(object):
+    def __init__(self, interval=None):
+        self.trigger_interval = interval or []
+
+    def register(self, trainer):
+        raise NotImplementedError
+
+
+_pk, _pp, _ppp = (types.ModuleType(n) for n in ('torch.utils.trainer', 'torch.utils.trainer.plugins',
+                                                'torch.utils.trainer.plugins.plugin'))
+_pp.LossMonitor = _pp.Logger = _ppp.Plugin = _Plugin
+_pk.plugins = _pp
+_pp.plugin = _ppp
+sys.modules.update({m.__name__: m for m in (_pk, _pp, _ppp)})
+
+import contextlib, io  # noqa: E402
+with contextlib.redirect_stdout(io.StringIO()):
+    import network            # noqa: E402
+    import wgan_gp_loss       # noqa: E402
+    import trainer as ref_trainer   # noqa: E402
+    import plugins as ref_plugins   # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def export_params(model, prefix):
+    out = {}
+    for k, v in model.state_dict().items():
+        out['%s/%s' % (prefix, k)] = v.detach().numpy().copy()
+    for name, m in model.named_modules():
+        if isinstance(m, network.PGConv2d):
+            out['%s/%s.c' % (prefix, name)] = np.float32(float(m.c))
+    return out
+
+
+def synthetic(seed, n, C, res, latent):
+    rs = np.random.RandomState(seed)
+    real = rs.rand(n, C, res, res).astype(np.float32) * 2 - 1
+    z_d = rs.randn(n, latent).astype(np.float32)
+    z_g = rs.randn(n, latent).astype(np.float32)
+    mix = rs.rand(n, 1).astype(np.float32)
+    return real, z_d, z_g, mix
+
+
+def force_mix(mix):
+    """Make wgan_gp_loss.calc_gradient_penalty use our mixing factors: the module-global scratch
+    tensor (wgan_gp_loss.py:15-17) is pre-seeded with ``mix`` and its uniform_() is made a no-op."""
+    t = torch.from_numpy(mix.copy())
+    t.uniform_ = lambda *a, **k: t
+    wgan_gp_loss.mixing_factors = t
+    return t
+
+
+def grads_of(model):
+    return {k: p.grad.detach().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def run_steps(G, D, depth, alpha, real, z_d, z_g, mix):
+    """reference D loss + backward, then G loss + backward (no optimizer step)."""
+    G.depth = D.depth = depth
+    G.alpha = D.alpha = alpha
+    out = {}
+    for p in list(G.parameters()) + list(D.parameters()):
+        p.grad = None
+    force_mix(mix)
+    d_cost, d_real_loss, d_fake_loss = wgan_gp_loss.wgan_gp_D_loss(
+        D, G, torch.from_numpy(real), torch.from_numpy(z_d))
+    d_cost.backward()
+    out['D_cost'] = d_cost.detach().numpy()
+    out['D_real_loss'] = d_real_loss.detach().numpy()
+    out['D_fake_loss'] = d_fake_loss.detach().numpy()
+    dg = grads_of(D)
+    for p in list(G.parameters()) + list(D.parameters()):
+        p.grad = None
+    g_cost = wgan_gp_loss.wgan_gp_G_loss(G, D, torch.from_numpy(z_g))
+    g_cost.backward()
+    out['G_cost'] = g_cost.detach().numpy()
+    gg = grads_of(G)
+    with torch.no_grad():
+        out['G_out'] = G(torch.from_numpy(z_d)).numpy()
+        out['D_real'] = D(torch.from_numpy(real)).numpy()
+        out['D_fake'] = D(torch.from_numpy(out['G_out'])).numpy()
+    return out, dg, gg
+
+
+def checksum(a):
+    a = np.asarray(a, dtype=np.float64)
+    return [float(a.sum()), float(np.abs(a).sum()), float((a * a).sum())]
+
+
+# ---- fixture 1+2+3: tiny res-32 nets: init parity, forward, D/G step gradients ---------
+def make_tiny32():
+    kw = dict(fmap_base=64, fmap_max=16, fmap_decay=1.0)
+    shape = (1, 3, 32, 32)
+    torch.manual_seed(1337)
+    G = quiet(network.Generator, shape, latent_size=16, **kw)
+    D = quiet(network.Discriminator, shape, **kw)
+    fx = {}
+    fx.update(export_params(G, 'G'))
+    fx.update(export_params(D, 'D'))
+    cases = []
+    for depth in range(4):
+        for alpha in ((1.0,) if depth == 0 else (1.0, 0.37)):
+            n = 4
+            res = 4 * 2 ** depth
+            seed = 100 + 10 * depth + (0 if alpha == 1.0 else 1)
+            real, z_d, z_g, mix = synthetic(seed, n, 3, res, 16)
+            out, dg, gg = run_steps(G, D, depth, alpha, real, z_d, z_g, mix)
+            tag = 'd%d_a%s' % (depth, ('1' if alpha == 1.0 else '037'))
+            cases.append(dict(tag=tag, depth=depth, alpha=alpha, n=n, seed=seed))
+            for k, v in out.items():
+                fx['%s/%s' % (tag, k)] = v
+            for k, v in dg.items():
+                fx['%s/Dgrad/%s' % (tag, k)] = v
+            for k, v in gg.items():
+                fx['%s/Ggrad/%s' % (tag, k)] = v
+    np.savez_compressed(os.path.join(HERE, 'tiny32.npz'), **fx)
+    with open(os.path.join(HERE, 'tiny32.json'), 'w') as f:
+        json.dump(dict(cfg=dict(resolution=32, num_channels=3, latent_size=16, **kw), cases=cases,
+                       init_seed=1337), f, indent=1)
+
+
+# ---- fixture 4: single-channel (spectrogram-shape) net, res 16, C=1 ---------------------
+def make_tiny16_c1():
+    kw = dict(fmap_base=128, fmap_max=32, fmap_decay=1.0)
+    shape = (1, 1, 16, 16)
+    torch.manual_seed(7)
+    G = quiet(network.Generator, shape, latent_size=32, **kw)
+    D = quiet(network.Discriminator, shape, **kw)
+    fx = {}
+    fx.update(export_params(G, 'G'))
+    fx.update(export_params(D, 'D'))
+    cases = []
+    for depth, alpha in ((2, 1.0), (2, 0.5), (1, 0.25)):
+        n = 6
+        res = 4 * 2 ** depth
+        seed = 300 + 10 * depth + int(alpha * 100)
+        real, z_d, z_g, mix = synthetic(seed, n, 1, res, 32)
+        out, dg, gg = run_steps(G, D, depth, alpha, real, z_d, z_g, mix)
+        tag = 'd%d_a%03d' % (depth, int(alpha * 100))
+        cases.append(dict(tag=tag, depth=depth, alpha=alpha, n=n, seed=seed))
+        for k, v in out.items():
+            fx['%s/%s' % (tag, k)] = v
+        for k, v in dg.items():
+            fx['%s/Dgrad/%s' % (tag, k)] = v
+        for k, v in gg.items():
+            fx['%s/Ggrad/%s' % (tag, k)] = v
+    np.savez_compressed(os.path.join(HERE, 'tiny16c1.npz'), **fx)
+    with open(os.path.join(HERE, 'tiny16c1.json'), 'w') as f:
+        json.dump(dict(cfg=dict(resolution=16, num_channels=1, latent_size=32, **kw), cases=cases,
+                       init_seed=7), f, indent=1)
+
+
+# ---- fixture 5: tiny-width 1024x1024 net (all nine growth stages exist) ------------------
+def make_thin1024():
+    kw = dict(fmap_base=2048, fmap_max=16, fmap_decay=1.0)   # nf = 16 x8, 8, 4
+    shape = (1, 3, 1024, 1024)
+    torch.manual_seed(11)
+    G = quiet(network.Generator, shape, latent_size=16, **kw)
+    D = quiet(network.Discriminator, shape, **kw)
+    fx = {}
+    fx.update(export_params(G, 'G'))
+    fx.update(export_params(D, 'D'))
+    cases = []
+    for depth, alpha, n in ((8, 1.0, 2), (7, 0.5, 2), (5, 1.0, 3)):
+        res = 4 * 2 ** depth
+        seed = 500 + depth
+        real, z_d, z_g, mix = synthetic(seed, n, 3, res, 16)
+        out, dg, gg = run_steps(G, D, depth, alpha, real, z_d, z_g, mix)
+        tag = 'd%d_a%03d' % (depth, int(alpha * 100))
+        cases.append(dict(tag=tag, depth=depth, alpha=alpha, n=n, seed=seed))
+        g_out = out.pop('G_out')
+        fx['%s/G_out_checksum' % tag] = np.array(checksum(g_out))
+        fx['%s/G_out_sample' % tag] = g_out[:, :, ::61, ::67].copy()
+        for k, v in out.items():
+            fx['%s/%s' % (tag, k)] = v
+        for k, v in dg.items():
+            fx['%s/Dgrad/%s' % (tag, k)] = v
+        for k, v in gg.items():
+            fx['%s/Ggrad/%s' % (tag, k)] = v
+    np.savez_compressed(os.path.join(HERE, 'thin1024.npz'), **fx)
+    with open(os.path.join(HERE, 'thin1024.json'), 'w') as f:
+        json.dump(dict(cfg=dict(resolution=1024, num_channels=3, latent_size=16, **kw), cases=cases,
+                       init_seed=11), f, indent=1)
+
+
+# ---- fixture 6: default-width res-32 net (512 channels): weights re-derived from the seed ---
+def make_full32():
+    shape = (1, 3, 32, 32)
+    torch.manual_seed(1337)
+    G = quiet(network.Generator, shape)
+    D = quiet(network.Discriminator, shape)
+    fx = {}
+    # weights are NOT stored (80 MB); the init rule is pinned by tiny32 and re-run from the seed.
+    fx['G/param_checksums'] = np.array([checksum(v.detach().numpy()) for v in G.parameters()])
+    fx['D/param_checksums'] = np.array([checksum(v.detach().numpy()) for v in D.parameters()])
+    cs = {}
+    for pre, m in (('G', G), ('D', D)):
+        for name, mod in m.named_modules():
+            if isinstance(mod, network.PGConv2d):
+                cs['%s/%s.c' % (pre, name)] = float(mod.c)
+    cases = []
+    for depth, alpha, n in ((0, 1.0, 16), (2, 0.6, 8), (3, 1.0, 4)):
+        res = 4 * 2 ** depth
+        seed = 700 + depth
+        real, z_d, z_g, mix = synthetic(seed, n, 3, res, 512)
+        out, dg, gg = run_steps(G, D, depth, alpha, real, z_d, z_g, mix)
+        tag = 'd%d_a%03d' % (depth, int(alpha * 100))
+        cases.append(dict(tag=tag, depth=depth, alpha=alpha, n=n, seed=seed))
+        for k, v in out.items():
+            fx['%s/%s' % (tag, k)] = v
+        for pre, gr in (('Dgrad', dg), ('Ggrad', gg)):
+            for k, v in gr.items():
+                if v.size <= 4096:
+                    fx['%s/%s/%s' % (tag, pre, k)] = v
+                else:
+                    fx['%s/%s_checksum/%s' % (tag, pre, k)] = np.array(checksum(v))
+                    fx['%s/%s_sample/%s' % (tag, pre, k)] = v.reshape(-1)[::997].copy()
+    np.savez_compressed(os.path.join(HERE, 'full32.npz'), **fx)
+    with open(os.path.join(HERE, 'full32.json'), 'w') as f:
+        json.dump(dict(cfg=dict(resolution=32, num_channels=3, latent_size=512, fmap_base=4096,
+                                fmap_max=512, fmap_decay=1.0), cases=cases, init_seed=1337, c=cs),
+                  f, indent=1)
+
+
+# ---- fixture 7: DepthManager / LRScheduler schedule table (bit-exact) --------------------
+class _FakeNet(object):
+    depth = 0
+    alpha = 1.0
+
+
+class _FakeDataset(object):
+    model_depth = 0
+    alpha = 1.0
+
+
+class _FakeTrainer(object):
+    def __init__(self):
+        self.cur_nimg = 0
+        self.D, self.G, self.dataset = _FakeNet(), _FakeNet(), _FakeDataset()
+        self.stats = {}
+        self.dataiter = None
+        self.random_latents_generator = None
+        self.tick_duration_nimg = 2000
+
+
+def make_schedule():
+    rows = []
+    sweeps = [
+        dict(max_depth=8, kw={}),
+        dict(max_depth=3, kw=dict(lod_training_nimg=640, lod_transition_nimg=1280, minibatch_default=64)),
+        dict(max_depth=5, kw=dict(lod_training_nimg=1000, lod_transition_nimg=700,
+                                  minibatch_overrides={4: 8, 5: 4}, tick_kimg_overrides={2: 7})),
+    ]
+    for sw in sweeps:
+        mbs = []
+        dm = ref_plugins.DepthManager(lambda mb: [mb], lambda mb: (lambda: mb), sw['max_depth'], **sw['kw'])
+        tr = _FakeTrainer()
+        dm.register(tr)
+        lt = sw['kw'].get('lod_training_nimg', 100000)
+        ltr = sw['kw'].get('lod_transition_nimg', 100000)
+        period = lt + ltr
+        pts = set()
+        for k in range(sw['max_depth'] + 2):
+            for off in (0, 1, 16, lt - 1, lt, lt + 1, lt + 16, lt + ltr // 2, lt + ltr // 3, period - 1):
+                pts.add(k * period + off)
+        rs = np.random.RandomState(5)
+        pts.update(int(v) for v in rs.randint(0, (sw['max_depth'] + 2) * period, size=200))
+        table = []
+        for nimg in sorted(pts):
+            tr.cur_nimg = nimg
+            dm.iteration()
+            table.append([nimg, tr.G.depth, repr(float(tr.G.alpha)), tr.stats['minibatch_size'],
+                          tr.tick_duration_nimg])
+        rows.append(dict(max_depth=sw['max_depth'], kw={k: (v if not isinstance(v, dict) else
+                                                           {str(a): b for a, b in v.items()})
+                                                        for k, v in sw['kw'].items()}, table=table))
+    # lr rampup (train.py:151-156) through the real LambdaLR + LRScheduler plugin
+    from torch.optim import Adam
+    from torch.optim.lr_scheduler import LambdaLR
+
+    def rampup(cur_nimg, lr_rampup_kimg=40):
+        if cur_nimg < lr_rampup_kimg * 1000:
+            p = max(0.0, 1 - cur_nimg / (lr_rampup_kimg * 1000))
+            return np.exp(-p * p * 5.0)
+        return 1.0
+    w = torch.nn.Parameter(torch.zeros(1))
+    opt = Adam([w], 0.001, betas=(0.0, 0.99))
+    import warnings
+    warnings.simplefilter('ignore')
+    lrs = LambdaLR(opt, rampup)
+    lr_rows = []
+    for nimg in (0, 16, 160, 1600, 10000, 20000, 39984, 39999, 40000, 40016, 100000):
+        lrs.step(nimg)
+        lr_rows.append([nimg, repr(float(opt.param_groups[0]['lr']))])
+    with open(os.path.join(HERE, 'schedule.json'), 'w') as f:
+        json.dump(dict(sweeps=rows, lr=lr_rows), f)
+
+
+# ---- fixture 8: Trainer.train() trace with DepthManager + LRScheduler + Adam -------------
+def make_trace():
+    from torch.optim import Adam
+    from torch.optim.lr_scheduler import LambdaLR
+    kw = dict(fmap_base=64, fmap_max=16, fmap_decay=1.0)
+    shape = (1, 3, 16, 16)
+    latent = 16
+    torch.manual_seed(3)
+    G = quiet(network.Generator, shape, latent_size=latent, **kw)
+    D = quiet(network.Discriminator, shape, **kw)
+    fx = {}
+    fx.update(export_params(G, 'G0'))
+    fx.update(export_params(D, 'D0'))
+    opt_g = Adam(G.parameters(), 0.001, betas=(0.0, 0.99))
+    opt_d = Adam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    rk = 0.2   # lr_rampup_kimg
+
+    def rampup(cur_nimg):
+        if cur_nimg < rk * 1000:
+            p = max(0.0, 1 - cur_nimg / (rk * 1000))
+            return np.exp(-p * p * 5.0)
+        return 1.0
+    import warnings
+    warnings.simplefilter('ignore')
+    lrs_d, lrs_g = LambdaLR(opt_d, rampup), LambdaLR(opt_g, rampup)
+
+    log = dict(real=[], z=[], mix=[], depth=[], alpha=[], mb=[], lr=[], G_cost=[], D_cost=[], nimg=[])
+    rs = np.random.RandomState(99)
+    state = dict(depth=0)
+
+    class Data(object):
+        model_depth = 0
+        alpha = 1.0
+
+    dataset = Data()
+
+    def make_loader(mb):
+        def gen():
+            while True:
+                res = 4 * 2 ** dataset.model_depth
+                x = rs.rand(mb, 3, res, res).astype(np.float32) * 2 - 1
+                log['real'].append(x)
+                yield torch.from_numpy(x)
+        return gen()
+
+    def make_rlg(mb):
+        def f():
+            z = rs.randn(mb, latent).astype(np.float32)
+            log['z'].append(z)
+            return torch.from_numpy(z)
+        return f
+
+    def d_loss(Dm, Gm, real, z):
+        mix = rs.rand(real.size(0), 1).astype(np.float32)
+        log['mix'].append(mix)
+        force_mix(mix)
+        return wgan_gp_loss.wgan_gp_D_loss(Dm, Gm, real, z)
+
+    tr = ref_trainer.Trainer(D, G, d_loss, wgan_gp_loss.wgan_gp_G_loss, opt_d, opt_g, dataset,
+                             make_loader(4), make_rlg(4))
+    dm_kw = dict(minibatch_default=4, minibatch_overrides={2: 2}, lod_training_nimg=8,
+                 lod_transition_nimg=12)
+    tr.register_plugin(ref_plugins.DepthManager(make_loader, make_rlg, 2, **dm_kw))
+    tr.register_plugin(ref_plugins.LRScheduler(lrs_d, lrs_g))
+
+    class Rec(_Plugin):
+        def __init__(self):
+            super(Rec, self).__init__([(1, 'iteration')])
+
+        def register(self, trainer):
+            self.trainer = trainer
+
+        def iteration(self, i, g_cost, d_cost, d_real, d_fake):
+            log['G_cost'].append(float(g_cost))
+            log['D_cost'].append(float(d_cost))
+    # the recorder is registered FIRST in queue order? no: after, so it sees the losses of the
+    # iteration just run; depth/alpha used by an iteration are those set by the previous call.
+    tr.register_plugin(Rec())
+    import heapq
+    for q in tr.plugin_queues.values():
+        heapq.heapify(q)
+    n_iter = 14
+    for it in range(n_iter):
+        log['depth'].append(int(G.depth))
+        log['alpha'].append(repr(float(G.alpha)))
+        log['lr'].append(repr(float(opt_d.param_groups[0]['lr'])))
+        log['nimg'].append(int(tr.cur_nimg))
+        before = len(log['real'])
+        tr.train()
+        log['mb'].append(int(log['real'][before].shape[0]))
+    fx.update(export_params(G, 'G1'))
+    fx.update(export_params(D, 'D1'))
+    for i, a in enumerate(log['real']):
+        fx['real/%d' % i] = a
+    for i, a in enumerate(log['z']):
+        fx['z/%d' % i] = a
+    for i, a in enumerate(log['mix']):
+        fx['mix/%d' % i] = a
+    np.savez_compressed(os.path.join(HERE, 'trace16.npz'), **fx)
+    with open(os.path.join(HERE, 'trace16.json'), 'w') as f:
+        json.dump(dict(cfg=dict(resolution=16, num_channels=3, latent_size=latent, **kw), init_seed=3,
+                       dm_kw={k: (v if not isinstance(v, dict) else {str(a): b for a, b in v.items()})
+                              for k, v in dm_kw.items()},
+                       lr_rampup_kimg=rk, n_iter=n_iter, final_nimg=int(tr.cur_nimg),
+                       depth=log['depth'], alpha=log['alpha'], lr=log['lr'], nimg=log['nimg'],
+                       mb=log['mb'], G_cost=log['G_cost'], D_cost=log['D_cost'],
+                       n_real=len(log['real']), n_z=len(log['z']), n_mix=len(log['mix'])), f, indent=1)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['tiny32', 'tiny16c1', 'thin1024', 'full32', 'schedule', 'trace']
+    for w in which:
+        print('making', w, flush=True)
+        globals()['make_' + {'tiny16c1': 'tiny16_c1'}.get(w, w)]()
+    print('done')
