@@ -1,0 +1,197 @@
+/* libpggan_hip.so — C-ABI of the MI355X (gfx950) PGGAN hot-path kernels.
+ *
+ * The reference (deepsound-project/pggan-pytorch) has no FFI of its own: its hot path is the
+ * sequence of ATen op call sites issued by network.py / wgan_gp_loss.py.  Each
+ * entry point below replaces one such call site (or a fused group of them); the reference
+ * file:line it stands in for is cited on every declaration.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the caller owns all
+ *     buffers (no allocation, no ownership transfer, no global mutable state => re-entrant);
+ *   - "feature" tensors are NHWC  [N][H][W][C]  with C % 4 == 0 and 16-byte aligned bases;
+ *   - "image"   tensors are NCHW  [N][C][H][W]  (the reference's layout at the G-output/D-input);
+ *   - conv weights are packed  [KH][KW][Cout][Cin]  (the K dimension contiguous);
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*), never
+ *     synchronise, and are safe to capture into a hipGraph;
+ *   - return value: 0 = ok, <0 = argument error (PG_E_*), >0 = hipError_t of the launch.
+ */
+#ifndef PGGAN_HIP_H
+#define PGGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_E_ARG     (-1)   /* bad dimension / null pointer            */
+#define PG_E_ALIGN   (-2)   /* channel count not a multiple of 4, ...  */
+#define PG_E_UNSUP   (-3)   /* unsupported kernel size / configuration */
+
+typedef void* pg_stream_t;
+
+/* Library / device info.  Returns the ABI version (bumped on any signature change). */
+int pg_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Equalized-lr convolution, implicit GEMM on v_mfma_f32_16x16x4_f32.
+ * Replaces: `h = x * self.c; h = self.conv(h); h = self.act(h)`      network.py:33-36
+ *           (and, through autograd, its backward-data pass and the "masked linear map" of the
+ *            gradient-penalty tangent pass, wgan_gp_loss.py:25-28 + trainer.py:98).
+ *
+ *   z[n,oh,ow,co] = scale * sum_{kh,kw,ci} xin[n, oh-pad+kh, ow-pad+kw, ci] * w[kh][kw][co][ci]
+ *   xin = x, or (ups != 0) the nearest-neighbour x2 upsampling of x   (network.py:127,129)
+ *   y = mask ? z * (mask>0 ? 1 : mask_slope)                          (LeakyReLU' re-applied)
+ *            : lrelu_slope(z + bias)      (slope 1.0 == no activation; bias may be NULL)
+ *   Hin,Win: dims of xin (AFTER upsampling).  Hout = Hin + 2*pad - KS + 1.  KS in {1,3,4}.
+ *   x: [N][Hin/(ups?2:1)][Win/(ups?2:1)][Cin]   y,mask: [N][Hout][Wout][Cout]
+ */
+int pg_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* mask, float* y,
+                   int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
+                   float scale, float slope, float mask_slope, pg_stream_t stream);
+
+/* Weight gradient of the convolution above (autograd of network.py:34):
+ *   dw[kh][kw][co][ci] += scale * sum_{n,oh,ow} gz[n,oh,ow,co] * xin[n,oh-pad+kh,ow-pad+kw,ci]
+ *   db[co]             += sum_{n,oh,ow} gz[n,oh,ow,co]          (db may be NULL)
+ * gz is the adjoint of the pre-activation z (LeakyReLU mask already applied).  Accumulates
+ * (atomic fp32 adds): the caller zeroes dw/db once per step.  */
+int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, float* db,
+                         int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
+                         float scale, pg_stream_t stream);
+
+/* Repack forward weights [KS][KS][Cout][Cin] into the weights of the backward-data convolution
+ * [KS][KS][Cin][Cout] (spatially flipped, channels transposed).                               */
+int pg_pack_dgrad_weights(const float* w, float* wt, int KS, int Cout, int Cin, pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fromRGB: 1x1 conv from an NCHW image (C_img in {1,3,4}) to NHWC features, fused LeakyReLU.
+ * Replaces DBlock/DLastBlock.fromRGB  network.py:145,160 (+ F.avg_pool2d(x,2) network.py:231 when
+ * pool != 0: the image is [N][C][2H][2W] and is 2x2-averaged on the fly).
+ *   y[n,h,w,co] = epilogue(scale * sum_c img[n,c,h,w] * w[co][c])   epilogue as pg_conv2d_nhwc. */
+int pg_fromrgb_fwd(const float* img, const float* w, const float* bias, const float* mask, float* y,
+                   int N, int C, int H, int W, int Cout, int pool,
+                   float scale, float slope, float mask_slope, pg_stream_t stream);
+
+/* d/d img of the above: gimg[n,c,h,w] (+)= mul * scale * sum_co gz[n,h,w,co] * w[co][c]
+ * (pool != 0: each of the 2x2 source pixels receives a quarter).  accumulate != 0 adds.       */
+int pg_fromrgb_bwd_data(const float* gz, const float* w, float* gimg,
+                        int N, int C, int H, int W, int Cout, int pool, int accumulate,
+                        float scale, pg_stream_t stream);
+
+/* dw[co][c] += scale * sum_pix gz[pix,co] * img[pix,c];  db[co] += sum_pix gz[pix,co].        */
+int pg_fromrgb_wgrad(const float* gz, const float* img, float* dw, float* db,
+                     int N, int C, int H, int W, int Cout, int pool, float scale, pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * toRGB: 1x1 conv from NHWC features to an NCHW image, no activation, fused fade-in blend.
+ * Replaces GBlock.toRGB network.py:49,65,70 and `preult_rgb*(1-alpha) + ult*alpha` network.py:138
+ * (toRGB of the previous block commutes with the nearest upsample, so `prev` is low-res):
+ *   out[n,c,h,w] = out_mul * (scale * sum_ci x[n,h,w,ci]*w[c][ci] + bias[c])
+ *                + (prev ? prev_mul * prev[n,c,h/2,w/2] : 0)                                  */
+int pg_torgb_fwd(const float* x, const float* w, const float* bias, const float* prev, float* out,
+                 int N, int C, int H, int W, int Cin, float scale, float out_mul, float prev_mul,
+                 pg_stream_t stream);
+
+/* gx[n,h,w,ci] = mul * scale * sum_c g[n,c,h(*),w(*)] * w[c][ci]
+ * down != 0: g is [N][C][2H][2W] and is 2x2-SUMMED on the fly (adjoint of the upsample of `prev`). */
+int pg_torgb_bwd_data(const float* g, const float* w, float* gx,
+                      int N, int C, int H, int W, int Cin, int down, float mul_scale, pg_stream_t stream);
+
+/* dw[c][ci] += mul_scale * sum_pix g[pix,c]*x[pix,ci];  db[c] += mul * sum_pix g[pix,c].       */
+int pg_torgb_wgrad(const float* g, const float* x, float* dw, float* db,
+                   int N, int C, int H, int W, int Cin, int down, float mul_scale, float mul,
+                   pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2x2 average pool on NHWC features with the D-side fade-in blend fused.
+ * Replaces F.avg_pool2d network.py:229,238 and `h*alpha + (1-alpha)*preult_rgb` network.py:233.
+ *   y = a * avgpool2(x) + (other ? b * other : 0)        x:[N][2H][2W][C]  y,other:[N][H][W][C] */
+int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
+                    float a, float b, pg_stream_t stream);
+
+/* Adjoint: gx[n,h,w,c] = mul * 0.25 * gy[n,h/2,w/2,c] * (mask ? (mask[n,h,w,c]>0 ? 1 : mask_slope) : 1)
+ * gx,mask: [N][2H][2W][C]   gy: [N][H][W][C]                                                   */
+int pg_avgpool2_bwd(const float* gy, const float* mask, float* gx, int N, int H, int W, int C,
+                    float mul, float mask_slope, pg_stream_t stream);
+
+/* Adjoint of the nearest x2 upsample (network.py:127,129): gx[n,h,w,c] = sum_{2x2} g[n,2h+i,2w+j,c]. */
+int pg_upsample2_bwd(const float* g, float* gx, int N, int H, int W, int C, pg_stream_t stream);
+
+/* y = a*x + b*other (other may be NULL), y = (mask>0?1:mask_slope) * that.  Flat length n % 4 == 0. */
+int pg_axpby_mask(const float* x, const float* other, const float* mask, float* y, int64_t n,
+                  float a, float b, float mask_slope, pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PixelNorm over channels.  Replaces network.py:37-40 and :120-123.
+ *   r[p] = rsqrt(mean_c(x[p,c]^2) + eps);  y[p,c] = x[p,c]*r[p]     (y may alias x)            */
+int pg_pixelnorm_fwd(const float* x, float* y, float* r, int64_t P, int C, float eps, pg_stream_t stream);
+
+/* Adjoint of (LeakyReLU -> PixelNorm) given the saved OUTPUT y and r:
+ *   gh = r * (gy - y * mean_c(gy*y));   gz = gh * (y>0 ? 1 : slope)          (gz may alias gy)
+ * r == NULL: PixelNorm absent, only the LeakyReLU mask is applied.                             */
+int pg_pixelnorm_lrelu_bwd(const float* gy, const float* y, const float* r, float* gz,
+                           int64_t P, int C, float slope, pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Minibatch stddev (network.py:174-187): ONE scalar per group over the whole [n,H,W,C] tensor.
+ * x: [NB][HW][C]   y: [NB][HW][CP] (CP >= C+1, CP % 4 == 0; channels > C are zero-filled)
+ * NB = G groups of n consecutive images.  stats[g] = {mu, sigma}.
+ *   y[...,:C] = x;  y[...,C] = sigma_g = sqrt(mean((x-mu)^2) + 1e-8)                           */
+int pg_mbstd_fwd(const float* x, float* y, float* stats, int G, int n, int HW, int C, int CP,
+                 pg_stream_t stream);
+
+/* Tangent (forward-mode) of the above, used by the gradient-penalty second-order pass:
+ *   ty[...,:C] = tx;  ty[...,C] = <x-mu, tx> / (M*sigma);  tstats[g] = {mean(tx), <x-mu,tx>}    */
+int pg_mbstd_tangent(const float* x, const float* tx, const float* stats, float* ty, float* tstats,
+                     int G, int n, int HW, int C, int CP, pg_stream_t stream);
+
+/* Adjoint: gx = (gy[...,:C] + Gs*(x-mu)/(M*sigma) + hvp) * (x>0 ? 1 : mask_slope),  Gs = sum gy[...,C]
+ *   hvp (only when tx != NULL; Gs then comes from `gy_first`, the adjoint of the FIRST backward):
+ *   hvp = Gs1/(M*sigma) * ((tx - mean tx) - (x-mu)*<x-mu,tx>/(M*sigma^2)),  Gs1 = sum gy_first[...,C]
+ * gy may be NULL (then only the hvp term is produced).  `apply_mask`==0 skips the LeakyReLU mask. */
+int pg_mbstd_bwd(const float* gy, const float* x, const float* stats,
+                 const float* tx, const float* tstats, const float* gy_first,
+                 float* gx, int G, int n, int HW, int C, int CP, int apply_mask, float mask_slope,
+                 pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Final nn.Linear(nf0, 1)  network.py:219,239.   s[n] = sum_c h[n,c]*w[c] + b                  */
+int pg_linear1_fwd(const float* h, const float* w, const float* b, float* s, int N, int C, pg_stream_t stream);
+/* gh[n,c] = gs[n]*w[c] * (mask ? (mask[n,c]>0?1:mask_slope) : 1)                               */
+int pg_linear1_bwd_data(const float* gs, const float* w, const float* mask, float* gh, int N, int C,
+                        float mask_slope, pg_stream_t stream);
+/* dw[c] += sum_n gs[n]*h[n,c];  db[0] += sum_n gs[n]                                          */
+int pg_linear1_wgrad(const float* gs, const float* h, float* dw, float* db, int N, int C, pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * WGAN-GP pieces  (wgan_gp_loss.py).
+ * mixed = real*(1-m[n]) + fake*m[n]            wgan_gp_loss.py:8-10,19   (E elements per image) */
+int pg_gp_mix(const float* real, const float* fake, const float* m, float* mixed, int N, int64_t E,
+              pg_stream_t stream);
+/* ss[n] = sum_e g[n,e]^2   (ss must be zeroed by the caller; atomic accumulation)              */
+int pg_row_sumsq(const float* g, float* ss, int N, int64_t E, pg_stream_t stream);
+/* gp[n] = lambda*(sqrt(ss[n])-target)^2/target^2                        wgan_gp_loss.py:31
+ * u[n,e] = inv_n * 2*lambda*(norm-target)/(target^2*norm) * g[n,e]   (seed of the tangent pass) */
+int pg_gp_seed(const float* g, const float* ss, float* gp, float* u, int N, int64_t E,
+               float lambda, float target, float inv_n, pg_stream_t stream);
+/* Loss algebra wgan_gp_loss.py:48,55,62: scores s = [real(N) | fake(N) | mixed(N)].
+ *   d_real_loss[n] = -s_r + eps*s_r^2;  d_fake_loss[n] = s_f;  d_cost = mean(d_fake+d_real+gp)
+ *   gscore[0:N] = (-1+2*eps*s_r)/N;  gscore[N:2N] = 1/N;  gscore[2N:3N] = 0                   */
+int pg_d_loss(const float* s, const float* gp, float* d_cost, float* d_real_loss, float* d_fake_loss,
+              float* gscore, int N, float eps, pg_stream_t stream);
+/* g_cost = mean(-s);  gscore[n] = -1/N                                  wgan_gp_loss.py:72-73   */
+int pg_g_loss(const float* s, float* g_cost, float* gscore, int N, pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Adam (train.py:148-149,195; torch-2.10 form) on one flat segment, gradient pre-scaled by
+ * grad_scale (1/world_size after the RCCL sum).  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)   */
+int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+            float eps, float bc1, float bc2_sqrt, float grad_scale, pg_stream_t stream);
+
+/* Utility: async fill with zero bytes.                                                         */
+int pg_zero(void* p, int64_t bytes, pg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGGAN_HIP_H */

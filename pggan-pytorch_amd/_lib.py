@@ -1,0 +1,98 @@
+"""ctypes binding of libpggan_hip.so (C-ABI declared in include/pggan_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol is absent the
+import of the product path fails loudly (``PgganLibraryError``).  Build it with
+``python __graft_entry__.py`` (or ``__graft_entry__.build()``)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpggan_hip.so')
+ABI_VERSION = 1
+
+
+class PgganLibraryError(RuntimeError):
+    pass
+
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_int64
+F = ctypes.c_float
+
+# name -> argtypes (stream is always the last void*).  Mirrors include/pggan_hip.h 1:1.
+SIGNATURES = {
+    'pg_abi_version': [],
+    'pg_conv2d_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
+    'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
+    'pg_pack_dgrad_weights': [P, P, I, I, I, P],
+    'pg_fromrgb_fwd': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
+    'pg_fromrgb_bwd_data': [P, P, P, I, I, I, I, I, I, I, F, P],
+    'pg_fromrgb_wgrad': [P, P, P, P, I, I, I, I, I, I, F, P],
+    'pg_torgb_fwd': [P, P, P, P, P, I, I, I, I, I, F, F, F, P],
+    'pg_torgb_bwd_data': [P, P, P, I, I, I, I, I, I, F, P],
+    'pg_torgb_wgrad': [P, P, P, P, I, I, I, I, I, I, F, F, P],
+    'pg_avgpool2_fwd': [P, P, P, I, I, I, I, F, F, P],
+    'pg_avgpool2_bwd': [P, P, P, I, I, I, I, F, F, P],
+    'pg_upsample2_bwd': [P, P, I, I, I, I, P],
+    'pg_axpby_mask': [P, P, P, P, L, F, F, F, P],
+    'pg_pixelnorm_fwd': [P, P, P, L, I, F, P],
+    'pg_pixelnorm_lrelu_bwd': [P, P, P, P, L, I, F, P],
+    'pg_mbstd_fwd': [P, P, P, I, I, I, I, I, P],
+    'pg_mbstd_tangent': [P, P, P, P, P, I, I, I, I, I, P],
+    'pg_mbstd_bwd': [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+    'pg_linear1_fwd': [P, P, P, P, I, I, P],
+    'pg_linear1_bwd_data': [P, P, P, P, I, I, F, P],
+    'pg_linear1_wgrad': [P, P, P, P, I, I, P],
+    'pg_gp_mix': [P, P, P, P, I, L, P],
+    'pg_row_sumsq': [P, P, I, L, P],
+    'pg_gp_seed': [P, P, P, P, I, L, F, F, F, P],
+    'pg_d_loss': [P, P, P, P, P, P, I, F, P],
+    'pg_g_loss': [P, P, P, I, P],
+    'pg_adam': [P, P, P, P, L, F, F, F, F, F, F, F, P],
+    'pg_zero': [P, L, P],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once and declare every prototype.  Raises PgganLibraryError."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgganLibraryError(
+            'libpggan_hip.so not found at %s: the HIP extension is not built (run '
+            '`python __graft_entry__.py`). There is no CPU fallback.' % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise PgganLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise PgganLibraryError('symbol %s missing from %s' % (name, LIB_PATH))
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    v = lib.pg_abi_version()
+    if v != ABI_VERSION:
+        raise PgganLibraryError('ABI version mismatch: library %d, binding %d' % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: 'PG_E_ARG (bad dimension / null pointer)', -2: 'PG_E_ALIGN (channel count / alignment)',
+        -3: 'PG_E_UNSUP (unsupported configuration)'}
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point and raise on a non-zero return."""
+    fn = getattr(load(), name)
+    check(fn(*args), name)

@@ -1,0 +1,623 @@
+// HBM-streaming and small-reduction kernels of the PGGAN hot path: pooling / upsample adjoint,
+// fade-in blends, PixelNorm, minibatch-stddev (forward, adjoint, tangent, Hessian-vector term),
+// the final Linear(nf0,1), WGAN-GP mixing / norms / seeds, loss algebra and Adam.
+// All are float4-vectorised, grid-stride, with wavefront (64-lane) shuffle reductions.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pggan_hip.h"
+
+namespace {
+
+inline int grid_for(size_t total, int block = 256, int cap = 256 * 16)
+{
+    size_t g = (total + block - 1) / block;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x == 1024 or 256 (multiple of 64); result valid in every thread.
+__device__ __forceinline__ float block_sum(float v, float* sh)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
+
+__device__ __forceinline__ float4 mask4(float4 v, float4 m, float slope)
+{
+    v.x *= m.x > 0.f ? 1.f : slope; v.y *= m.y > 0.f ? 1.f : slope;
+    v.z *= m.z > 0.f ? 1.f : slope; v.w *= m.w > 0.f ? 1.f : slope;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------- pooling
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ other,
+                                                           float* __restrict__ y, int N, int H, int W, int C4, float a, float b)
+{
+    const size_t total = (size_t)N * H * W * C4;
+    const size_t rs = (size_t)2 * W * C4;                 // input row stride in float4
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* o4 = reinterpret_cast<const float4*>(other);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        size_t r = idx / C4;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); const size_t n = r / H;
+        const size_t base = ((n * 2 * H + 2 * h) * 2 * W + 2 * w) * C4 + c;
+        const float4 p0 = x4[base], p1 = x4[base + C4], p2 = x4[base + rs], p3 = x4[base + rs + C4];
+        float4 v;
+        v.x = ((p0.x + p1.x) + (p2.x + p3.x)) * 0.25f; v.y = ((p0.y + p1.y) + (p2.y + p3.y)) * 0.25f;
+        v.z = ((p0.z + p1.z) + (p2.z + p3.z)) * 0.25f; v.w = ((p0.w + p1.w) + (p2.w + p3.w)) * 0.25f;
+        if (other) {
+            const float4 q = o4[idx];
+            v.x = v.x * a + b * q.x; v.y = v.y * a + b * q.y; v.z = v.z * a + b * q.z; v.w = v.w * a + b * q.w;
+        } else if (a != 1.f) { v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
+        y4[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mask,
+                                                           float* __restrict__ gx, int N, int H, int W, int C4,
+                                                           float mul, float mask_slope)
+{
+    // one thread per INPUT (fine) float4
+    const int H2 = 2 * H, W2 = 2 * W;
+    const size_t total = (size_t)N * H2 * W2 * C4;
+    const float4* g4 = reinterpret_cast<const float4*>(gy);
+    const float4* m4 = reinterpret_cast<const float4*>(mask);
+    float4* o4 = reinterpret_cast<float4*>(gx);
+    const float k = mul * 0.25f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        size_t r = idx / C4;
+        const int w = (int)(r % W2); r /= W2;
+        const int h = (int)(r % H2); const size_t n = r / H2;
+        float4 v = g4[((n * H + (h >> 1)) * W + (w >> 1)) * C4 + c];
+        v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+        if (mask) v = mask4(v, m4[idx], mask_slope);
+        o4[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx,
+                                                            int N, int H, int W, int C4)
+{
+    const size_t total = (size_t)N * H * W * C4;
+    const size_t rs = (size_t)2 * W * C4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* o4 = reinterpret_cast<float4*>(gx);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        size_t r = idx / C4;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); const size_t n = r / H;
+        const size_t base = ((n * 2 * H + 2 * h) * 2 * W + 2 * w) * C4 + c;
+        const float4 p0 = g4[base], p1 = g4[base + C4], p2 = g4[base + rs], p3 = g4[base + rs + C4];
+        float4 v;
+        v.x = (p0.x + p1.x) + (p2.x + p3.x); v.y = (p0.y + p1.y) + (p2.y + p3.y);
+        v.z = (p0.z + p1.z) + (p2.z + p3.z); v.w = (p0.w + p1.w) + (p2.w + p3.w);
+        o4[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpby_mask_kernel(const float* __restrict__ x, const float* __restrict__ other,
+                                                         const float* __restrict__ mask, float* __restrict__ y,
+                                                         size_t n4, float a, float b, float mask_slope)
+{
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* o4 = reinterpret_cast<const float4*>(other);
+    const float4* m4 = reinterpret_cast<const float4*>(mask);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = x4[i];
+        v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+        if (other) { const float4 q = o4[i]; v.x += b * q.x; v.y += b * q.y; v.z += b * q.z; v.w += b * q.w; }
+        if (mask) v = mask4(v, m4[i], mask_slope);
+        y4[i] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------- pixelnorm
+// LPP lanes cooperate on one pixel (LPP = power of two <= 64, each lane strides over C in float4).
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int o = LPP >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            float* __restrict__ r, size_t P, int C, float eps)
+{
+    // all LPP lanes of a group share `pix`, so a group enters/leaves the loop together and the
+    // xor-shuffles below only ever read lanes of the own (active) group.
+    const int C4 = C >> 2;
+    const int sub = threadIdx.x % LPP;
+    const size_t pstride = (size_t)gridDim.x * (256 / LPP);
+    for (size_t pix = (size_t)blockIdx.x * (256 / LPP) + threadIdx.x / LPP; pix < P; pix += pstride) {
+        const float4* xp = reinterpret_cast<const float4*>(x + pix * C);
+        float s = 0.f;
+        for (int c = sub; c < C4; c += LPP) { const float4 v = xp[c]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+        s = group_sum<LPP>(s);
+        const float rr = rsqrtf(s / (float)C + eps);
+        float4* yp = reinterpret_cast<float4*>(y + pix * C);
+        for (int c = sub; c < C4; c += LPP) { float4 v = xp[c]; v.x *= rr; v.y *= rr; v.z *= rr; v.w *= rr; yp[c] = v; }
+        if (sub == 0 && r) r[pix] = rr;
+    }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void pixelnorm_lrelu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                                  const float* __restrict__ r, float* __restrict__ gz,
+                                                                  size_t P, int C, float slope)
+{
+    const int C4 = C >> 2;
+    const int sub = threadIdx.x % LPP;
+    const size_t pstride = (size_t)gridDim.x * (256 / LPP);
+    for (size_t pix = (size_t)blockIdx.x * (256 / LPP) + threadIdx.x / LPP; pix < P; pix += pstride) {
+        const float4* gp = reinterpret_cast<const float4*>(gy + pix * C);
+        const float4* yp = reinterpret_cast<const float4*>(y + pix * C);
+        float s = 0.f;
+        if (r) for (int c = sub; c < C4; c += LPP) {
+            const float4 g = gp[c], v = yp[c];
+            s += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
+        }
+        s = group_sum<LPP>(s);
+        const float rr = r ? r[pix] : 1.f;
+        const float mean = r ? s / (float)C : 0.f;
+        float4* op = reinterpret_cast<float4*>(gz + pix * C);
+        for (int c = sub; c < C4; c += LPP) {
+            const float4 g = gp[c], v = yp[c];
+            float4 o;
+            o.x = rr * (g.x - v.x * mean) * (v.x > 0.f ? 1.f : slope);
+            o.y = rr * (g.y - v.y * mean) * (v.y > 0.f ? 1.f : slope);
+            o.z = rr * (g.z - v.z * mean) * (v.z > 0.f ? 1.f : slope);
+            o.w = rr * (g.w - v.w * mean) * (v.w > 0.f ? 1.f : slope);
+            op[c] = o;
+        }
+    }
+}
+
+inline int pick_lpp(int C) { int c4 = C >> 2; int l = 1; while (l < c4 && l < 64) l <<= 1; return l; }
+
+// ------------------------------------------------------------------------------ minibatch stddev
+// One 1024-thread workgroup per group (the tensor is n*HW*C <= a few 100 K floats, L2-resident).
+__global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ stats, int n, int HW, int C, int CP)
+{
+    __shared__ float sh[16];
+    const int g = blockIdx.x;
+    const size_t M = (size_t)n * HW * C;
+    const float* xg = x + (size_t)g * M;
+    const float4* x4 = reinterpret_cast<const float4*>(xg);
+    const size_t M4 = M >> 2;
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < M4; i += blockDim.x) { const float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
+    const float mu = block_sum(s, sh) / (float)M;
+    float q = 0.f;
+    for (size_t i = threadIdx.x; i < M4; i += blockDim.x) {
+        const float4 v = x4[i];
+        const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float sigma = sqrtf(block_sum(q, sh) / (float)M + 1.0e-8f);
+    if (threadIdx.x == 0) { stats[2 * g] = mu; stats[2 * g + 1] = sigma; }
+    // write y: copy + sigma channel + zero padding
+    const int C4 = C >> 2, CP4 = CP >> 2;
+    const size_t rows = (size_t)n * HW;
+    float4* y4 = reinterpret_cast<float4*>(y + (size_t)g * rows * CP);
+    for (size_t i = threadIdx.x; i < rows * CP4; i += blockDim.x) {
+        const size_t row = i / CP4; const int c = (int)(i % CP4);
+        float4 v;
+        if (c < C4) v = x4[row * C4 + c];
+        else if (c == C4) v = make_float4(sigma, 0.f, 0.f, 0.f);
+        else v = make_float4(0.f, 0.f, 0.f, 0.f);
+        y4[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(1024) void mbstd_tangent_kernel(const float* __restrict__ x, const float* __restrict__ tx,
+                                                             const float* __restrict__ stats, float* __restrict__ ty,
+                                                             float* __restrict__ tstats, int n, int HW, int C, int CP)
+{
+    __shared__ float sh[16];
+    const int g = blockIdx.x;
+    const size_t M = (size_t)n * HW * C, M4 = M >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)g * M);
+    const float4* t4 = reinterpret_cast<const float4*>(tx + (size_t)g * M);
+    const float mu = stats[2 * g], sigma = stats[2 * g + 1];
+    float s = 0.f, d = 0.f;
+    for (size_t i = threadIdx.x; i < M4; i += blockDim.x) {
+        const float4 v = x4[i], t = t4[i];
+        s += (t.x + t.y) + (t.z + t.w);
+        d += (v.x - mu) * t.x + (v.y - mu) * t.y + (v.z - mu) * t.z + (v.w - mu) * t.w;
+    }
+    const float tmean = block_sum(s, sh) / (float)M;
+    const float dot = block_sum(d, sh);
+    const float tsigma = dot / ((float)M * sigma);
+    if (threadIdx.x == 0) { tstats[2 * g] = tmean; tstats[2 * g + 1] = dot; }
+    const int C4 = C >> 2, CP4 = CP >> 2;
+    const size_t rows = (size_t)n * HW;
+    float4* y4 = reinterpret_cast<float4*>(ty + (size_t)g * rows * CP);
+    for (size_t i = threadIdx.x; i < rows * CP4; i += blockDim.x) {
+        const size_t row = i / CP4; const int c = (int)(i % CP4);
+        float4 v;
+        if (c < C4) v = t4[row * C4 + c];
+        else if (c == C4) v = make_float4(tsigma, 0.f, 0.f, 0.f);
+        else v = make_float4(0.f, 0.f, 0.f, 0.f);
+        y4[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                         const float* __restrict__ stats, const float* __restrict__ tx,
+                                                         const float* __restrict__ tstats, const float* __restrict__ gy_first,
+                                                         float* __restrict__ gx, int n, int HW, int C, int CP,
+                                                         int apply_mask, float mask_slope)
+{
+    __shared__ float sh[16];
+    const int g = blockIdx.x;
+    const size_t rows = (size_t)n * HW;
+    const size_t M = rows * C;
+    const float mu = stats[2 * g], sigma = stats[2 * g + 1];
+    float gs = 0.f, gs1 = 0.f;
+    if (gy) for (size_t r = threadIdx.x; r < rows; r += blockDim.x) gs += gy[((size_t)g * rows + r) * CP + C];
+    if (tx) for (size_t r = threadIdx.x; r < rows; r += blockDim.x) gs1 += gy_first[((size_t)g * rows + r) * CP + C];
+    const float Gs = gy ? block_sum(gs, sh) : 0.f;
+    const float Gs1 = tx ? block_sum(gs1, sh) : 0.f;
+    const float invMs = 1.f / ((float)M * sigma);
+    const float k1 = Gs * invMs;
+    float tmean = 0.f, k2 = 0.f, k3 = 0.f;
+    if (tx) {
+        tmean = tstats[2 * g];
+        const float dot = tstats[2 * g + 1];
+        k2 = Gs1 * invMs;                                   // multiplies (tx - mean tx)
+        k3 = k2 * dot / ((float)M * sigma * sigma);         // multiplies (x - mu)
+    }
+    const int C4 = C >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)g * M);
+    const float4* t4 = tx ? reinterpret_cast<const float4*>(tx + (size_t)g * M) : nullptr;
+    float4* o4 = reinterpret_cast<float4*>(gx + (size_t)g * M);
+    for (size_t i = threadIdx.x; i < rows * C4; i += blockDim.x) {
+        const size_t row = i / C4; const int c = (int)(i % C4);
+        const float4 xv = x4[i];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy) v = *reinterpret_cast<const float4*>(gy + ((size_t)g * rows + row) * CP + 4 * c);
+        const float kx = k1 - k3;
+        v.x += kx * (xv.x - mu); v.y += kx * (xv.y - mu); v.z += kx * (xv.z - mu); v.w += kx * (xv.w - mu);
+        if (tx) {
+            const float4 t = t4[i];
+            v.x += k2 * (t.x - tmean); v.y += k2 * (t.y - tmean); v.z += k2 * (t.z - tmean); v.w += k2 * (t.w - tmean);
+        }
+        if (apply_mask) v = mask4(v, xv, mask_slope);
+        o4[i] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------- Linear(C,1)
+__global__ __launch_bounds__(64) void linear1_fwd_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ s, int C)
+{
+    const int n = blockIdx.x;
+    float a = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) a = fmaf(h[(size_t)n * C + c], w[c], a);
+    a = wave_sum(a);
+    if (threadIdx.x == 0) s[n] = a + (b ? b[0] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void linear1_bwd_data_kernel(const float* __restrict__ gs, const float* __restrict__ w,
+                                                               const float* __restrict__ mask, float* __restrict__ gh,
+                                                               int N, int C, float mask_slope)
+{
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const size_t n = i / C;
+        float v = gs[n] * w[c];
+        if (mask) v *= mask[i] > 0.f ? 1.f : mask_slope;
+        gh[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void linear1_wgrad_kernel(const float* __restrict__ gs, const float* __restrict__ h,
+                                                            float* __restrict__ dw, float* __restrict__ db, int N, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float a = 0.f;
+        for (int n = 0; n < N; ++n) a = fmaf(gs[n], h[(size_t)n * C + c], a);
+        dw[c] += a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && db) {
+        float a = 0.f;
+        for (int n = 0; n < N; ++n) a += gs[n];
+        db[0] += a;
+    }
+}
+
+// ------------------------------------------------------------------------------------- WGAN-GP
+__global__ __launch_bounds__(256) void gp_mix_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                     const float* __restrict__ m, float* __restrict__ mixed, size_t E4)
+{
+    const int n = blockIdx.y;
+    const float mf = m[n], mr = 1.f - mf;
+    const float4* r4 = reinterpret_cast<const float4*>(real) + (size_t)n * E4;
+    const float4* f4 = reinterpret_cast<const float4*>(fake) + (size_t)n * E4;
+    float4* o4 = reinterpret_cast<float4*>(mixed) + (size_t)n * E4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < E4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = r4[i], b = f4[i];
+        o4[i] = make_float4(a.x * mr + b.x * mf, a.y * mr + b.y * mf, a.z * mr + b.z * mf, a.w * mr + b.w * mf);
+    }
+}
+
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ g, float* __restrict__ ss, size_t E4)
+{
+    __shared__ float sh[16];
+    const int n = blockIdx.y;
+    const float4* g4 = reinterpret_cast<const float4*>(g) + (size_t)n * E4;
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < E4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = g4[i]; s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) atomicAdd(ss + n, s);
+}
+
+__global__ __launch_bounds__(256) void gp_seed_kernel(const float* __restrict__ g, const float* __restrict__ ss,
+                                                      float* __restrict__ gp, float* __restrict__ u, size_t E4,
+                                                      float lambda, float target, float inv_n)
+{
+    const int n = blockIdx.y;
+    const float norm = sqrtf(ss[n]);
+    const float d = norm - target;
+    const float coef = norm > 0.f ? inv_n * 2.f * lambda * d / (target * target * norm) : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) gp[n] = d * d * lambda / (target * target);
+    const float4* g4 = reinterpret_cast<const float4*>(g) + (size_t)n * E4;
+    float4* u4 = reinterpret_cast<float4*>(u) + (size_t)n * E4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < E4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        u4[i] = make_float4(v.x * coef, v.y * coef, v.z * coef, v.w * coef);
+    }
+}
+
+__global__ __launch_bounds__(64) void d_loss_kernel(const float* __restrict__ s, const float* __restrict__ gp,
+                                                    float* __restrict__ d_cost, float* __restrict__ d_real_loss,
+                                                    float* __restrict__ d_fake_loss, float* __restrict__ gscore,
+                                                    int N, float eps)
+{
+    float acc = 0.f;
+    const float invn = 1.f / (float)N;
+    for (int n = threadIdx.x; n < N; n += 64) {
+        const float sr = s[n], sf = s[N + n];
+        const float rl = -sr + sr * sr * eps;
+        d_real_loss[n] = rl; d_fake_loss[n] = sf;
+        acc += sf + rl + gp[n];
+        gscore[n] = (-1.f + 2.f * eps * sr) * invn;
+        gscore[N + n] = invn;
+        gscore[2 * N + n] = 0.f;
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) d_cost[0] = acc * invn;
+}
+
+__global__ __launch_bounds__(64) void g_loss_kernel(const float* __restrict__ s, float* __restrict__ g_cost,
+                                                    float* __restrict__ gscore, int N)
+{
+    float acc = 0.f;
+    const float invn = 1.f / (float)N;
+    for (int n = threadIdx.x; n < N; n += 64) { acc -= s[n]; gscore[n] = -invn; }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) g_cost[0] = acc * invn;
+}
+
+// ---------------------------------------------------------------------------------------- Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                   float step_size, float beta1, float beta2, float eps,
+                                                   float inv_bc2_sqrt, float grad_scale)
+{
+    const size_t n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+#define ADAM1(P, G, Mm, V) { const float g_ = (G) * grad_scale; Mm = Mm * beta1 + omb1 * g_; V = V * beta2 + omb2 * g_ * g_; \
+                             P -= step_size * Mm / (sqrtf(V) * inv_bc2_sqrt + eps); }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i]; const float4 gg = g4[i];
+        ADAM1(pp.x, gg.x, mm.x, vv.x) ADAM1(pp.y, gg.y, mm.y, vv.y) ADAM1(pp.z, gg.z, mm.z, vv.z) ADAM1(pp.w, gg.w, mm.w, vv.w)
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    const size_t tail0 = n4 << 2;
+    if (blockIdx.x == 0 && threadIdx.x < (n - tail0)) {
+        const size_t i = tail0 + threadIdx.x;
+        float pp = p[i], mm = m[i], vv = v[i];
+        ADAM1(pp, g[i], mm, vv)
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+#undef ADAM1
+}
+
+}  // namespace
+
+#define LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__); \
+    return (int)hipGetLastError()
+
+extern "C" int pg_abi_version(void) { return 1; }
+
+extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
+                               float a, float b, pg_stream_t stream)
+{
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    LAUNCH(avgpool2_fwd_kernel, dim3(grid_for((size_t)N * H * W * (C >> 2))), dim3(256), 0, stream, x, other, y, N, H, W, C >> 2, a, b);
+}
+
+extern "C" int pg_avgpool2_bwd(const float* gy, const float* mask, float* gx, int N, int H, int W, int C,
+                               float mul, float mask_slope, pg_stream_t stream)
+{
+    if (!gy || !gx || N <= 0 || H <= 0 || W <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    LAUNCH(avgpool2_bwd_kernel, dim3(grid_for((size_t)N * 4 * H * W * (C >> 2))), dim3(256), 0, stream, gy, mask, gx, N, H, W, C >> 2, mul, mask_slope);
+}
+
+extern "C" int pg_upsample2_bwd(const float* g, float* gx, int N, int H, int W, int C, pg_stream_t stream)
+{
+    if (!g || !gx || N <= 0 || H <= 0 || W <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    LAUNCH(upsample2_bwd_kernel, dim3(grid_for((size_t)N * H * W * (C >> 2))), dim3(256), 0, stream, g, gx, N, H, W, C >> 2);
+}
+
+extern "C" int pg_axpby_mask(const float* x, const float* other, const float* mask, float* y, int64_t n,
+                             float a, float b, float mask_slope, pg_stream_t stream)
+{
+    if (!x || !y || n <= 0) return PG_E_ARG;
+    if (n & 3) return PG_E_ALIGN;
+    LAUNCH(axpby_mask_kernel, dim3(grid_for((size_t)n >> 2)), dim3(256), 0, stream, x, other, mask, y, (size_t)n >> 2, a, b, mask_slope);
+}
+
+extern "C" int pg_pixelnorm_fwd(const float* x, float* y, float* r, int64_t P, int C, float eps, pg_stream_t stream)
+{
+    if (!x || !y || P <= 0 || C <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    const int lpp = pick_lpp(C);
+    const int grid = grid_for((size_t)P * lpp);
+    hipStream_t s = (hipStream_t)stream;
+    switch (lpp) {
+#define CASE(L) case L: hipLaunchKernelGGL(pixelnorm_fwd_kernel<L>, dim3(grid), dim3(256), 0, s, x, y, r, (size_t)P, C, eps); break;
+        CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
+#undef CASE
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_pixelnorm_lrelu_bwd(const float* gy, const float* y, const float* r, float* gz,
+                                      int64_t P, int C, float slope, pg_stream_t stream)
+{
+    if (!gy || !y || !gz || P <= 0 || C <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    const int lpp = pick_lpp(C);
+    const int grid = grid_for((size_t)P * lpp);
+    hipStream_t s = (hipStream_t)stream;
+    switch (lpp) {
+#define CASE(L) case L: hipLaunchKernelGGL(pixelnorm_lrelu_bwd_kernel<L>, dim3(grid), dim3(256), 0, s, gy, y, r, gz, (size_t)P, C, slope); break;
+        CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
+#undef CASE
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_mbstd_fwd(const float* x, float* y, float* stats, int G, int n, int HW, int C, int CP, pg_stream_t stream)
+{
+    if (!x || !y || !stats || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
+    if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
+    LAUNCH(mbstd_fwd_kernel, dim3(G), dim3(1024), 0, stream, x, y, stats, n, HW, C, CP);
+}
+
+extern "C" int pg_mbstd_tangent(const float* x, const float* tx, const float* stats, float* ty, float* tstats,
+                                int G, int n, int HW, int C, int CP, pg_stream_t stream)
+{
+    if (!x || !tx || !stats || !ty || !tstats || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
+    if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
+    LAUNCH(mbstd_tangent_kernel, dim3(G), dim3(1024), 0, stream, x, tx, stats, ty, tstats, n, HW, C, CP);
+}
+
+extern "C" int pg_mbstd_bwd(const float* gy, const float* x, const float* stats,
+                            const float* tx, const float* tstats, const float* gy_first,
+                            float* gx, int G, int n, int HW, int C, int CP, int apply_mask, float mask_slope,
+                            pg_stream_t stream)
+{
+    if (!x || !stats || !gx || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
+    if (!gy && !tx) return PG_E_ARG;
+    if (tx && (!tstats || !gy_first)) return PG_E_ARG;
+    if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
+    LAUNCH(mbstd_bwd_kernel, dim3(G), dim3(1024), 0, stream, gy, x, stats, tx, tstats, gy_first, gx, n, HW, C, CP, apply_mask, mask_slope);
+}
+
+extern "C" int pg_linear1_fwd(const float* h, const float* w, const float* b, float* s, int N, int C, pg_stream_t stream)
+{
+    if (!h || !w || !s || N <= 0 || C <= 0) return PG_E_ARG;
+    LAUNCH(linear1_fwd_kernel, dim3(N), dim3(64), 0, stream, h, w, b, s, C);
+}
+
+extern "C" int pg_linear1_bwd_data(const float* gs, const float* w, const float* mask, float* gh, int N, int C,
+                                   float mask_slope, pg_stream_t stream)
+{
+    if (!gs || !w || !gh || N <= 0 || C <= 0) return PG_E_ARG;
+    LAUNCH(linear1_bwd_data_kernel, dim3(grid_for((size_t)N * C)), dim3(256), 0, stream, gs, w, mask, gh, N, C, mask_slope);
+}
+
+extern "C" int pg_linear1_wgrad(const float* gs, const float* h, float* dw, float* db, int N, int C, pg_stream_t stream)
+{
+    if (!gs || !h || !dw || N <= 0 || C <= 0) return PG_E_ARG;
+    LAUNCH(linear1_wgrad_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, gs, h, dw, db, N, C);
+}
+
+extern "C" int pg_gp_mix(const float* real, const float* fake, const float* m, float* mixed, int N, int64_t E, pg_stream_t stream)
+{
+    if (!real || !fake || !m || !mixed || N <= 0 || E <= 0) return PG_E_ARG;
+    if (E & 3) return PG_E_ALIGN;
+    LAUNCH(gp_mix_kernel, dim3(grid_for((size_t)E >> 2, 256, 1024), N), dim3(256), 0, stream, real, fake, m, mixed, (size_t)E >> 2);
+}
+
+extern "C" int pg_row_sumsq(const float* g, float* ss, int N, int64_t E, pg_stream_t stream)
+{
+    if (!g || !ss || N <= 0 || E <= 0) return PG_E_ARG;
+    if (E & 3) return PG_E_ALIGN;
+    LAUNCH(row_sumsq_kernel, dim3(grid_for((size_t)E >> 2, 256 * 8, 256), N), dim3(256), 0, stream, g, ss, (size_t)E >> 2);
+}
+
+extern "C" int pg_gp_seed(const float* g, const float* ss, float* gp, float* u, int N, int64_t E,
+                          float lambda, float target, float inv_n, pg_stream_t stream)
+{
+    if (!g || !ss || !gp || !u || N <= 0 || E <= 0) return PG_E_ARG;
+    if (E & 3) return PG_E_ALIGN;
+    LAUNCH(gp_seed_kernel, dim3(grid_for((size_t)E >> 2, 256, 1024), N), dim3(256), 0, stream, g, ss, gp, u, (size_t)E >> 2, lambda, target, inv_n);
+}
+
+extern "C" int pg_d_loss(const float* s, const float* gp, float* d_cost, float* d_real_loss, float* d_fake_loss,
+                         float* gscore, int N, float eps, pg_stream_t stream)
+{
+    if (!s || !gp || !d_cost || !d_real_loss || !d_fake_loss || !gscore || N <= 0) return PG_E_ARG;
+    LAUNCH(d_loss_kernel, dim3(1), dim3(64), 0, stream, s, gp, d_cost, d_real_loss, d_fake_loss, gscore, N, eps);
+}
+
+extern "C" int pg_g_loss(const float* s, float* g_cost, float* gscore, int N, pg_stream_t stream)
+{
+    if (!s || !g_cost || !gscore || N <= 0) return PG_E_ARG;
+    LAUNCH(g_loss_kernel, dim3(1), dim3(64), 0, stream, s, g_cost, gscore, N);
+}
+
+extern "C" int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float bc1, float bc2_sqrt, float grad_scale, pg_stream_t stream)
+{
+    if (!p || !g || !m || !v || n <= 0) return PG_E_ARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return PG_E_ALIGN;
+    LAUNCH(adam_kernel, dim3(grid_for(((size_t)n + 3) >> 2, 256, 2048)), dim3(256), 0, stream, p, g, m, v, (size_t)n,
+           lr / bc1, beta1, beta2, eps, 1.f / bc2_sqrt, grad_scale);
+}
+
+extern "C" int pg_zero(void* p, int64_t bytes, pg_stream_t stream)
+{
+    if (!p || bytes < 0) return PG_E_ARG;
+    if (bytes == 0) return 0;
+    return (int)hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,367 @@
+// fromRGB / toRGB: the 1x1 convolutions at the image boundary (C_img = 1..4 channels).
+// These are HBM-streaming kernels (arithmetic intensity ~1 FLOP/B): no MFMA, coalesced float4
+// traffic on the NHWC feature side, row-contiguous traffic on the NCHW image side, the
+// fade-in blend / 2x2 pooling of the image fused so the image is touched exactly once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pggan_hip.h"
+
+namespace {
+
+constexpr int MAXC = 4;
+
+__device__ __forceinline__ float img_fetch(const float* img, int n, int c, int h, int w, int C, int H, int W, int pool)
+{
+    if (!pool) return img[(((size_t)n * C + c) * H + h) * W + w];
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* p = img + (((size_t)n * C + c) * H2 + 2 * h) * W2 + 2 * w;
+    return ((p[0] + p[1]) + (p[W2] + p[W2 + 1])) * 0.25f;
+}
+
+// thread -> (pixel, 4 couts).  y[pix][co4] float4 stores are fully coalesced.
+__global__ __launch_bounds__(256) void fromrgb_fwd_kernel(
+    const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ mask, float* __restrict__ y,
+    int N, int C, int H, int W, int Cout, int pool, float scale, float slope, float mask_slope)
+{
+    const int c4n = Cout >> 2;
+    const size_t total = (size_t)N * H * W * c4n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const size_t pix = idx / c4n;
+        const int wv = (int)(pix % W);
+        const size_t r = pix / W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        float xin[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) xin[c] = c < C ? img_fetch(img, n, c, h, wv, C, H, W, pool) : 0.f;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* wr = w + (size_t)(4 * c4 + j) * C;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C) a = fmaf(xin[c], wr[c], a);
+            o[j] = a * scale;
+        }
+        const size_t off = pix * Cout + 4 * c4;
+        if (mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(mask + off);
+            o[0] *= mk.x > 0.f ? 1.f : mask_slope; o[1] *= mk.y > 0.f ? 1.f : mask_slope;
+            o[2] *= mk.z > 0.f ? 1.f : mask_slope; o[3] *= mk.w > 0.f ? 1.f : mask_slope;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = o[j] + (bias ? bias[4 * c4 + j] : 0.f);
+                o[j] = v > 0.f ? v : v * slope;
+            }
+        }
+        *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// thread -> pixel; loops over Cout in float4 steps.
+__global__ __launch_bounds__(256) void fromrgb_bwd_data_kernel(
+    const float* __restrict__ gz, const float* __restrict__ w, float* __restrict__ gimg,
+    int N, int C, int H, int W, int Cout, int pool, int accumulate, float scale)
+{
+    extern __shared__ float wl[];                 // [Cout][C]
+    for (int i = threadIdx.x; i < Cout * C; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+    const size_t total = (size_t)N * H * W;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+        const int wv = (int)(pix % W);
+        const size_t r = pix / W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        float a[MAXC] = {0.f, 0.f, 0.f, 0.f};
+        const float* g = gz + pix * Cout;
+        for (int co = 0; co < Cout; co += 4) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + co);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C) {
+                a[c] = fmaf(gv.x, wl[(co + 0) * C + c], a[c]);
+                a[c] = fmaf(gv.y, wl[(co + 1) * C + c], a[c]);
+                a[c] = fmaf(gv.z, wl[(co + 2) * C + c], a[c]);
+                a[c] = fmaf(gv.w, wl[(co + 3) * C + c], a[c]);
+            }
+        }
+        for (int c = 0; c < C; ++c) {
+            if (!pool) {
+                float* o = gimg + (((size_t)n * C + c) * H + h) * W + wv;
+                const float v = a[c] * scale;
+                *o = accumulate ? *o + v : v;
+            } else {
+                const int H2 = 2 * H, W2 = 2 * W;
+                float* o = gimg + (((size_t)n * C + c) * H2 + 2 * h) * W2 + 2 * wv;
+                const float v = a[c] * scale * 0.25f;
+                if (accumulate) { o[0] += v; o[1] += v; o[W2] += v; o[W2 + 1] += v; }
+                else { o[0] = v; o[1] = v; o[W2] = v; o[W2 + 1] = v; }
+            }
+        }
+    }
+}
+
+// dw[co][c] += scale * sum_pix gz[pix][co]*img[pix][c]; db[co] += sum_pix gz[pix][co].
+// Block: CPB couts per pass x PL pixel lanes; per-block partials reduced in LDS, one atomic each.
+__global__ __launch_bounds__(256) void fromrgb_wgrad_kernel(
+    const float* __restrict__ gz, const float* __restrict__ img, float* __restrict__ dw, float* __restrict__ db,
+    int N, int C, int H, int W, int Cout, int pool, float scale, int pix_per_block)
+{
+    __shared__ float red[256 * (MAXC + 1)];
+    const int cpb = Cout < 256 ? Cout : 256;          // couts handled per pass (Cout is a multiple of 4)
+    const int PL = 256 / cpb;                          // pixel lanes
+    const int col = threadIdx.x % cpb, pl = threadIdx.x / cpb;
+    const size_t total = (size_t)N * H * W;
+    const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+    const size_t p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
+    for (int cbase = 0; cbase < Cout; cbase += cpb) {
+        const int co = cbase + col;
+        float a[MAXC + 1] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pl < PL && co < Cout) {
+            for (size_t pix = p0 + pl; pix < p1; pix += PL) {
+                const int wv = (int)(pix % W);
+                const size_t r = pix / W;
+                const int h = (int)(r % H), n = (int)(r / H);
+                const float g = gz[pix * Cout + co];
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) if (c < C) a[c] = fmaf(g, img_fetch(img, n, c, h, wv, C, H, W, pool), a[c]);
+                a[MAXC] += g;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c <= MAXC; ++c) red[c * 256 + threadIdx.x] = a[c];
+        __syncthreads();
+        if (pl == 0 && co < Cout) {
+#pragma unroll
+            for (int c = 0; c <= MAXC; ++c) {
+                float s = 0.f;
+                for (int q = 0; q < PL; ++q) s += red[c * 256 + q * cpb + col];
+                if (c < C) atomicAdd(dw + (size_t)co * C + c, s * scale);
+                else if (c == MAXC && db) atomicAdd(db + co, s);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// thread -> pixel: out[n,c,h,w] for all c; reads the pixel's Cin features with float4 loads.
+__global__ __launch_bounds__(256) void torgb_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ prev, float* __restrict__ out,
+    int N, int C, int H, int W, int Cin, float scale, float out_mul, float prev_mul)
+{
+    extern __shared__ float wl[];                 // [C][Cin]
+    for (int i = threadIdx.x; i < C * Cin; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+    const size_t total = (size_t)N * H * W;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+        const int wv = (int)(pix % W);
+        const size_t r = pix / W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        float a[MAXC] = {0.f, 0.f, 0.f, 0.f};
+        const float* xp = x + pix * Cin;
+        for (int ci = 0; ci < Cin; ci += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + ci);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C) {
+                const float* wr = wl + c * Cin + ci;
+                a[c] = fmaf(xv.x, wr[0], a[c]); a[c] = fmaf(xv.y, wr[1], a[c]);
+                a[c] = fmaf(xv.z, wr[2], a[c]); a[c] = fmaf(xv.w, wr[3], a[c]);
+            }
+        }
+        for (int c = 0; c < C; ++c) {
+            float v = (a[c] * scale + (bias ? bias[c] : 0.f)) * out_mul;
+            if (prev) v += prev_mul * prev[(((size_t)n * C + c) * (H >> 1) + (h >> 1)) * (W >> 1) + (wv >> 1)];
+            out[(((size_t)n * C + c) * H + h) * W + wv] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ float g_fetch(const float* g, int n, int c, int h, int w, int C, int H, int W, int down)
+{
+    if (!down) return g[(((size_t)n * C + c) * H + h) * W + w];
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* p = g + (((size_t)n * C + c) * H2 + 2 * h) * W2 + 2 * w;
+    return (p[0] + p[1]) + (p[W2] + p[W2 + 1]);
+}
+
+// thread -> (pixel, 4 cins): gx[pix][ci4] = mul_scale * sum_c g[pix,c]*w[c][ci]
+__global__ __launch_bounds__(256) void torgb_bwd_data_kernel(
+    const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ gx,
+    int N, int C, int H, int W, int Cin, int down, float mul_scale)
+{
+    const int c4n = Cin >> 2;
+    const size_t total = (size_t)N * H * W * c4n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const size_t pix = idx / c4n;
+        const int wv = (int)(pix % W);
+        const size_t r = pix / W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            const float gv = g_fetch(g, n, c, h, wv, C, H, W, down);
+            const float4 wv4 = *reinterpret_cast<const float4*>(w + (size_t)c * Cin + 4 * c4);
+            o[0] = fmaf(gv, wv4.x, o[0]); o[1] = fmaf(gv, wv4.y, o[1]);
+            o[2] = fmaf(gv, wv4.z, o[2]); o[3] = fmaf(gv, wv4.w, o[3]);
+        }
+        *reinterpret_cast<float4*>(gx + pix * Cin + 4 * c4) =
+            make_float4(o[0] * mul_scale, o[1] * mul_scale, o[2] * mul_scale, o[3] * mul_scale);
+    }
+}
+
+// dw[c][ci] += mul_scale * sum_pix g[pix,c]*x[pix,ci];  db[c] += mul * sum_pix g[pix,c]
+__global__ __launch_bounds__(256) void torgb_wgrad_kernel(
+    const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
+    int N, int C, int H, int W, int Cin, int down, float mul_scale, float mul, int pix_per_block)
+{
+    __shared__ float red[256 * (MAXC + 1)];
+    const int cpb = Cin < 256 ? Cin : 256;
+    const int PL = 256 / cpb;
+    const int col = threadIdx.x % cpb, pl = threadIdx.x / cpb;
+    const size_t total = (size_t)N * H * W;
+    const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+    const size_t p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
+    for (int cbase = 0; cbase < Cin; cbase += cpb) {
+        const int ci = cbase + col;
+        float a[MAXC + 1] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pl < PL && ci < Cin) {
+            for (size_t pix = p0 + pl; pix < p1; pix += PL) {
+                const int wv = (int)(pix % W);
+                const size_t r = pix / W;
+                const int h = (int)(r % H), n = (int)(r / H);
+                const float xv = x[pix * Cin + ci];
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) if (c < C) {
+                    const float gv = g_fetch(g, n, c, h, wv, C, H, W, down);
+                    a[c] = fmaf(gv, xv, a[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) red[c * 256 + threadIdx.x] = a[c];
+        __syncthreads();
+        if (pl == 0 && ci < Cin) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C) {
+                float s = 0.f;
+                for (int q = 0; q < PL; ++q) s += red[c * 256 + q * cpb + col];
+                atomicAdd(dw + (size_t)c * Cin + ci, s * mul_scale);
+            }
+        }
+        __syncthreads();
+    }
+    // bias: db[c] += mul * sum over this block's pixels of g[pix,c]
+    if (db) {
+        float a[MAXC] = {0.f, 0.f, 0.f, 0.f};
+        for (size_t pix = p0 + threadIdx.x; pix < p1; pix += 256) {
+            const int wv = (int)(pix % W);
+            const size_t r = pix / W;
+            const int h = (int)(r % H), n = (int)(r / H);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C) a[c] += g_fetch(g, n, c, h, wv, C, H, W, down);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) red[c * 256 + threadIdx.x] = a[c];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s)
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) red[c * 256 + threadIdx.x] += red[c * 256 + threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x < C) atomicAdd(db + threadIdx.x, red[threadIdx.x * 256] * mul);
+    }
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 256 * 16)
+{
+    size_t g = (total + block - 1) / block;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int pg_fromrgb_fwd(const float* img, const float* w, const float* bias, const float* mask, float* y,
+                              int N, int C, int H, int W, int Cout, int pool,
+                              float scale, float slope, float mask_slope, pg_stream_t stream)
+{
+    if (!img || !w || !y || N <= 0 || H <= 0 || W <= 0) return PG_E_ARG;
+    if (C < 1 || C > MAXC) return PG_E_UNSUP;
+    if (Cout & 3) return PG_E_ALIGN;
+    const size_t total = (size_t)N * H * W * (Cout >> 2);
+    hipLaunchKernelGGL(fromrgb_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       img, w, bias, mask, y, N, C, H, W, Cout, pool, scale, slope, mask_slope);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_fromrgb_bwd_data(const float* gz, const float* w, float* gimg,
+                                   int N, int C, int H, int W, int Cout, int pool, int accumulate,
+                                   float scale, pg_stream_t stream)
+{
+    if (!gz || !w || !gimg || N <= 0) return PG_E_ARG;
+    if (C < 1 || C > MAXC) return PG_E_UNSUP;
+    if (Cout & 3) return PG_E_ALIGN;
+    const size_t total = (size_t)N * H * W;
+    hipLaunchKernelGGL(fromrgb_bwd_data_kernel, dim3(grid_for(total)), dim3(256), (size_t)Cout * C * sizeof(float),
+                       (hipStream_t)stream, gz, w, gimg, N, C, H, W, Cout, pool, accumulate, scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_fromrgb_wgrad(const float* gz, const float* img, float* dw, float* db,
+                                int N, int C, int H, int W, int Cout, int pool, float scale, pg_stream_t stream)
+{
+    if (!gz || !img || !dw || N <= 0) return PG_E_ARG;
+    if (C < 1 || C > MAXC) return PG_E_UNSUP;
+    if (Cout & 3) return PG_E_ALIGN;
+    const size_t total = (size_t)N * H * W;
+    int blocks = grid_for(total, 64, 1024);
+    const int ppb = (int)((total + blocks - 1) / blocks);
+    blocks = (int)((total + ppb - 1) / ppb);
+    hipLaunchKernelGGL(fromrgb_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       gz, img, dw, db, N, C, H, W, Cout, pool, scale, ppb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_torgb_fwd(const float* x, const float* w, const float* bias, const float* prev, float* out,
+                            int N, int C, int H, int W, int Cin, float scale, float out_mul, float prev_mul,
+                            pg_stream_t stream)
+{
+    if (!x || !w || !out || N <= 0) return PG_E_ARG;
+    if (C < 1 || C > MAXC) return PG_E_UNSUP;
+    if (Cin & 3) return PG_E_ALIGN;
+    const size_t total = (size_t)N * H * W;
+    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(grid_for(total, 256, 256 * 8)), dim3(256), (size_t)C * Cin * sizeof(float),
+                       (hipStream_t)stream, x, w, bias, prev, out, N, C, H, W, Cin, scale, out_mul, prev_mul);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_torgb_bwd_data(const float* g, const float* w, float* gx,
+                                 int N, int C, int H, int W, int Cin, int down, float mul_scale, pg_stream_t stream)
+{
+    if (!g || !w || !gx || N <= 0) return PG_E_ARG;
+    if (C < 1 || C > MAXC) return PG_E_UNSUP;
+    if (Cin & 3) return PG_E_ALIGN;
+    const size_t total = (size_t)N * H * W * (Cin >> 2);
+    hipLaunchKernelGGL(torgb_bwd_data_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       g, w, gx, N, C, H, W, Cin, down, mul_scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_torgb_wgrad(const float* g, const float* x, float* dw, float* db,
+                              int N, int C, int H, int W, int Cin, int down, float mul_scale, float mul,
+                              pg_stream_t stream)
+{
+    if (!g || !x || !dw || N <= 0) return PG_E_ARG;
+    if (C < 1 || C > MAXC) return PG_E_UNSUP;
+    if (Cin & 3) return PG_E_ALIGN;
+    const size_t total = (size_t)N * H * W;
+    int blocks = grid_for(total, 64, 1024);
+    const int ppb = (int)((total + blocks - 1) / blocks);
+    blocks = (int)((total + ppb - 1) / ppb);
+    hipLaunchKernelGGL(torgb_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       g, x, dw, db, N, C, H, W, Cin, down, mul_scale, mul, ppb);
+    return (int)hipGetLastError();
+}

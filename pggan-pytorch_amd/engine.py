@@ -1,0 +1,457 @@
+"""Explicit launch schedules of the PGGAN hot path (no autograd graph, no tracing compiler).
+
+Every pass below is a hand-ordered sequence of the C-ABI kernels (``ops``):
+
+  generator_forward / generator_backward            reference network.py:118-139 + its autograd
+  discriminator forward (batched [real|fake|mixed])  reference network.py:225-240
+  d_backward            first-order adjoint sweep (data-only or data+weights)
+  d_tangent_wgrad       forward-mode (tangent) sweep of the gradient-penalty second-order term
+
+The WGAN-GP double backward (wgan_gp_loss.py:25-31 + trainer.py:98) is NOT done with a generic
+autograd.  With default flags D is piecewise linear except for minibatch-stddev, so
+
+    d/dtheta  sum_i gp_i / N   =   d/dtheta  < u , grad_x S(x^, theta) >        (u held constant)
+                               =   grad_theta of the directional derivative of S along u
+
+which is evaluated as (i) a tangent pass pushing u through the same masked linear maps,
+(ii) weight gradients  tangent_input (x) first-backward-adjoint  per layer, and (iii) the
+minibatch-stddev Hessian-vector term injected into the ordinary batched backward of the mixed
+samples (SURVEY.md §7 "hard parts"; formulas verified against autograd in tests/).
+"""
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------
+def _check_dev(t, what):
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise RuntimeError('%s must be a tensor on the MI355X device (no CPU path exists); got %s'
+                           % (what, getattr(t, 'device', type(t))))
+    if t.dtype != torch.float32:
+        raise RuntimeError('%s must be float32' % what)
+    return t.contiguous()
+
+
+def _wt(net, layer):
+    """Backward-data (flipped/transposed) copy of a conv layer's weights, refreshed lazily."""
+    net._ensure_buffers()
+    ver = net._param_version
+    if getattr(layer, '_wt_ver', None) != ver or layer._wt is None:
+        ops.pack_dgrad_weights(layer.conv.weight.data, layer._wt)
+        layer._wt_ver = ver
+    return layer._wt
+
+
+def _conv(x, layer, N, H, act=True, mask=None, bias=True, ups=False, out=None):
+    """Forward conv (+bias+act) or, with ``mask``, the masked linear map of the tangent pass."""
+    return ops.conv2d(x, layer.conv.weight.data, layer.conv.bias.data if bias else None, N, H, H,
+                      layer.ksize, layer.pad, layer.c, layer.slope if act else 1.0,
+                      mask=mask, mask_slope=layer.slope, ups=ups, out=out)
+
+
+def _dgrad(net, gz, layer, N, Hout, mask=None, mask_slope=0.2):
+    """Adjoint of the conv wrt its input: gz [N,Hout,Hout,Cout] -> [N,Hin,Hin,Cin_store] (* mask)."""
+    return ops.conv2d(gz, _wt(net, layer), None, N, Hout, Hout, layer.ksize, layer.ksize - 1 - layer.pad,
+                      layer.c, 1.0, mask=mask, mask_slope=mask_slope)
+
+
+def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False):
+    ops.conv2d_wgrad(x, gz, layer._gw, layer._gb if bias else None, N, Hin, Hin, layer.ksize, layer.pad,
+                     layer.c, ups=ups)
+
+
+_ONES = {}
+
+
+def _ones(n, device):
+    key = (n, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
+    return _ONES[key]
+
+
+# ------------------------------------------------------------------------------------------
+# Generator
+# ------------------------------------------------------------------------------------------
+def generator_forward(G, z, save=False, out=None):
+    """reference network.py:118-139.  z [N,latent] -> NCHW image [N,C,r,r] (written into ``out``)."""
+    ops.require_gpu()
+    z = _check_dev(z, 'latents')
+    N, L = z.shape
+    if L != G.latent_size or L % 4:
+        raise ValueError('latent size %d (expected %d, multiple of 4)' % (L, G.latent_size))
+    depth, alpha = int(G.depth), float(G.alpha)
+    C = G.num_channels
+    b0 = G.block0
+    ctx = dict(N=N, depth=depth, alpha=alpha, recs=[])
+    if G.normalize_latents:
+        zn, _ = ops.pixelnorm_fwd(z, G.eps)                                   # :120-123
+    else:
+        zn = z
+    ctx['zn'] = zn
+
+    def layer(x, lay, H, ups=False):
+        y = _conv(x, lay, N, H, ups=ups)
+        r = None
+        if lay.pixelnorm:
+            y, r = ops.pixelnorm_fwd(y, lay.eps, inplace=True)
+        return y, r
+
+    y1, r1 = layer(zn.view(N, 1, 1, L), b0.c1, 1)                            # 4x4 conv pad 3 on 1x1
+    y2, r2 = layer(y1, b0.c2, 4)
+    ctx.update(y1=y1, r1=r1, y2=y2, r2=r2)
+    if depth == 0:
+        t = b0.toRGB
+        img = ops.torgb_fwd(y2, t.conv.weight.data, t.conv.bias.data, N, C, 4, 4, t.c, out=out)   # :55-56
+        return (img, ctx) if save else img
+    h, H = y2, 4
+    for i in range(depth):                                                    # :126-130
+        blk = G.blocks[i]
+        H *= 2
+        a1, ra1 = layer(h, blk.c1, H, ups=True)                               # upsample fused into the conv
+        a2, ra2 = layer(a1, blk.c2, H)
+        ctx['recs'].append(dict(blk=blk, inp=h, a1=a1, r1=ra1, a2=a2, r2=ra2, H=H))
+        hprev, h = h, a2
+    t = G.blocks[depth - 1].toRGB
+    prev = None
+    if alpha < 1.0:                                                           # :131-135
+        pt = G.blocks[depth - 2].toRGB if depth > 1 else b0.toRGB
+        prev = ops.torgb_fwd(hprev, pt.conv.weight.data, pt.conv.bias.data, N, C, H // 2, H // 2, pt.c)
+    img = ops.torgb_fwd(h, t.conv.weight.data, t.conv.bias.data, N, C, H, H, t.c, out_mul=alpha,
+                        prev=prev, prev_mul=1.0 - alpha, out=out)             # :138
+    return (img, ctx) if save else img
+
+
+def generator_backward(G, ctx, g_out):
+    """Adjoint sweep of generator_forward: accumulates into G's flat gradient buffer."""
+    G._ensure_buffers()
+    N, depth, alpha = ctx['N'], ctx['depth'], ctx['alpha']
+    C = G.num_channels
+    b0 = G.block0
+    active = [b0.c1, b0.c2]
+    g_extra = None
+    if depth == 0:
+        t = b0.toRGB
+        ops.torgb_wgrad(g_out, ctx['y2'], t._gw, t._gb, N, C, 4, 4, t.c, 1.0)
+        g = ops.torgb_bwd_data(g_out, t.conv.weight.data, N, C, 4, 4, t.c)
+        active.append(t)
+    else:
+        rec = ctx['recs'][-1]
+        H = rec['H']
+        t = rec['blk'].toRGB
+        ops.torgb_wgrad(g_out, rec['a2'], t._gw, t._gb, N, C, H, H, alpha * t.c, alpha)
+        g = ops.torgb_bwd_data(g_out, t.conv.weight.data, N, C, H, H, alpha * t.c)
+        active.append(t)
+        if alpha < 1.0:
+            pt = G.blocks[depth - 2].toRGB if depth > 1 else b0.toRGB
+            ops.torgb_wgrad(g_out, rec['inp'], pt._gw, pt._gb, N, C, H // 2, H // 2, (1 - alpha) * pt.c,
+                            1 - alpha, down=True)
+            g_extra = ops.torgb_bwd_data(g_out, pt.conv.weight.data, N, C, H // 2, H // 2, (1 - alpha) * pt.c, down=True)
+            active.append(pt)
+    for rec in reversed(ctx['recs']):
+        blk, H = rec['blk'], rec['H']
+        c1, c2 = blk.c1, blk.c2
+        gz2 = ops.pixelnorm_lrelu_bwd(g, rec['a2'], rec['r2'], c2.slope, inplace=True)
+        _wgrad(rec['a1'], gz2, c2, N, H)
+        g1 = _dgrad(G, gz2, c2, N, H)
+        gz1 = ops.pixelnorm_lrelu_bwd(g1, rec['a1'], rec['r1'], c1.slope, inplace=True)
+        _wgrad(rec['inp'], gz1, c1, N, H, ups=True)
+        gup = _dgrad(G, gz1, c1, N, H)
+        g = ops.upsample2_bwd(gup)
+        if g_extra is not None:
+            g = ops.axpby_mask(g, other=g_extra, a=1.0, b=1.0, out=g)
+            g_extra = None
+        active += [c1, c2]
+    gz2 = ops.pixelnorm_lrelu_bwd(g, ctx['y2'], ctx['r2'], b0.c2.slope, inplace=True)
+    _wgrad(ctx['y1'], gz2, b0.c2, N, 4)
+    g1 = _dgrad(G, gz2, b0.c2, N, 4)
+    gz1 = ops.pixelnorm_lrelu_bwd(g1, ctx['y1'], ctx['r1'], b0.c1.slope, inplace=True)
+    _wgrad(ctx['zn'].view(N, 1, 1, -1), gz1, b0.c1, N, 1)
+    return active
+
+
+# ------------------------------------------------------------------------------------------
+# Discriminator
+# ------------------------------------------------------------------------------------------
+def d_forward(D, x, groups=1):
+    """reference network.py:225-240 on a batch of ``groups`` independent minibatches stacked along
+    N (minibatch-stddev is evaluated per group).  Returns (scores [NB], ctx with every activation)."""
+    NB, C, r, _ = x.shape
+    depth, alpha = int(D.depth), float(D.alpha)
+    if r != 4 * 2 ** depth or C != D.num_channels:
+        raise ValueError('input %s does not match depth %d / %d channels' % (tuple(x.shape), depth, D.num_channels))
+    nb = len(D.blocks)
+    e = nb - 1 - depth                                                        # blocks[-(depth+1)]  (:227)
+    ctx = dict(NB=NB, groups=groups, depth=depth, alpha=alpha, x=x, recs=[])
+    fr = D.blocks[e].fromRGB
+    cur = ops.fromrgb_fwd(x, fr.conv.weight.data, fr.conv.bias.data, NB, C, r, r, fr.c, fr.slope)
+    H = r
+    a2 = None
+    for k, j in enumerate(range(e, nb)):
+        blk = D.blocks[j]
+        last = (j == nb - 1)
+        rec = dict(blk=blk, inp=cur, H=H, first=(k == 0), last=last)
+        if last:
+            mb, stats = ops.mbstd_fwd(cur, groups, blk.c1.cin_store)          # :168
+            a1 = _conv(mb, blk.c1, NB, H)
+            a2 = _conv(a1, blk.c2, NB, H)                                     # 4x4 pad 0 -> 1x1
+            rec.update(mb=mb, stats=stats, a1=a1, a2=a2)
+        else:
+            a1 = _conv(cur, blk.c1, NB, H)
+            a2 = _conv(a1, blk.c2, NB, H)
+            rec.update(a1=a1, a2=a2)
+            if k == 0 and alpha < 1.0:                                        # :230-233
+                nfr = D.blocks[j + 1].fromRGB
+                pf = ops.fromrgb_fwd(x, nfr.conv.weight.data, nfr.conv.bias.data, NB, C, H // 2, H // 2,
+                                     nfr.c, nfr.slope, pool=True)
+                cur = ops.avgpool2_fwd(a2, pf, alpha, 1.0 - alpha)
+                rec['pf'] = pf
+            else:
+                cur = ops.avgpool2_fwd(a2)                                    # :229,238
+            H //= 2
+        ctx['recs'].append(rec)
+    s = ops.linear1_fwd(a2, D.linear.weight.data, D.linear.bias.data)         # :239
+    return s, ctx
+
+
+def _slice_ctx(ctx, a, b, g0, g1):
+    """View of a batched context restricted to images [a,b) == groups [g0,g1)."""
+    sub = dict(NB=b - a, groups=g1 - g0, depth=ctx['depth'], alpha=ctx['alpha'], x=ctx['x'][a:b], recs=[])
+    for rec in ctx['recs']:
+        r2 = dict(rec)
+        for k in ('inp', 'a1', 'a2', 'mb', 'pf'):
+            if k in rec:
+                r2[k] = rec[k][a:b]
+        if 'stats' in rec:
+            r2['stats'] = rec['stats'][g0:g1]
+        sub['recs'].append(r2)
+    return sub
+
+
+def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
+    """First-order adjoint sweep through D for the batch in ``ctx``.
+
+    gscore [NB] : d loss / d score.   full: also accumulate weight/bias gradients.
+    want_gimg   : return d loss / d input image (NCHW).
+    hvp         : (n_head, tx, tstats, gy_first) — the last ``NB-n_head`` images form one extra group
+                  whose score gradient is zero and which only receives the minibatch-stddev
+                  Hessian-vector injection; ``gscore`` then has n_head entries."""
+    D._ensure_buffers()
+    NB, alpha = ctx['NB'], ctx['alpha']
+    x = ctx['x']
+    C = D.num_channels
+    recs = ctx['recs']
+    adj = [dict() for _ in recs]
+    lastrec = recs[-1]
+    nh = NB if hvp is None else hvp[0]
+    a2 = lastrec['a2']
+    lc2 = lastrec['blk'].c2
+    if full:
+        ops.linear1_wgrad(gscore, a2[:nh], D._lin_gw, D._lin_gb)
+    g = ops.linear1_bwd_data(gscore, D.linear.weight.data, a2[:nh], (nh,) + tuple(a2.shape[1:]), lc2.slope)
+    gimg = None
+    pending_prev = None
+    for idx in range(len(recs) - 1, -1, -1):
+        rec = recs[idx]
+        blk, H = rec['blk'], rec['H']
+        c1, c2 = blk.c1, blk.c2
+        fr_slope = blk.fromRGB.slope
+        if rec['last']:
+            gz2 = g                                                           # [nh,1,1,C]
+            a1, mb, inp = rec['a1'], rec['mb'], rec['inp']
+            if full:
+                _wgrad(a1[:nh], gz2, c2, nh, H)
+            gz1 = _dgrad(D, gz2, c2, nh, 1, mask=a1[:nh], mask_slope=c1.slope)
+            if full:
+                _wgrad(mb[:nh], gz1, c1, nh, H)
+            gmb = _dgrad(D, gz1, c1, nh, H)                                   # [nh,4,4,CP]
+            cp = c1.cin_store
+            if hvp is None:
+                gin = ops.mbstd_bwd(gmb, inp, rec['stats'], cp, rec['first'], fr_slope)
+            else:
+                _, tx, tstats, gy_first = hvp
+                gin = torch.empty_like(inp)
+                ng = rec['stats'].shape[0] - 1
+                ops.mbstd_bwd(gmb, inp[:nh], rec['stats'][:ng], cp, rec['first'], fr_slope, out=gin[:nh])
+                ops.mbstd_bwd(None, inp[nh:], rec['stats'][ng:], cp, rec['first'], fr_slope,
+                              tx=tx, tstats=tstats, gy_first=gy_first, out=gin[nh:])
+            if save_adjoints:
+                adj[idx].update(gz2=gz2, gz1=gz1, gmb=gmb)
+        else:
+            gz2 = g
+            if full:
+                _wgrad(rec['a1'], gz2, c2, NB, H)
+            gz1 = _dgrad(D, gz2, c2, NB, H, mask=rec['a1'], mask_slope=c1.slope)
+            if full:
+                _wgrad(rec['inp'], gz1, c1, NB, H)
+            gin = _dgrad(D, gz1, c1, NB, H, mask=rec['inp'] if rec['first'] else None, mask_slope=fr_slope)
+            if save_adjoints:
+                adj[idx].update(gz2=gz2, gz1=gz1)
+        if rec['first']:
+            gf = gin                                                          # adjoint of fromRGB pre-activation
+            fr = blk.fromRGB
+            if save_adjoints:
+                adj[idx]['gf'] = gf
+            if full:
+                ops.fromrgb_wgrad(gf, x, fr._gw, fr._gb, NB, C, H, H, fr.c)
+            if want_gimg:
+                gimg = torch.empty_like(x)
+                ops.fromrgb_bwd_data(gf, fr.conv.weight.data, gimg, NB, C, H, H, fr.c)
+                if pending_prev is not None:
+                    gpf, pfr = pending_prev
+                    ops.fromrgb_bwd_data(gpf, pfr.conv.weight.data, gimg, NB, C, H // 2, H // 2, pfr.c,
+                                         pool=True, accumulate=True)
+        else:
+            prev = recs[idx - 1]
+            pc2 = prev['blk'].c2
+            if prev['first'] and alpha < 1.0:
+                g = ops.avgpool2_bwd(gin, prev['a2'], alpha, pc2.slope)
+                pfr = blk.fromRGB                                             # the block whose fromRGB fed the fade-in
+                gpf = ops.axpby_mask(gin, mask=prev['pf'], a=1.0 - alpha, mask_slope=pfr.slope)
+                if save_adjoints:
+                    adj[idx - 1]['gpf'] = gpf
+                if full:
+                    ops.fromrgb_wgrad(gpf, x, pfr._gw, pfr._gb, NB, C, H, H, pfr.c, pool=True)
+                pending_prev = (gpf, pfr)
+            else:
+                g = ops.avgpool2_bwd(gin, prev['a2'], 1.0, pc2.slope)
+    return gimg, adj
+
+
+def d_tangent_wgrad(D, sub, adj, u):
+    """Gradient-penalty second-order term, steps (i)+(ii): push the seed ``u`` (NCHW, same shape as the
+    mixed batch) through the masked linear maps of D and accumulate, per layer,
+    dW += c * wgrad(tangent_input, first_backward_adjoint).  Returns the minibatch-stddev HVP inputs."""
+    D._ensure_buffers()
+    N, alpha = sub['NB'], sub['alpha']
+    C = D.num_channels
+    recs = sub['recs']
+    rec0 = recs[0]
+    fr = rec0['blk'].fromRGB
+    H = rec0['H']
+    ops.fromrgb_wgrad(adj[0]['gf'], u, fr._gw, None, N, C, H, H, fr.c)
+    cur = ops.fromrgb_fwd(u, fr.conv.weight.data, None, N, C, H, H, fr.c, 1.0, mask=rec0['inp'], mask_slope=fr.slope)
+    hvp = None
+    t2 = None
+    for idx, rec in enumerate(recs):
+        blk, H = rec['blk'], rec['H']
+        c1, c2 = blk.c1, blk.c2
+        if rec['last']:
+            tmb, tstats = ops.mbstd_tangent(rec['inp'], cur, rec['stats'], c1.cin_store)
+            hvp = (cur, tstats, adj[idx]['gmb'])
+            _wgrad(tmb, adj[idx]['gz1'], c1, N, H, bias=False)
+            t1 = _conv(tmb, c1, N, H, mask=rec['a1'], bias=False)
+            _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False)
+            t2 = _conv(t1, c2, N, H, mask=rec['a2'], bias=False)
+        else:
+            _wgrad(cur, adj[idx]['gz1'], c1, N, H, bias=False)
+            t1 = _conv(cur, c1, N, H, mask=rec['a1'], bias=False)
+            _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False)
+            t2 = _conv(t1, c2, N, H, mask=rec['a2'], bias=False)
+            if rec['first'] and alpha < 1.0:
+                nfr = recs[idx + 1]['blk'].fromRGB
+                ops.fromrgb_wgrad(adj[idx]['gpf'], u, nfr._gw, None, N, C, H // 2, H // 2, nfr.c, pool=True)
+                tpf = ops.fromrgb_fwd(u, nfr.conv.weight.data, None, N, C, H // 2, H // 2, nfr.c, 1.0,
+                                      pool=True, mask=rec['pf'], mask_slope=nfr.slope)
+                cur = ops.avgpool2_fwd(t2, tpf, alpha, 1.0 - alpha)
+            else:
+                cur = ops.avgpool2_fwd(t2)
+    # Linear: d/dw <ones, w . t2> = sum_n t2[n]
+    ops.linear1_wgrad(_ones(N, u.device), t2, D._lin_gw, None)
+    return hvp
+
+
+def d_active_params(D, depth, alpha):
+    """Parameters that take part at (depth, alpha) — the ones autograd would give a gradient."""
+    nb = len(D.blocks)
+    e = nb - 1 - depth
+    layers = [D.blocks[e].fromRGB]
+    if depth > 0 and alpha < 1.0:
+        layers.append(D.blocks[e + 1].fromRGB)
+    for j in range(e, nb):
+        layers += [D.blocks[j].c1, D.blocks[j].c2]
+    return layers
+
+
+def discriminator_forward(D, x):
+    """Plain ``D(x)`` (network.py:225-240): NCHW image batch -> scores [N,1]."""
+    ops.require_gpu()
+    x = _check_dev(x, 'D input')
+    s, _ = d_forward(D, x, 1)
+    return s.view(-1, 1)
+
+
+# ------------------------------------------------------------------------------------------
+# WGAN-GP steps
+# ------------------------------------------------------------------------------------------
+def _assign_grads(net, layers, linear=False):
+    for m in layers:
+        m.conv.weight.grad = m._gw
+        m.conv.bias.grad = m._gb
+    if linear:
+        net.linear.weight.grad = net._lin_gw
+        net.linear.bias.grad = net._lin_gb
+
+
+def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_target):
+    """Forward half of wgan_gp_D_loss (wgan_gp_loss.py:36-65): three D passes batched as
+    [real | fake | mixed], G without graph, and the first backward of the gradient penalty."""
+    ops.require_gpu()
+    real = _check_dev(real, 'real images')
+    latents = _check_dev(latents, 'latents')
+    mix = _check_dev(mix, 'mixing factors').view(-1)
+    N = real.shape[0]
+    D._sync_version()
+    x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
+    x3[:N].copy_(real)                                                        # D2D memcpy (plumbing)
+    generator_forward(G, latents, out=x3[N:2 * N])                            # :51-52  (no graph kept)
+    ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                      # :19
+    s, ctx = d_forward(D, x3, groups=3)                                       # :47,54,20
+    sub = _slice_ctx(ctx, 2 * N, 3 * N, 2, 3)
+    gimg, adj = d_backward(D, sub, _ones(N, real.device), full=False, want_gimg=True, save_adjoints=True)  # :25-28
+    ss = ops.row_sumsq(gimg)
+    gp, u = ops.gp_seed(gimg, ss, iwass_lambda, iwass_target, 1.0 / N)        # :29-31
+    d_cost, d_real_loss, d_fake_loss, gscore = ops.d_loss(s, gp, N, iwass_epsilon)   # :48,55,62
+    state = dict(D=D, ctx=ctx, sub=sub, adj=adj, u=u, gscore=gscore, N=N, scores=s, gp=gp)
+    return d_cost, d_real_loss, d_fake_loss, state
+
+
+def d_loss_backward(state, scale=1.0):
+    """``D_cost.backward()`` (trainer.py:98): tangent pass + batched [real|fake|mixed] adjoint sweep."""
+    D, ctx, N = state['D'], state['ctx'], state['N']
+    D._ensure_buffers()
+    ops.zero_(D._flat_grad)
+    hvp = d_tangent_wgrad(D, state['sub'], state['adj'], state['u'])
+    gs = state['gscore'][:2 * N]
+    d_backward(D, ctx, gs, full=True, want_gimg=False, hvp=(2 * N,) + hvp)
+    if scale != 1.0:
+        ops.axpby_mask(D._flat_grad, a=scale, out=D._flat_grad)
+    _assign_grads(D, d_active_params(D, ctx['depth'], ctx['alpha']), linear=True)
+
+
+def g_loss_forward(G, D, latents):
+    """wgan_gp_G_loss (wgan_gp_loss.py:68-74)."""
+    ops.require_gpu()
+    latents = _check_dev(latents, 'latents')
+    D._sync_version()
+    G._sync_version()
+    fake, gctx = generator_forward(G, latents, save=True)
+    s, dctx = d_forward(D, fake, 1)
+    g_cost, gscore = ops.g_loss(s)
+    return g_cost, dict(G=G, D=D, gctx=gctx, dctx=dctx, gscore=gscore)
+
+
+def g_loss_backward(state, scale=1.0):
+    """``G_cost.backward()`` (trainer.py:111).  D's weight gradients, which the reference computes here
+    and throws away at its next D.zero_grad(), are not computed."""
+    G, D = state['G'], state['D']
+    G._ensure_buffers()
+    ops.zero_(G._flat_grad)
+    gimg, _ = d_backward(D, state['dctx'], state['gscore'], full=False, want_gimg=True)
+    active = generator_backward(G, state['gctx'], gimg)
+    if scale != 1.0:
+        ops.axpby_mask(G._flat_grad, a=scale, out=G._flat_grad)
+    _assign_grads(G, active)

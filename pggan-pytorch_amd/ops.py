@@ -1,0 +1,245 @@
+"""Tensor-level wrappers of the C-ABI kernels (include/pggan_hip.h).
+
+PyTorch is used only as the device allocator and stream provider: every function takes fp32
+CUDA(HIP) tensors, allocates its output with ``torch.empty`` and launches a hand-written HIP
+kernel on the current stream.  No ATen arithmetic, no CPU fallback.
+Feature tensors are NHWC ``[N,H,W,C]``; image tensors are NCHW ``[N,C,H,W]``."""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    """Device pointer of a checked tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError('expected a contiguous fp32 device tensor, got %s %s contiguous=%s on %s'
+                         % (tuple(t.shape), t.dtype, t.is_contiguous(), t.device))
+    return t.data_ptr()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('pggan-pytorch_amd needs an MI355X (gfx950) device: the hot path has no CPU fallback')
+    _lib.load()
+
+
+# ------------------------------------------------------------------------------------ conv
+def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False,
+           out=None):
+    """x: [N,Hin(/2),Win(/2),Cin]; w packed [ks,ks,Cout,Cin] -> y [N,Hout,Wout,Cout]."""
+    cout, cin = w.shape[2], w.shape[3]
+    ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
+    y = out if out is not None else torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_nhwc', _p(x), _p(w), _p(bias), _p(mask), _p(y), N, Hin, Win, cin, cout, ks, pad,
+              1 if ups else 0, scale, slope, mask_slope, _stream())
+    return y
+
+
+def conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=False):
+    """Accumulates into dw [ks,ks,Cout,Cin] (and db [Cout] if given)."""
+    cout, cin = dw.shape[2], dw.shape[3]
+    _lib.call('pg_conv2d_wgrad_nhwc', _p(x), _p(gz), _p(dw), _p(db), N, Hin, Win, cin, cout, ks, pad,
+              1 if ups else 0, scale, _stream())
+
+
+def pack_dgrad_weights(w, wt):
+    ks, _, cout, cin = w.shape
+    _lib.call('pg_pack_dgrad_weights', _p(w), _p(wt), ks, cout, cin, _stream())
+    return wt
+
+
+# --------------------------------------------------------------------------------- from/toRGB
+def fromrgb_fwd(img, w, bias, N, C, H, W, scale, slope, pool=False, mask=None, mask_slope=0.2):
+    cout = w.shape[0]
+    y = torch.empty((N, H, W, cout), device=img.device, dtype=torch.float32)
+    _lib.call('pg_fromrgb_fwd', _p(img), _p(w), _p(bias), _p(mask), _p(y), N, C, H, W, cout, 1 if pool else 0,
+              scale, slope, mask_slope, _stream())
+    return y
+
+
+def fromrgb_bwd_data(gz, w, gimg, N, C, H, W, scale, pool=False, accumulate=False):
+    cout = w.shape[0]
+    _lib.call('pg_fromrgb_bwd_data', _p(gz), _p(w), _p(gimg), N, C, H, W, cout, 1 if pool else 0,
+              1 if accumulate else 0, scale, _stream())
+
+
+def fromrgb_wgrad(gz, img, dw, db, N, C, H, W, scale, pool=False):
+    cout = dw.shape[0]
+    _lib.call('pg_fromrgb_wgrad', _p(gz), _p(img), _p(dw), _p(db), N, C, H, W, cout, 1 if pool else 0, scale, _stream())
+
+
+def torgb_fwd(x, w, bias, N, C, H, W, scale, out_mul=1.0, prev=None, prev_mul=0.0, out=None):
+    cin = w.shape[1]
+    if out is None:
+        out = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+    _lib.call('pg_torgb_fwd', _p(x), _p(w), _p(bias), _p(prev), _p(out), N, C, H, W, cin, scale, out_mul, prev_mul, _stream())
+    return out
+
+
+def torgb_bwd_data(g, w, N, C, H, W, mul_scale, down=False):
+    cin = w.shape[1]
+    gx = torch.empty((N, H, W, cin), device=g.device, dtype=torch.float32)
+    _lib.call('pg_torgb_bwd_data', _p(g), _p(w), _p(gx), N, C, H, W, cin, 1 if down else 0, mul_scale, _stream())
+    return gx
+
+
+def torgb_wgrad(g, x, dw, db, N, C, H, W, mul_scale, mul, down=False):
+    cin = dw.shape[1]
+    _lib.call('pg_torgb_wgrad', _p(g), _p(x), _p(dw), _p(db), N, C, H, W, cin, 1 if down else 0, mul_scale, mul, _stream())
+
+
+# --------------------------------------------------------------------------- pool / upsample
+def avgpool2_fwd(x, other=None, a=1.0, b=0.0):
+    N, H2, W2, C = x.shape
+    y = torch.empty((N, H2 // 2, W2 // 2, C), device=x.device, dtype=torch.float32)
+    _lib.call('pg_avgpool2_fwd', _p(x), _p(other), _p(y), N, H2 // 2, W2 // 2, C, a, b, _stream())
+    return y
+
+
+def avgpool2_bwd(gy, mask=None, mul=1.0, mask_slope=0.2):
+    N, H, W, C = gy.shape
+    gx = torch.empty((N, 2 * H, 2 * W, C), device=gy.device, dtype=torch.float32)
+    _lib.call('pg_avgpool2_bwd', _p(gy), _p(mask), _p(gx), N, H, W, C, mul, mask_slope, _stream())
+    return gx
+
+
+def upsample2_bwd(g):
+    N, H2, W2, C = g.shape
+    gx = torch.empty((N, H2 // 2, W2 // 2, C), device=g.device, dtype=torch.float32)
+    _lib.call('pg_upsample2_bwd', _p(g), _p(gx), N, H2 // 2, W2 // 2, C, _stream())
+    return gx
+
+
+def axpby_mask(x, other=None, mask=None, a=1.0, b=0.0, mask_slope=0.2, out=None):
+    y = out if out is not None else torch.empty_like(x)
+    _lib.call('pg_axpby_mask', _p(x), _p(other), _p(mask), _p(y), x.numel(), a, b, mask_slope, _stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------- pixelnorm
+def pixelnorm_fwd(x, eps=1e-8, inplace=False):
+    C = x.shape[-1]
+    P = x.numel() // C
+    y = x if inplace else torch.empty_like(x)
+    r = torch.empty((P,), device=x.device, dtype=torch.float32)
+    _lib.call('pg_pixelnorm_fwd', _p(x), _p(y), _p(r), P, C, eps, _stream())
+    return y, r
+
+
+def pixelnorm_lrelu_bwd(gy, y, r, slope, inplace=False):
+    C = y.shape[-1]
+    P = y.numel() // C
+    gz = gy if inplace else torch.empty_like(gy)
+    _lib.call('pg_pixelnorm_lrelu_bwd', _p(gy), _p(y), _p(r), _p(gz), P, C, slope, _stream())
+    return gz
+
+
+# -------------------------------------------------------------------------------------- mbstd
+def mbstd_fwd(x, groups, cp):
+    NB, H, W, C = x.shape
+    y = torch.empty((NB, H, W, cp), device=x.device, dtype=torch.float32)
+    stats = torch.empty((groups, 2), device=x.device, dtype=torch.float32)
+    _lib.call('pg_mbstd_fwd', _p(x), _p(y), _p(stats), groups, NB // groups, H * W, C, cp, _stream())
+    return y, stats
+
+
+def mbstd_tangent(x, tx, stats, cp):
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    ty = torch.empty((NB, H, W, cp), device=x.device, dtype=torch.float32)
+    tstats = torch.empty((groups, 2), device=x.device, dtype=torch.float32)
+    _lib.call('pg_mbstd_tangent', _p(x), _p(tx), _p(stats), _p(ty), _p(tstats), groups, NB // groups, H * W, C, cp, _stream())
+    return ty, tstats
+
+
+def mbstd_bwd(gy, x, stats, cp, apply_mask, mask_slope=0.2, tx=None, tstats=None, gy_first=None, out=None):
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    gx = out if out is not None else torch.empty_like(x)
+    _lib.call('pg_mbstd_bwd', _p(gy), _p(x), _p(stats), _p(tx), _p(tstats), _p(gy_first), _p(gx), groups,
+              NB // groups, H * W, C, cp, 1 if apply_mask else 0, mask_slope, _stream())
+    return gx
+
+
+# ------------------------------------------------------------------------------------- linear
+def linear1_fwd(h, w, b):
+    N, C = h.shape[0], h.numel() // h.shape[0]
+    s = torch.empty((N,), device=h.device, dtype=torch.float32)
+    _lib.call('pg_linear1_fwd', _p(h), _p(w), _p(b), _p(s), N, C, _stream())
+    return s
+
+
+def linear1_bwd_data(gs, w, mask, shape, mask_slope=0.2):
+    N = gs.shape[0]
+    C = w.numel()
+    gh = torch.empty(shape, device=gs.device, dtype=torch.float32)
+    _lib.call('pg_linear1_bwd_data', _p(gs), _p(w), _p(mask), _p(gh), N, C, mask_slope, _stream())
+    return gh
+
+
+def linear1_wgrad(gs, h, dw, db):
+    N = gs.shape[0]
+    C = dw.numel()
+    _lib.call('pg_linear1_wgrad', _p(gs), _p(h), _p(dw), _p(db), N, C, _stream())
+
+
+# ------------------------------------------------------------------------------------ WGAN-GP
+def gp_mix(real, fake, m, out=None):
+    N = real.shape[0]
+    E = real.numel() // N
+    if out is None:
+        out = torch.empty_like(real)
+    _lib.call('pg_gp_mix', _p(real), _p(fake), _p(m), _p(out), N, E, _stream())
+    return out
+
+
+def row_sumsq(g):
+    N = g.shape[0]
+    E = g.numel() // N
+    ss = torch.empty((N,), device=g.device, dtype=torch.float32)
+    zero_(ss)
+    _lib.call('pg_row_sumsq', _p(g), _p(ss), N, E, _stream())
+    return ss
+
+
+def gp_seed(g, ss, lam, target, inv_n):
+    N = g.shape[0]
+    E = g.numel() // N
+    gp = torch.empty((N,), device=g.device, dtype=torch.float32)
+    u = torch.empty_like(g)
+    _lib.call('pg_gp_seed', _p(g), _p(ss), _p(gp), _p(u), N, E, lam, target, inv_n, _stream())
+    return gp, u
+
+
+def d_loss(scores, gp, N, eps):
+    dev = scores.device
+    d_cost = torch.empty((), device=dev, dtype=torch.float32)
+    d_real_loss = torch.empty((N, 1), device=dev, dtype=torch.float32)
+    d_fake_loss = torch.empty((N, 1), device=dev, dtype=torch.float32)
+    gscore = torch.empty((3 * N,), device=dev, dtype=torch.float32)
+    _lib.call('pg_d_loss', _p(scores), _p(gp), _p(d_cost), _p(d_real_loss), _p(d_fake_loss), _p(gscore), N, eps, _stream())
+    return d_cost, d_real_loss, d_fake_loss, gscore
+
+
+def g_loss(scores):
+    N = scores.shape[0]
+    g_cost = torch.empty((), device=scores.device, dtype=torch.float32)
+    gscore = torch.empty((N,), device=scores.device, dtype=torch.float32)
+    _lib.call('pg_g_loss', _p(scores), _p(g_cost), _p(gscore), N, _stream())
+    return g_cost, gscore
+
+
+# --------------------------------------------------------------------------------------- misc
+def adam(p, g, m, v, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale=1.0):
+    _lib.call('pg_adam', _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, _stream())
+
+
+def zero_(t):
+    _lib.call('pg_zero', _p(t), t.numel() * 4, _stream())
+    return t

@@ -1,0 +1,65 @@
+"""Host-side helpers with the reference's names (/root/reference/utils.py) that the hot path's callers use."""
+import numpy as np
+import torch
+
+
+def random_latents(num_latents, latent_size):
+    """reference utils.py:56-57 — host-side ``np.random.randn`` -> fp32 tensor (moved to the GPU by Trainer)."""
+    return torch.from_numpy(np.random.randn(num_latents, latent_size).astype(np.float32))
+
+
+def generate_samples(generator, gen_input):
+    """reference utils.py:8-11."""
+    out = generator.forward(gen_input)
+    return out.cpu().data.numpy()
+
+
+def adjust_dynamic_range(data, range_in, range_out):
+    """reference utils.py:24-30."""
+    if range_in != range_out:
+        (min_in, max_in) = range_in
+        (min_out, max_out) = range_out
+        scale_factor = (max_out - min_out) / (max_in - min_in)
+        data = (data - min_in) * scale_factor + min_out
+    return data
+
+
+def rampup(cur_nimg, lr_rampup_kimg=40):
+    """Learning-rate ramp-up multiplier.  reference train.py:151-156."""
+    if cur_nimg < lr_rampup_kimg * 1000:
+        p = max(0.0, 1 - cur_nimg / (lr_rampup_kimg * 1000))
+        return np.exp(-p * p * 5.0)
+    return 1.0
+
+
+class SyntheticDataset(object):
+    """Seeded synthetic images in [-1,1) with the DepthDataset protocol the DepthManager drives
+    (``model_depth``, ``alpha``, ``shape``; reference dataset.py:31-70).  Batches are generated on the
+    device, so the benchmark measures the train step and not a host data loader."""
+
+    def __init__(self, resolution, num_channels=3, seed=1337, device='cuda'):
+        self.shape = (1, num_channels, resolution, resolution)
+        self.model_depth = 0
+        self.alpha = 1.0
+        self.device = device
+        self._gen = torch.Generator(device=device)
+        self._gen.manual_seed(int(seed))
+
+    def batch(self, n):
+        r = 4 * 2 ** self.model_depth
+        x = torch.rand((n, self.shape[1], r, r), device=self.device, dtype=torch.float32, generator=self._gen)
+        return x.mul_(2).sub_(1)
+
+    def loader(self, minibatch_size):
+        while True:
+            yield self.batch(minibatch_size)
+
+    def close(self):
+        pass
+
+
+def device_latents(minibatch_size, latent_size, seed=1337, device='cuda'):
+    """Device-side replacement of ``random_latents`` for benchmarks (no H2D copy per iteration)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    return lambda: torch.randn((minibatch_size, latent_size), device=device, dtype=torch.float32, generator=gen)

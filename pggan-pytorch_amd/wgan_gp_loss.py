@@ -1,0 +1,84 @@
+"""WGAN-GP losses with the reference's call signatures (/root/reference/wgan_gp_loss.py).
+
+``wgan_gp_D_loss(D, G, real, latents, ...) -> (D_cost, D_real_loss, D_fake_loss)`` and
+``wgan_gp_G_loss(G, D, latents) -> G_cost`` return device tensors; ``D_cost.backward()`` /
+``G_cost.backward()`` (called by ``Trainer.train``, trainer.py:98,111) run the explicit HIP
+backward schedules of ``engine`` and leave the gradients in ``param.grad`` (views of each
+network's flat gradient buffer), exactly where ``optimizer.step()`` expects them."""
+import torch
+
+from . import engine
+
+# wgan_gp_loss.py:4-5 keeps module-global scratch; the only state kept here is the injectable RNG.
+mixing_factors = None
+_generator = None
+
+
+def set_mixing_factors(m):
+    """Inject the U[0,1) draw of wgan_gp_loss.py:15-17 for the NEXT wgan_gp_D_loss call (parity tests)."""
+    global mixing_factors
+    mixing_factors = m
+
+
+def manual_seed(seed, device='cuda'):
+    """Seed the device generator the mixing factors are drawn from."""
+    global _generator
+    _generator = torch.Generator(device=device)
+    _generator.manual_seed(int(seed))
+
+
+class LossTensor(torch.Tensor):
+    """A scalar device tensor whose ``backward()`` launches an explicit HIP backward schedule."""
+
+    @staticmethod
+    def wrap(t, backward_fn):
+        out = torch.Tensor._make_subclass(LossTensor, t)
+        out._pg_backward = backward_fn
+        return out
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        if create_graph:
+            raise NotImplementedError('third-order differentiation is not part of the path')
+        fn = getattr(self, '_pg_backward', None)
+        if fn is None:
+            raise RuntimeError('backward() was already consumed (or this tensor is a derived copy)')
+        scale = 1.0 if gradient is None else float(gradient)
+        fn(scale)
+        if not retain_graph:
+            self._pg_backward = None
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        # derived tensors (``.mean()``, ``.item()`` ...) are plain tensors
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
+                   iwass_lambda=10.0,
+                   iwass_epsilon=0.001,
+                   iwass_target=1.0,
+                   return_all=True):
+    """reference wgan_gp_loss.py:36-65."""
+    global mixing_factors
+    D.zero_grad()                                                        # :42
+    G.zero_grad()                                                        # :43
+    n = real_images_in.size(0)
+    if mixing_factors is not None:
+        mix = mixing_factors.to(device=real_images_in.device, dtype=torch.float32).reshape(n, 1)
+        mixing_factors = None
+    else:                                                                # :15-17 (device RNG)
+        mix = torch.rand((n, 1), device=real_images_in.device, dtype=torch.float32, generator=_generator)
+    d_cost, d_real_loss, d_fake_loss, state = engine.d_loss_forward(
+        D, G, real_images_in, fake_latents_in, mix, iwass_lambda, iwass_epsilon, iwass_target)
+    d_cost = LossTensor.wrap(d_cost, lambda scale: engine.d_loss_backward(state, scale))
+    if return_all:
+        return d_cost, d_real_loss, d_fake_loss
+    return d_cost
+
+
+def wgan_gp_G_loss(G, D, fake_latents_in):
+    """reference wgan_gp_loss.py:68-74."""
+    G.zero_grad()                                                        # :69
+    g_cost, state = engine.g_loss_forward(G, D, fake_latents_in)
+    return LossTensor.wrap(g_cost, lambda scale: engine.g_loss_backward(state, scale))

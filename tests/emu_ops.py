@@ -1,0 +1,290 @@
+"""TEST INFRASTRUCTURE: a torch-CPU emulation of ``pggan-pytorch_amd/ops.py`` (same signatures).
+
+Purpose: run the *host-side* launch schedules of ``engine.py`` (the hand-derived WGAN-GP
+double-backward, the batched [real|fake|mixed] sweep, the flat-buffer optimizer) on a machine
+without a GPU and compare them with the autograd-based CPU oracle.  It is installed only by the
+``emu`` pytest fixture (monkeypatch) and is never imported by the product: the product path has no
+CPU fallback.  Each function states the arithmetic contract of the kernel it stands in for, i.e.
+the same contract written in include/pggan_hip.h."""
+import torch
+import torch.nn.functional as F
+
+
+def require_gpu():
+    return None
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _ret(y, out):
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def _maskmul(v, mask, slope):
+    return v * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, slope))
+
+
+def _lrelu(v, slope):
+    return torch.where(v > 0, v, v * slope)
+
+
+def _wref(w):
+    return w.permute(2, 3, 0, 1)            # [ks,ks,co,ci] -> [co,ci,ks,ks]
+
+
+def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None):
+    xi = _nchw(x)
+    if ups:
+        xi = F.interpolate(xi, scale_factor=2, mode='nearest')
+    assert xi.shape[2] == Hin and xi.shape[3] == Win and xi.shape[0] == N
+    z = F.conv2d(xi, _wref(w), None, 1, pad) * scale
+    z = _nhwc(z)
+    if mask is not None:
+        y = _maskmul(z, mask, mask_slope)
+    else:
+        if bias is not None:
+            z = z + bias
+        y = _lrelu(z, slope)
+    return _ret(y, out)
+
+
+def conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=False):
+    xi = _nchw(x)
+    if ups:
+        xi = F.interpolate(xi, scale_factor=2, mode='nearest')
+    g = _nchw(gz)
+    co, ci = dw.shape[2], dw.shape[3]
+    gw = torch.nn.grad.conv2d_weight(xi.contiguous(), (co, ci, ks, ks), g.contiguous(), stride=1, padding=pad)
+    dw += gw.permute(2, 3, 0, 1) * scale
+    if db is not None:
+        db += gz.sum(dim=(0, 1, 2))
+
+
+def pack_dgrad_weights(w, wt):
+    wt.copy_(w.flip(0, 1).permute(0, 1, 3, 2))
+    return wt
+
+
+def _img(img, pool):
+    return F.avg_pool2d(img, 2) if pool else img
+
+
+def fromrgb_fwd(img, w, bias, N, C, H, W, scale, slope, pool=False, mask=None, mask_slope=0.2):
+    xi = _img(img, pool)
+    z = torch.einsum('nchw,oc->nhwo', xi, w) * scale
+    if mask is not None:
+        return _maskmul(z, mask, mask_slope).contiguous()
+    if bias is not None:
+        z = z + bias
+    return _lrelu(z, slope).contiguous()
+
+
+def fromrgb_bwd_data(gz, w, gimg, N, C, H, W, scale, pool=False, accumulate=False):
+    g = torch.einsum('nhwo,oc->nchw', gz, w) * scale
+    if pool:
+        g = F.interpolate(g, scale_factor=2, mode='nearest') * 0.25
+    if accumulate:
+        gimg += g
+    else:
+        gimg.copy_(g)
+
+
+def fromrgb_wgrad(gz, img, dw, db, N, C, H, W, scale, pool=False):
+    xi = _img(img, pool)
+    dw += torch.einsum('nhwo,nchw->oc', gz, xi) * scale
+    if db is not None:
+        db += gz.sum(dim=(0, 1, 2))
+
+
+def torgb_fwd(x, w, bias, N, C, H, W, scale, out_mul=1.0, prev=None, prev_mul=0.0, out=None):
+    y = torch.einsum('nhwi,ci->nchw', x, w) * scale
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    y = y * out_mul
+    if prev is not None:
+        y = y + prev_mul * F.interpolate(prev, scale_factor=2, mode='nearest')
+    return _ret(y.contiguous(), out)
+
+
+def torgb_bwd_data(g, w, N, C, H, W, mul_scale, down=False):
+    gg = F.avg_pool2d(g, 2) * 4 if down else g
+    return (torch.einsum('nchw,ci->nhwi', gg, w) * mul_scale).contiguous()
+
+
+def torgb_wgrad(g, x, dw, db, N, C, H, W, mul_scale, mul, down=False):
+    gg = F.avg_pool2d(g, 2) * 4 if down else g
+    dw += torch.einsum('nchw,nhwi->ci', gg, x) * mul_scale
+    if db is not None:
+        db += gg.sum(dim=(0, 2, 3)) * mul
+
+
+def avgpool2_fwd(x, other=None, a=1.0, b=0.0):
+    y = _nhwc(F.avg_pool2d(_nchw(x), 2))
+    if other is not None:
+        return y * a + b * other
+    return y * a
+
+
+def avgpool2_bwd(gy, mask=None, mul=1.0, mask_slope=0.2):
+    g = _nhwc(F.interpolate(_nchw(gy), scale_factor=2, mode='nearest')) * (0.25 * mul)
+    if mask is not None:
+        g = _maskmul(g, mask, mask_slope)
+    return g.contiguous()
+
+
+def upsample2_bwd(g):
+    return _nhwc(F.avg_pool2d(_nchw(g), 2) * 4)
+
+
+def axpby_mask(x, other=None, mask=None, a=1.0, b=0.0, mask_slope=0.2, out=None):
+    y = x * a
+    if other is not None:
+        y = y + b * other
+    if mask is not None:
+        y = _maskmul(y, mask, mask_slope)
+    return _ret(y, out)
+
+
+def pixelnorm_fwd(x, eps=1e-8, inplace=False):
+    C = x.shape[-1]
+    r = torch.rsqrt((x * x).mean(dim=-1) + eps)
+    y = x * r.unsqueeze(-1)
+    if inplace:
+        x.copy_(y)
+        y = x
+    return y, r.reshape(-1)
+
+
+def pixelnorm_lrelu_bwd(gy, y, r, slope, inplace=False):
+    if r is not None:
+        rr = r.view(y.shape[:-1]).unsqueeze(-1)
+        gh = rr * (gy - y * (gy * y).mean(dim=-1, keepdim=True))
+    else:
+        gh = gy
+    gz = _maskmul(gh, y, slope)
+    if inplace:
+        gy.copy_(gz)
+        return gy
+    return gz
+
+
+def mbstd_fwd(x, groups, cp):
+    NB, H, W, C = x.shape
+    n = NB // groups
+    y = torch.zeros((NB, H, W, cp))
+    y[..., :C] = x
+    stats = torch.zeros((groups, 2))
+    for g in range(groups):
+        xg = x[g * n:(g + 1) * n]
+        mu = xg.mean()
+        sigma = torch.sqrt(((xg - mu) ** 2).mean() + 1e-8)
+        stats[g, 0], stats[g, 1] = mu, sigma
+        y[g * n:(g + 1) * n, :, :, C] = sigma
+    return y, stats
+
+
+def mbstd_tangent(x, tx, stats, cp):
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    n = NB // groups
+    ty = torch.zeros((NB, H, W, cp))
+    ty[..., :C] = tx
+    tstats = torch.zeros((groups, 2))
+    for g in range(groups):
+        xg, tg = x[g * n:(g + 1) * n], tx[g * n:(g + 1) * n]
+        mu, sigma = stats[g, 0], stats[g, 1]
+        M = xg.numel()
+        dot = ((xg - mu) * tg).sum()
+        tstats[g, 0], tstats[g, 1] = tg.mean(), dot
+        ty[g * n:(g + 1) * n, :, :, C] = dot / (M * sigma)
+    return ty, tstats
+
+
+def mbstd_bwd(gy, x, stats, cp, apply_mask, mask_slope=0.2, tx=None, tstats=None, gy_first=None, out=None):
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    n = NB // groups
+    gx = torch.zeros_like(x)
+    for g in range(groups):
+        sl = slice(g * n, (g + 1) * n)
+        xg = x[sl]
+        mu, sigma = stats[g, 0], stats[g, 1]
+        M = xg.numel()
+        v = torch.zeros_like(xg)
+        if gy is not None:
+            Gs = gy[sl][..., C].sum()
+            v = gy[sl][..., :C] + Gs * (xg - mu) / (M * sigma)
+        if tx is not None:
+            Gs1 = gy_first[sl][..., C].sum()
+            tmean, dot = tstats[g, 0], tstats[g, 1]
+            v = v + Gs1 / (M * sigma) * ((tx[sl] - tmean) - (xg - mu) * dot / (M * sigma * sigma))
+        if apply_mask:
+            v = _maskmul(v, xg, mask_slope)
+        gx[sl] = v
+    return _ret(gx, out)
+
+
+def linear1_fwd(h, w, b):
+    return h.reshape(h.shape[0], -1) @ w.reshape(-1) + (b if b is not None else 0.0)
+
+
+def linear1_bwd_data(gs, w, mask, shape, mask_slope=0.2):
+    gh = (gs.view(-1, 1) * w.reshape(1, -1)).view(shape)
+    if mask is not None:
+        gh = _maskmul(gh, mask.reshape(shape), mask_slope)
+    return gh.contiguous()
+
+
+def linear1_wgrad(gs, h, dw, db):
+    dw += (gs.view(-1, 1) * h.reshape(h.shape[0], -1)).sum(0).view(dw.shape)
+    if db is not None:
+        db += gs.sum()
+
+
+def gp_mix(real, fake, m, out=None):
+    mm = m.view(-1, 1, 1, 1)
+    return _ret(real * (1 - mm) + fake * mm, out)
+
+
+def row_sumsq(g):
+    return (g.reshape(g.shape[0], -1) ** 2).sum(1)
+
+
+def gp_seed(g, ss, lam, target, inv_n):
+    norm = ss.sqrt()
+    gp = (norm - target) ** 2 * lam / target ** 2
+    coef = inv_n * 2 * lam * (norm - target) / (target ** 2 * norm)
+    return gp, g * coef.view(-1, 1, 1, 1)
+
+
+def d_loss(scores, gp, N, eps):
+    sr, sf = scores[:N], scores[N:2 * N]
+    rl = -sr + sr * sr * eps
+    d_cost = (sf + rl + gp).mean()
+    gscore = torch.cat([(-1 + 2 * eps * sr) / N, torch.full((N,), 1.0 / N), torch.zeros(N)])
+    return d_cost, rl.view(N, 1).clone(), sf.view(N, 1).clone(), gscore
+
+
+def g_loss(scores):
+    N = scores.shape[0]
+    return (-scores).mean(), torch.full((N,), -1.0 / N)
+
+
+def adam(p, g, m, v, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale=1.0):
+    gg = g * grad_scale
+    m.mul_(beta1).add_(gg, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    p.sub_((lr / bc1) * m / (v.sqrt() / bc2_sqrt + eps))
+
+
+def zero_(t):
+    return t.zero_()

@@ -85,6 +85,37 @@ def grads_of(model):
     return {k: p.grad.detach().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
 
 
+_MIN_PREACT = [float('inf')]
+
+
+def _track_preact(module, inp, out):
+    _MIN_PREACT[0] = min(_MIN_PREACT[0], float(out.detach().abs().min()))
+
+
+def pick_seed(G, D, depth, alpha, n, C, res, latent, seed0):
+    """LeakyReLU'(z) is discontinuous at z == 0: a pre-activation within fp32 round-off of zero makes
+    the reference's gradients depend on its conv summation order (an implementation that sums in a
+    different order may land on the other side).  Such ill-conditioned draws are rare (~1e-3 per
+    tiny case) but would make a fixture test the summation order instead of the algorithm, so every
+    case uses the first seed (seed0, seed0+1000, ...) whose smallest |pre-activation| over all
+    D and G passes is > 2e-6.  Forward hooks only observe nn.Conv2d outputs; nothing is modified."""
+    hooks = [m.register_forward_hook(_track_preact) for net in (G, D) for m in net.modules()
+             if isinstance(m, torch.nn.Conv2d) and m.out_channels > 4]
+    try:
+        seed = seed0
+        while True:
+            _MIN_PREACT[0] = float('inf')
+            real, z_d, z_g, mix = synthetic(seed, n, C, res, latent)
+            run_steps(G, D, depth, alpha, real, z_d, z_g, mix)
+            if _MIN_PREACT[0] > 2e-6:
+                return seed
+            print('   seed %d rejected (min |pre-activation| = %.2e)' % (seed, _MIN_PREACT[0]))
+            seed += 1000
+    finally:
+        for h in hooks:
+            h.remove()
+
+
 def run_steps(G, D, depth, alpha, real, z_d, z_g, mix):
     """reference D loss + backward, then G loss + backward (no optimizer step)."""
     G.depth = D.depth = depth
@@ -133,7 +164,7 @@ def make_tiny32():
         for alpha in ((1.0,) if depth == 0 else (1.0, 0.37)):
             n = 4
             res = 4 * 2 ** depth
-            seed = 100 + 10 * depth + (0 if alpha == 1.0 else 1)
+            seed = pick_seed(G, D, depth, alpha, n, 3, res, 16, 100 + 10 * depth + (0 if alpha == 1.0 else 1))
             real, z_d, z_g, mix = synthetic(seed, n, 3, res, 16)
             out, dg, gg = run_steps(G, D, depth, alpha, real, z_d, z_g, mix)
             tag = 'd%d_a%s' % (depth, ('1' if alpha == 1.0 else '037'))
@@ -164,7 +195,7 @@ def make_tiny16_c1():
     for depth, alpha in ((2, 1.0), (2, 0.5), (1, 0.25)):
         n = 6
         res = 4 * 2 ** depth
-        seed = 300 + 10 * depth + int(alpha * 100)
+        seed = pick_seed(G, D, depth, alpha, n, 1, res, 32, 300 + 10 * depth + int(alpha * 100))
         real, z_d, z_g, mix = synthetic(seed, n, 1, res, 32)
         out, dg, gg = run_steps(G, D, depth, alpha, real, z_d, z_g, mix)
         tag = 'd%d_a%03d' % (depth, int(alpha * 100))
