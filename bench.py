@@ -1,0 +1,296 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the PGGAN train step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--depth D] [--no-cpu] [--no-per-depth]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one Trainer.train() iteration (reference trainer.py:85-115): wgan_gp_D_loss + backward
+(3 D passes batched, G forward, gradient-penalty double backward) + Adam(D), then wgan_gp_G_loss +
+backward + Adam(G), on one synthetic minibatch already resident in HBM.  Headline workload: the
+1024x1024 growth stage (depth 8) of the default-width (fmap_base 4096) CelebA-HQ-shape network with
+the reference's per-depth minibatch (3 per GPU, plugins.py:20), fp32.  Data-parallel: one process
+per GPU, minibatch per rank fixed (weak scaling), one RCCL sum-all-reduce of each network's flat
+gradient buffer per iteration.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK = 157.3e12          # gfx950 f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+REF_MINIBATCH = {6: 14, 7: 6, 8: 3}          # reference plugins.py:19-20 (default 16)
+# per-image forward FLOPs (2*MAC, conv+linear), fmap_base 4096, alpha 1 — SURVEY.md §8a / BASELINE.md §4
+F_D = [0.0841, 0.6882, 3.1047, 6.7294, 10.3548, 13.9819, 17.6120, 21.2485, 24.8975]
+
+
+def layer_flops(layer, n, hout, wgrad_or_conv='conv'):
+    """Algorithmic FLOPs of one conv launch: 2*N*Hout*Wout*Cout*Cin*taps with the reference's channel
+    counts (513, not the stored 528) and one live tap per output pixel for the 1x1->4x4 first layer."""
+    taps = layer.ksize * layer.ksize
+    if layer.ksize == 4 and layer.pad == 3:
+        taps = 1
+    return 2.0 * n * hout * hout * layer.ch_out * layer.ch_in * taps
+
+
+class KernelTimer(object):
+    """HIP-event timing of every conv launch of a step (torch.cuda.Event on the current stream == the
+    stream the kernels are launched on).  Installed only for the instrumented passes."""
+
+    def __init__(self, pg):
+        self.pg, self.rec, self.saved = pg, [], {}
+
+    def _wrap(self, name, family, hout_of):
+        eng = self.pg.engine
+        orig = getattr(eng, name)
+        self.saved[name] = orig
+
+        def wrapped(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **k)
+            e1.record()
+            layer, n, hout = hout_of(a, k)
+            self.rec.append((family, layer_flops(layer, n, hout), e0, e1,
+                             '%s %d->%d k%d @%d n%d' % (name, layer.ch_in, layer.ch_out, layer.ksize, hout, n)))
+            return out
+        setattr(eng, name, wrapped)
+
+    def __enter__(self):
+        def conv_args(a, k):          # _conv(x, layer, N, H, ...): H is the input size (after upsample)
+            layer, n, h = a[1], a[2], a[3]
+            return layer, n, h + 2 * layer.pad - layer.ksize + 1
+
+        def dgrad_args(a, k):         # _dgrad(net, gz, layer, N, Hout, ...): output of dgrad = layer input
+            layer, n, hout = a[2], a[3], a[4]
+            hin = hout - 2 * layer.pad + layer.ksize - 1
+            return layer, n, (hout if not (layer.ksize == 4) else max(hout, hin))
+
+        def wgrad_args(a, k):         # _wgrad(x, gz, layer, N, Hin, ...)
+            layer, n, h = a[2], a[3], a[4]
+            return layer, n, h + 2 * layer.pad - layer.ksize + 1
+        self._wrap('_conv', 'conv_igemm_kernel', conv_args)
+        self._wrap('_dgrad', 'conv_igemm_kernel', dgrad_args)
+        self._wrap('_wgrad', 'conv_wgrad_kernel', wgrad_args)
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self.saved.items():
+            setattr(self.pg.engine, name, orig)
+
+    def summary(self, nsteps):
+        torch.cuda.synchronize()
+        fam = {}
+        self.table = {}
+        for family, fl, e0, e1, tag in self.rec:
+            t = self.table.setdefault(tag, dict(flops=0.0, ms=0.0, launches=0))
+            t['flops'] += fl
+            t['ms'] += e0.elapsed_time(e1)
+            t['launches'] += 1
+            d = fam.setdefault(family, dict(flops=0.0, ms=0.0, launches=0))
+            d['flops'] += fl
+            d['ms'] += e0.elapsed_time(e1)
+            d['launches'] += 1
+        for d in fam.values():
+            d['flops_per_step'] = d['flops'] / nsteps
+            d['ms_per_step'] = d['ms'] / nsteps
+            d['launches_per_step'] = d['launches'] / nsteps
+            d['avg_launch_us'] = 1e3 * d['ms'] / max(1, d['launches'])
+            d['tflops'] = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+        return fam
+
+
+def make_trainer(pg, res, depth, alpha, mb, seed, dp, fmap_base=4096):
+    torch.manual_seed(1337)                       # same weights on every rank (train.py:21)
+    shape = (1, 3, res, res)
+    G = pg.Generator(shape, fmap_base=fmap_base).cuda()
+    D = pg.Discriminator(shape, fmap_base=fmap_base).cuda()
+    G.depth = D.depth = depth
+    G.alpha = D.alpha = alpha
+    gs = 1.0 if dp is None else dp.grad_scale
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99), grad_scale=gs)
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99), grad_scale=gs)
+    ds = pg.utils.SyntheticDataset(res, 3, seed=seed)
+    ds.model_depth = depth
+    pg.wgan_gp_loss.manual_seed(seed)
+    tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, ds.loader(mb),
+                    pg.utils.device_latents(mb, 512, seed=seed + 7), parallel=dp)
+    return tr
+
+
+def timed_steps(tr, steps, warmup, dp):
+    for _ in range(warmup):
+        tr.train()
+    if dp is not None:
+        dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train()
+    torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    if dp is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    return dt
+
+
+def d_step_ms(tr, steps):
+    """per-depth 'D+GP ms' = wgan_gp_D_loss + backward + Adam(D)."""
+    real = next(tr.dataiter)
+    z = tr.random_latents_generator()
+    for _ in range(2):
+        c = tr.D_loss(tr.D, tr.G, real, z)[0]
+        c.backward()
+        tr.optimizer_d.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c = tr.D_loss(tr.D, tr.G, real, z)[0]
+        c.backward()
+        tr.optimizer_d.step()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def cpu_baseline(depth, mb):
+    """The CPU oracle (a restatement of the reference's op sequence, pinned to the reference by the
+    golden fixtures) timed on this host: ONE full train iteration of the same growth stage on a
+    bounded sample (1 image; torch-CPU/oneDNN degrades with >32 threads on these convolutions, so at
+    most 32 threads are used and that is the core count reported)."""
+    from oracle import pggan_cpu as oc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 32)
+    mb = 1
+    torch.set_num_threads(cores)
+    res = 4 * 2 ** depth
+    cfg = oc.NetCfg(1024, 3)
+    torch.manual_seed(1337)
+    gp, dp_ = oc.init_generator(cfg), oc.init_discriminator(cfg)
+    real, z_d, z_g, mix = oc.synthetic_batch(1337, mb, 3, res, 512)
+    og, od = oc.AdamState(), oc.AdamState()
+    t0 = time.perf_counter()
+    oc.train_iteration(gp, dp_, cfg, og, od, real, z_d, z_g, mix, depth, 1.0, 1e-3, 1e-3)
+    dt = time.perf_counter() - t0
+    return dict(value=mb / dt, unit='images/sec', cores=cores, kind='port',
+                sample='1 full train iteration (D+GP step, G step, Adam) at depth %d (%dx%d), minibatch %d, '
+                       'torch-CPU fp32 oracle, %d threads, %.1f s' % (depth, res, res, mb, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--depth', type=int, default=8)
+    ap.add_argument('--alpha', type=float, default=1.0)
+    ap.add_argument('--minibatch', type=int, default=0, help='per-GPU minibatch (default: reference schedule)')
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-per-depth', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--kernel-table', action='store_true', help='per-layer conv timing table on stderr')
+    args = ap.parse_args()
+
+    import pggan_amd as pg
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dp = pg.parallel.DataParallel.from_env() if world > 1 else None
+    rank = 0 if dp is None else dp.rank
+    if dp is None:
+        torch.cuda.set_device(0)
+    n_gpus = world
+    depth = args.depth
+    res = 4 * 2 ** depth
+    mb = args.minibatch or REF_MINIBATCH.get(depth, 16)
+
+    tr = make_trainer(pg, 1024, depth, args.alpha, mb, pg.parallel.shard_seed(1337, rank), dp)
+    if dp is not None:
+        dp.broadcast_params(tr.G, tr.D)
+    dt = timed_steps(tr, args.steps, args.warmup, dp)
+    ms_per_step = 1e3 * dt / args.steps
+    value = n_gpus * mb * args.steps / dt
+
+    out = {
+        'metric': 'images/sec, PGGAN full train step (D+GP step + G step + Adam) at %dx%d' % (res, res),
+        'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'PGGAN (default widths fmap_base=4096, C=3, latent 512) growth stage depth %d = %dx%d, '
+                               'alpha %.2f, minibatch %d per GPU (reference per-depth schedule), Trainer.train() with '
+                               'WGAN-GP (lambda 10) and Adam(0,0.99), fp32' % (depth, res, res, args.alpha, mb),
+                   'resolution': res, 'depth': depth, 'minibatch_per_gpu': mb, 'global_batch': mb * n_gpus,
+                   'parallelism': 'dp%d' % n_gpus},
+    }
+    W = (14 * F_D[depth] + 4 * F_D[depth]) * 1e9 if depth < len(F_D) else None     # F_G ~= F_D
+    if W:
+        out['step_algorithmic_gflop_per_image'] = W / 1e9
+        out['step_mfma_frac'] = W * (value / n_gpus) / MFMA_F32_PEAK
+
+    if rank == 0 and not args.no_kernel_timing:
+        psteps = 3
+        with KernelTimer(pg) as kt:
+            for _ in range(psteps):
+                tr.train()
+            fam = kt.summary(psteps)
+        if args.kernel_table:
+            for tag, t in sorted(kt.table.items(), key=lambda kv: -kv[1]['ms']):
+                sys.stderr.write('%-44s calls/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f\n' % (
+                    tag, t['launches'] / psteps, t['ms'] / psteps, t['flops'] / (t['ms'] * 1e-3) / 1e12))
+        dom = max(fam, key=lambda k: fam[k]['ms'])
+        d = fam[dom]
+        out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': MFMA_F32_PEAK / 1e12,
+                           'unit': 'TFLOP/s', 'frac': d['tflops'] * 1e12 / MFMA_F32_PEAK, 'traffic': None,
+                           'avg_launch_us': d['avg_launch_us'], 'launches_per_step': d['launches_per_step'],
+                           'ms_per_step_in_kernel': d['ms_per_step'],
+                           'algorithmic_gflop_per_step': d['flops_per_step'] / 1e9}
+        out['kernels'] = {k: {'tflops': v['tflops'], 'ms_per_step': v['ms_per_step'],
+                              'launches_per_step': v['launches_per_step'], 'avg_launch_us': v['avg_launch_us']}
+                          for k, v in fam.items()}
+    elif dp is not None and not args.no_kernel_timing:
+        for _ in range(3):                                  # keep collectives matched with rank 0
+            tr.train()
+
+    if not args.no_per_depth and dp is None:
+        per = []
+        del tr
+        torch.cuda.empty_cache()
+        for d in range(0, 9):
+            m = REF_MINIBATCH.get(d, 16)
+            t = make_trainer(pg, 1024, d, 1.0, m, 1337, None)
+            k = 20 if d <= 5 else (8 if d <= 7 else 5)
+            tt = timed_steps(t, k, 3, None)
+            dms = d_step_ms(t, k)
+            Wd = 18 * F_D[d] * 1e9
+            per.append({'depth': d, 'res': 4 * 2 ** d, 'minibatch': m, 'images_per_sec': m * k / tt,
+                        'ms_per_step': 1e3 * tt / k, 'd_step_gp_ms': dms,
+                        'mfma_frac': Wd * (m * k / tt) / MFMA_F32_PEAK})
+            del t
+            torch.cuda.empty_cache()
+        out['per_depth'] = per
+
+    if rank == 0:
+        if not args.no_cpu and n_gpus == 1:
+            out['cpu_baseline'] = cpu_baseline(depth, mb)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if dp is not None:
+        dp.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -36,9 +36,15 @@ def fixture_params(data, prefix):
     return out
 
 
+def _cpu64(t):
+    if torch.is_tensor(t):
+        return t.detach().cpu().to(torch.float64).reshape(-1)
+    return torch.as_tensor(np.asarray(t), dtype=torch.float64).reshape(-1)
+
+
 def rel_err(a, b):
-    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1)
-    b = torch.as_tensor(b, dtype=torch.float64).reshape(-1)
+    """max|a-b| / max|b|  (tensors on any device, numpy arrays or scalars)."""
+    a, b = _cpu64(a), _cpu64(b)
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 

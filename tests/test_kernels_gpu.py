@@ -1,0 +1,241 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point vs the torch-CPU statement of its contract
+(tests/emu_ops.py, itself pinned to the reference through tests/test_engine_host.py).
+Calls go through pggan-pytorch_amd/ops.py -> ctypes -> libpggan_hip.so (the C-ABI)."""
+import numpy as np
+import pytest
+import torch
+
+import emu_ops as E
+from conftest import rel_err
+
+import pggan_amd as pg
+
+pytestmark = pytest.mark.gpu
+ops = pg.ops
+TOL = 2e-5
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g)
+
+
+def check(name, a, b, tol=TOL):
+    e = rel_err(a.cpu(), b)
+    print('%-60s rel_err %.2e' % (name, e))
+    assert e < tol, (name, e)
+
+
+CONV_CASES = [
+    # N, Hin(after ups), Cin, Cout, ks, pad, ups
+    (2, 32, 64, 64, 3, 1, 0), (3, 16, 128, 96, 3, 1, 0), (2, 32, 32, 32, 3, 1, 0), (2, 64, 16, 16, 3, 1, 0),
+    (1, 64, 8, 8, 3, 1, 0), (2, 32, 8, 16, 3, 1, 0), (2, 16, 4, 4, 3, 1, 0), (2, 16, 12, 20, 3, 1, 0),
+    (5, 4, 32, 16, 3, 1, 0), (3, 4, 48, 64, 3, 1, 0), (7, 4, 16, 16, 4, 0, 0), (48, 4, 64, 64, 4, 0, 0),
+    (6, 1, 16, 32, 4, 3, 0), (20, 1, 64, 64, 4, 3, 0), (2, 16, 32, 32, 1, 0, 0), (2, 16, 16, 16, 3, 1, 1),
+    (3, 8, 64, 32, 3, 1, 1), (3, 8, 528, 512, 3, 1, 0), (1, 256, 8, 8, 3, 1, 0), (2, 128, 16, 32, 3, 1, 1),
+    (70, 1, 32, 32, 4, 3, 0), (130, 4, 16, 16, 4, 0, 0),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd_and_masked(case):
+    N, H, ci, co, ks, pad, ups = case
+    hin = H // 2 if ups else H
+    x, w, b = rnd(N, hin, hin, ci), rnd(ks, ks, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    ho = H + 2 * pad - ks + 1
+    y = ops.conv2d(dev(x), dev(w), dev(b), N, H, H, ks, pad, 0.37, slope=0.2, ups=bool(ups))
+    check('conv fwd %s' % (case,), y, E.conv2d(x, w, b, N, H, H, ks, pad, 0.37, slope=0.2, ups=bool(ups)))
+    m = rnd(N, ho, ho, co, seed=3)
+    y = ops.conv2d(dev(x), dev(w), None, N, H, H, ks, pad, 0.37, mask=dev(m), mask_slope=0.2, ups=bool(ups))
+    check('conv masked %s' % (case,), y, E.conv2d(x, w, None, N, H, H, ks, pad, 0.37, mask=m, mask_slope=0.2, ups=bool(ups)))
+    y = ops.conv2d(dev(x), dev(w), dev(b), N, H, H, ks, pad, 1.0, slope=1.0, ups=bool(ups))
+    check('conv linear %s' % (case,), y, E.conv2d(x, w, b, N, H, H, ks, pad, 1.0, slope=1.0, ups=bool(ups)))
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_wgrad(case):
+    N, H, ci, co, ks, pad, ups = case
+    hin = H // 2 if ups else H
+    ho = H + 2 * pad - ks + 1
+    x, gz = rnd(N, hin, hin, ci), rnd(N, ho, ho, co, seed=5)
+    dw0, db0 = rnd(ks, ks, co, ci, seed=6), rnd(co, seed=7)
+    dw, db = dev(dw0.clone()), dev(db0.clone())
+    ops.conv2d_wgrad(dev(x), dev(gz), dw, db, N, H, H, ks, pad, 0.41, ups=bool(ups))
+    rw, rb = dw0.clone(), db0.clone()
+    E.conv2d_wgrad(x, gz, rw, rb, N, H, H, ks, pad, 0.41, ups=bool(ups))
+    check('wgrad dw %s' % (case,), dw, rw, 5e-5)
+    check('wgrad db %s' % (case,), db, rb, 5e-5)
+    dw = dev(dw0.clone())
+    ops.conv2d_wgrad(dev(x), dev(gz), dw, None, N, H, H, ks, pad, 0.41, ups=bool(ups))
+    check('wgrad dw (no bias) %s' % (case,), dw, rw, 5e-5)
+
+
+@pytest.mark.parametrize('ks,co,ci', [(3, 64, 32), (1, 16, 8), (4, 20, 12), (3, 512, 528)])
+def test_pack_dgrad(ks, co, ci):
+    w = rnd(ks, ks, co, ci)
+    wt = torch.empty(ks, ks, ci, co).cuda()
+    ops.pack_dgrad_weights(dev(w), wt)
+    ref = torch.empty(ks, ks, ci, co)
+    E.pack_dgrad_weights(w, ref)
+    assert torch.equal(wt.cpu(), ref)
+
+
+def test_dgrad_is_adjoint_of_conv():
+    """<conv(x), g> == <x, dgrad(g)> with the packed backward-data weights (transpose-detecting)."""
+    for (N, H, ci, co, ks, pad) in [(2, 16, 16, 32, 3, 1), (3, 4, 32, 16, 4, 0), (2, 8, 8, 8, 1, 0)]:
+        x, w = rnd(N, H, H, ci), rnd(ks, ks, co, ci, seed=1)
+        ho = H + 2 * pad - ks + 1
+        g = rnd(N, ho, ho, co, seed=2)
+        y = ops.conv2d(dev(x), dev(w), None, N, H, H, ks, pad, 1.0)
+        wt = torch.empty(ks, ks, ci, co).cuda()
+        ops.pack_dgrad_weights(dev(w), wt)
+        gx = ops.conv2d(dev(g), wt, None, N, ho, ho, ks, ks - 1 - pad, 1.0)
+        a = float((y.cpu().double() * g.double()).sum())
+        b = float((x.double() * gx.cpu().double()).sum())
+        print('adjoint', a, b)
+        assert abs(a - b) < 1e-4 * max(1.0, abs(a))
+
+
+RGB_CASES = [(2, 3, 16, 16), (3, 1, 8, 32), (2, 3, 4, 512), (1, 3, 64, 8), (2, 4, 8, 12)]
+
+
+@pytest.mark.parametrize('N,C,H,co', RGB_CASES)
+@pytest.mark.parametrize('pool', [False, True])
+def test_fromrgb(N, C, H, co, pool):
+    hi = 2 * H if pool else H
+    img, w, b = rnd(N, C, hi, hi), rnd(co, C, seed=1), rnd(co, seed=2)
+    y = ops.fromrgb_fwd(dev(img), dev(w), dev(b), N, C, H, H, 0.8, 0.2, pool=pool)
+    check('fromrgb fwd', y, E.fromrgb_fwd(img, w, b, N, C, H, H, 0.8, 0.2, pool=pool))
+    m = rnd(N, H, H, co, seed=3)
+    y = ops.fromrgb_fwd(dev(img), dev(w), None, N, C, H, H, 0.8, 1.0, pool=pool, mask=dev(m), mask_slope=0.2)
+    check('fromrgb masked', y, E.fromrgb_fwd(img, w, None, N, C, H, H, 0.8, 1.0, pool=pool, mask=m, mask_slope=0.2))
+    gz = rnd(N, H, H, co, seed=4)
+    for acc in (False, True):
+        g0 = rnd(N, C, hi, hi, seed=5)
+        gi = dev(g0.clone())
+        ops.fromrgb_bwd_data(dev(gz), dev(w), gi, N, C, H, H, 0.8, pool=pool, accumulate=acc)
+        r = g0.clone()
+        E.fromrgb_bwd_data(gz, w, r, N, C, H, H, 0.8, pool=pool, accumulate=acc)
+        check('fromrgb bwd_data acc=%s' % acc, gi, r)
+    dw0, db0 = rnd(co, C, seed=6), rnd(co, seed=7)
+    dw, db = dev(dw0.clone()), dev(db0.clone())
+    ops.fromrgb_wgrad(dev(gz), dev(img), dw, db, N, C, H, H, 0.8, pool=pool)
+    rw, rb = dw0.clone(), db0.clone()
+    E.fromrgb_wgrad(gz, img, rw, rb, N, C, H, H, 0.8, pool=pool)
+    check('fromrgb wgrad', dw, rw, 5e-5)
+    check('fromrgb bgrad', db, rb, 5e-5)
+
+
+@pytest.mark.parametrize('N,C,H,ci', RGB_CASES)
+def test_torgb(N, C, H, ci):
+    x, w, b = rnd(N, H, H, ci), rnd(C, ci, seed=1), rnd(C, seed=2)
+    prev = rnd(N, C, H // 2, H // 2, seed=3)
+    y = ops.torgb_fwd(dev(x), dev(w), dev(b), N, C, H, H, 0.7)
+    check('torgb fwd', y, E.torgb_fwd(x, w, b, N, C, H, H, 0.7))
+    y = ops.torgb_fwd(dev(x), dev(w), dev(b), N, C, H, H, 0.7, out_mul=0.3, prev=dev(prev), prev_mul=0.7)
+    check('torgb blend', y, E.torgb_fwd(x, w, b, N, C, H, H, 0.7, out_mul=0.3, prev=prev, prev_mul=0.7))
+    g = rnd(N, C, H, H, seed=4)
+    check('torgb bwd_data', ops.torgb_bwd_data(dev(g), dev(w), N, C, H, H, 0.21), E.torgb_bwd_data(g, w, N, C, H, H, 0.21))
+    g2 = rnd(N, C, 2 * H, 2 * H, seed=5)
+    check('torgb bwd_data down', ops.torgb_bwd_data(dev(g2), dev(w), N, C, H, H, 0.21, down=True),
+          E.torgb_bwd_data(g2, w, N, C, H, H, 0.21, down=True))
+    for down, gg in ((False, g), (True, g2)):
+        dw0, db0 = rnd(C, ci, seed=6), rnd(C, seed=7)
+        dw, db = dev(dw0.clone()), dev(db0.clone())
+        ops.torgb_wgrad(dev(gg), dev(x), dw, db, N, C, H, H, 0.21, 0.3, down=down)
+        rw, rb = dw0.clone(), db0.clone()
+        E.torgb_wgrad(gg, x, rw, rb, N, C, H, H, 0.21, 0.3, down=down)
+        check('torgb wgrad down=%s' % down, dw, rw, 5e-5)
+        check('torgb bgrad down=%s' % down, db, rb, 5e-5)
+
+
+@pytest.mark.parametrize('N,H,C', [(2, 8, 16), (3, 4, 512), (1, 64, 8), (2, 2, 4)])
+def test_pool_upsample_axpby(N, H, C):
+    x, o = rnd(N, 2 * H, 2 * H, C), rnd(N, H, H, C, seed=1)
+    check('avgpool', ops.avgpool2_fwd(dev(x)), E.avgpool2_fwd(x))
+    check('avgpool blend', ops.avgpool2_fwd(dev(x), dev(o), 0.3, 0.7), E.avgpool2_fwd(x, o, 0.3, 0.7))
+    gy, m = rnd(N, H, H, C, seed=2), rnd(N, 2 * H, 2 * H, C, seed=3)
+    check('avgpool bwd', ops.avgpool2_bwd(dev(gy), dev(m), 0.3, 0.2), E.avgpool2_bwd(gy, m, 0.3, 0.2))
+    check('avgpool bwd nomask', ops.avgpool2_bwd(dev(gy)), E.avgpool2_bwd(gy))
+    check('upsample bwd', ops.upsample2_bwd(dev(x)), E.upsample2_bwd(x))
+    check('axpby', ops.axpby_mask(dev(x), dev(m), dev(m), 0.3, 0.7, 0.2), E.axpby_mask(x, m, m, 0.3, 0.7, 0.2))
+    check('scale', ops.axpby_mask(dev(x), a=0.3), E.axpby_mask(x, a=0.3))
+
+
+@pytest.mark.parametrize('P,C', [(64, 512), (1000, 16), (4096, 8), (37, 4), (5, 32), (300, 256), (16, 64)])
+def test_pixelnorm(P, C):
+    x = rnd(P, C)
+    y, r = ops.pixelnorm_fwd(dev(x))
+    ry, rr = E.pixelnorm_fwd(x)
+    check('pn fwd', y, ry)
+    check('pn r', r, rr)
+    gy = rnd(P, C, seed=1)
+    check('pn bwd', ops.pixelnorm_lrelu_bwd(dev(gy), y, r, 0.2), E.pixelnorm_lrelu_bwd(gy, ry, rr, 0.2))
+    check('lrelu-only bwd', ops.pixelnorm_lrelu_bwd(dev(gy), y, None, 0.2), E.pixelnorm_lrelu_bwd(gy, ry, None, 0.2))
+
+
+@pytest.mark.parametrize('G,n,C', [(1, 4, 16), (3, 3, 512), (3, 16, 512), (2, 5, 32)])
+def test_mbstd(G, n, C):
+    cp = C + 16
+    x = rnd(G * n, 4, 4, C) + 0.3
+    y, st = ops.mbstd_fwd(dev(x), G, cp)
+    ry, rst = E.mbstd_fwd(x, G, cp)
+    check('mbstd fwd', y, ry)
+    check('mbstd stats', st, rst)
+    tx = rnd(G * n, 4, 4, C, seed=1)
+    ty, ts = ops.mbstd_tangent(dev(x), dev(tx), st, cp)
+    rty, rts = E.mbstd_tangent(x, tx, rst, cp)
+    check('mbstd tangent', ty, rty)
+    check('mbstd tstats', ts, rts, 1e-4)
+    gy, gf = rnd(G * n, 4, 4, cp, seed=2), rnd(G * n, 4, 4, cp, seed=3)
+    for am in (False, True):
+        check('mbstd bwd mask=%s' % am, ops.mbstd_bwd(dev(gy), dev(x), st, cp, am, 0.2), E.mbstd_bwd(gy, x, rst, cp, am, 0.2))
+        check('mbstd bwd+hvp', ops.mbstd_bwd(dev(gy), dev(x), st, cp, am, 0.2, tx=dev(tx), tstats=ts, gy_first=dev(gf)),
+              E.mbstd_bwd(gy, x, rst, cp, am, 0.2, tx=tx, tstats=rts, gy_first=gf), 1e-4)
+        check('mbstd hvp only', ops.mbstd_bwd(None, dev(x), st, cp, am, 0.2, tx=dev(tx), tstats=ts, gy_first=dev(gf)),
+              E.mbstd_bwd(None, x, rst, cp, am, 0.2, tx=tx, tstats=rts, gy_first=gf), 1e-4)
+
+
+def test_linear_gp_loss_adam():
+    N, C = 9, 512
+    h, w, b = rnd(N, 1, 1, C), rnd(1, C, seed=1), rnd(1, seed=2)
+    s = ops.linear1_fwd(dev(h), dev(w), dev(b))
+    check('linear fwd', s, E.linear1_fwd(h, w, b))
+    gs = rnd(N, seed=3)
+    check('linear bwd', ops.linear1_bwd_data(dev(gs), dev(w), dev(h), h.shape, 0.2), E.linear1_bwd_data(gs, w, h, h.shape, 0.2))
+    dw0, db0 = rnd(1, C, seed=4), rnd(1, seed=5)
+    dw, db = dev(dw0.clone()), dev(db0.clone())
+    ops.linear1_wgrad(dev(gs), dev(h), dw, db)
+    rw, rb = dw0.clone(), db0.clone()
+    E.linear1_wgrad(gs, h, rw, rb)
+    check('linear wgrad', dw, rw)
+    check('linear bgrad', db, rb)
+    real, fake, m = rnd(4, 3, 16, 16), rnd(4, 3, 16, 16, seed=1), torch.rand(4)
+    check('gp mix', ops.gp_mix(dev(real), dev(fake), dev(m)), E.gp_mix(real, fake, m))
+    ss = ops.row_sumsq(dev(real))
+    check('row sumsq', ss, E.row_sumsq(real))
+    gp, u = ops.gp_seed(dev(real), ss, 10.0, 1.0, 0.25)
+    rgp, ru = E.gp_seed(real, E.row_sumsq(real), 10.0, 1.0, 0.25)
+    check('gp', gp, rgp)
+    check('gp seed', u, ru)
+    sc, gpv = rnd(12, seed=7), torch.rand(4)
+    out = ops.d_loss(dev(sc), dev(gpv), 4, 0.001)
+    ref = E.d_loss(sc, gpv, 4, 0.001)
+    for nm, a, r in zip(('d_cost', 'd_real_loss', 'd_fake_loss', 'gscore'), out, ref):
+        check('d_loss ' + nm, a, r)
+    gc, gsc = ops.g_loss(dev(sc))
+    rgc, rgsc = E.g_loss(sc)
+    check('g_cost', gc, rgc)
+    check('g gscore', gsc, rgsc)
+    n = 1003
+    p, g, mm, vv = rnd(n), rnd(n, seed=1), rnd(n, seed=2) * 0.1, rnd(n, seed=3).abs() * 0.1
+    dp, dg, dm, dv = dev(p.clone()), dev(g), dev(mm.clone()), dev(vv.clone())
+    ops.adam(dp, dg, dm, dv, 1e-3, 0.0, 0.99, 1e-8, 1.0, 0.3, 0.5)
+    E.adam(p, g, mm, vv, 1e-3, 0.0, 0.99, 1e-8, 1.0, 0.3, 0.5)
+    check('adam p', dp, p)
+    check('adam m', dm, mm)
+    check('adam v', dv, vv)
