@@ -9,6 +9,12 @@
 // MFMA roles: A = weights (row i = cout), B = activations (col j = pixel); the C/D fragment then
 // holds 4 consecutive couts of one pixel per lane -> 16-byte NHWC stores.
 // Exact fp32 FMA chain (no reduced-precision path): parity with the fp32 CPU oracle to ~1e-6.
+//
+// Pipeline (both kernels): per-thread load descriptors are computed once; the NEXT K-chunk / pixel
+// tile is fetched global->VGPR while the MFMAs of the current one run out of LDS (one LDS buffer,
+// two workgroups per CU), and inside a chunk the fragments of the next tap / k-step are read
+// from LDS while the current MFMAs issue.  LDS row strides are chosen conflict-free for the
+// lane groups of ds_read_b128 / ds_read_b32 on gfx950 (24 floats for 16-channel rows).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "pggan_hip.h"
@@ -33,24 +39,35 @@ struct ConvP {
     int N, Hin, Win, Cin, Cout, Hout, Wout, KS, pad, ups;
     float scale, slope, mask_slope;
     int lgTW, lgTH, TN, tilesW, tilesH;
+    int ksplit;                 // >1: blockIdx.z owns a slice of the Cin chunks, partial sums are
+                                // committed with fp32 atomics into a pre-zeroed y (epilogue deferred)
 };
+
+// LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
+//   VEC=4 (ds_read_b128, 4x16 lanes, 64 banks): 24   VEC=2 (ds_read_b64): 12   VEC=1: 8
+template <int VEC> struct RowStride { static constexpr int value = VEC == 4 ? 24 : (VEC == 2 ? 12 : 8); };
 
 // One workgroup (4 waves) computes BCO couts x BPX output pixels; the pixel tile is
 // TN images x TH x TW (powers of two) so that the (KS-1)-halo of the input is staged once in LDS
 // and every tap is a shifted read of the same tile.
-template <int VEC, int WAVES_CO, int WM, int WN>
+template <int KS, int VEC, int WAVES_CO, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 {
     constexpr int WAVES_PX = 4 / WAVES_CO;
-    constexpr int BCO = 16 * WM * WAVES_CO;
-    constexpr int KC = 4 * VEC, KCP = KC + 4;
+    constexpr int BCO = 16 * WM * WAVES_CO, BPX = 16 * WN * WAVES_PX;
+    constexpr int KC = 4 * VEC, KCP = RowStride<VEC>::value;
+    constexpr int TAPS = KS * KS;
+    constexpr int WEL = TAPS * BCO * VEC;                       // float4 elements of one weight chunk
+    constexpr int WPT = (WEL + 255) / 256;
+    // halo pixels of a tile: <= BPX*(1+2/TH)(1+2/TW) <= 2.25*BPX for KS=3 (TH,TW>=4); KS=4 uses BPX=16
+    constexpr int XMAX = KS == 1 ? BPX : (KS == 3 ? (BPX * 9) / 4 : 16 * BPX);
+    constexpr int XPT = (XMAX * VEC + 255) / 256;
     extern __shared__ __align__(16) float lds[];
 
     const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
-    const int HT = TH + p.KS - 1, WT = TW + p.KS - 1;
-    const int taps = p.KS * p.KS;
-    float* wt = lds;                          // [taps][BCO][KCP]
-    float* xt = lds + taps * BCO * KCP;       // [TN][HT][WT][KCP]
+    const int HT = TH + KS - 1, WT = TW + KS - 1;
+    float* wt = lds;                          // [TAPS][BCO][KCP]
+    float* xt = lds + TAPS * BCO * KCP;       // [TN][HT][WT][KCP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_co = wave % WAVES_CO, wave_px = wave / WAVES_CO;
@@ -73,53 +90,88 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 #pragma unroll
     for (int m = 0; m < WM; ++m) wbase[m] = ((wave_co * WM + m) * 16 + li) * KCP + VEC * kk;
 
+    // ---- per-thread load descriptors (element offsets without the channel-chunk offset; -1 = zero fill)
+    const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
+    const int npix = p.TN * HT * WT;
+    int wsrc[WPT], wdst[WPT], xsrc[XPT], xdst[XPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / VEC, v = idx - r * VEC;
+        const int tap = r / BCO, col = r - tap * BCO, co = co0 + col;
+        wdst[i] = idx < WEL ? r * KCP + 4 * v : -1;
+        wsrc[i] = (idx < WEL && co < p.Cout) ? ((tap * p.Cout + co) * p.Cin + 4 * v) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / VEC, v = idx - q * VEC;
+        const int tw = q % WT, r2 = q / WT, th = r2 % HT, tn = r2 / HT;
+        const int n = n0 + tn;
+        int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
+        const bool in_tile = q < npix;
+        const bool ok = in_tile && n < p.N && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        if (p.ups) { ih >>= 1; iw >>= 1; }
+        xdst[i] = in_tile ? q * KCP + 4 * v : -1;
+        xsrc[i] = ok ? (((n * xH + ih) * xW + iw) * p.Cin + 4 * v) : -1;
+    }
+    int tapoff[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) tapoff[tp] = ((tp / KS) * WT + (tp % KS)) * KCP;
+
     f32x4 acc[WM][WN];
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int n = 0; n < WN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
-    const int wrows = taps * BCO;
-    const int npix = p.TN * HT * WT;
+    const int nchunks = p.Cin / KC;
+    const int cper = (nchunks + p.ksplit - 1) / p.ksplit;
+    const int kc_begin = blockIdx.z * cper;
+    const int kc_end = min(nchunks, kc_begin + cper);
 
-    for (int k0 = 0; k0 < p.Cin; k0 += KC) {
-        for (int idx = tid; idx < wrows * VEC; idx += 256) {
-            const int r = idx / VEC, v = idx - r * VEC;
-            const int tap = r / BCO, col = r - tap * BCO, co = co0 + col;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < p.Cout)
-                val = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * p.Cout + co) * p.Cin + k0 + 4 * v));
-            *reinterpret_cast<float4*>(wt + r * KCP + 4 * v) = val;
-        }
-        for (int idx = tid; idx < npix * VEC; idx += 256) {
-            const int q = idx / VEC, v = idx - q * VEC;
-            const int tw = q % WT, r2 = q / WT, th = r2 % HT, tn = r2 / HT;
-            const int n = n0 + tn;
-            int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.N && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
-                if (p.ups) { ih >>= 1; iw >>= 1; }
-                val = *reinterpret_cast<const float4*>(p.x + (((size_t)n * xH + ih) * xW + iw) * p.Cin + k0 + 4 * v);
-            }
-            *reinterpret_cast<float4*>(xt + q * KCP + 4 * v) = val;
-        }
+    float4 wreg[WPT], xreg[XPT];
+    auto fetch = [&](int kc) {
+        const int k0 = kc * KC;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            wreg[i] = wsrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.w + (size_t)(unsigned)(wsrc[i] + k0))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+            xreg[i] = xsrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)(xsrc[i] + k0))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    if (kc_begin < kc_end) fetch(kc_begin);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) if (wdst[i] >= 0) *reinterpret_cast<float4*>(wt + wdst[i]) = wreg[i];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) if (xdst[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
         __syncthreads();
-        for (int kh = 0; kh < p.KS; ++kh) {
-            for (int kw = 0; kw < p.KS; ++kw) {
-                const int tap = kh * p.KS + kw;
-                float a[WM][VEC], b[WN][VEC];
+        if (kc + 1 < kc_end) fetch(kc + 1);              // in flight while the MFMAs below run
+
+        float a[2][WM][VEC], b[2][WN][VEC];
 #pragma unroll
-                for (int m = 0; m < WM; ++m) lds_load<VEC>(wt + tap * BCO * KCP + wbase[m], a[m]);
+        for (int m = 0; m < WM; ++m) lds_load<VEC>(wt + wbase[m], a[0][m]);
 #pragma unroll
-                for (int n = 0; n < WN; ++n) lds_load<VEC>(xt + pixbase[n] + (kh * WT + kw) * KCP, b[n]);
+        for (int n = 0; n < WN; ++n) lds_load<VEC>(xt + pixbase[n] + tapoff[0], b[0][n]);
 #pragma unroll
-                for (int s = 0; s < VEC; ++s)
+        for (int tp = 0; tp < TAPS; ++tp) {
+            const int cur = tp & 1, nxt = cur ^ 1;
+            if (tp + 1 < TAPS) {
 #pragma unroll
-                    for (int m = 0; m < WM; ++m)
+                for (int m = 0; m < WM; ++m) lds_load<VEC>(wt + (tp + 1) * BCO * KCP + wbase[m], a[nxt][m]);
 #pragma unroll
-                        for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(a[m][s], b[n][s], acc[m][n]);
+                for (int n = 0; n < WN; ++n) lds_load<VEC>(xt + pixbase[n] + tapoff[tp + 1], b[nxt][n]);
             }
+#pragma unroll
+            for (int s = 0; s < VEC; ++s)
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(a[cur][m][s], b[cur][n][s], acc[m][n]);
         }
         __syncthreads();
     }
@@ -141,6 +193,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
             float4 o;
             o.x = acc[m][n][0] * p.scale; o.y = acc[m][n][1] * p.scale;
             o.z = acc[m][n][2] * p.scale; o.w = acc[m][n][3] * p.scale;
+            if (p.ksplit > 1) {
+                atomicAdd(p.y + off + 0, o.x); atomicAdd(p.y + off + 1, o.y);
+                atomicAdd(p.y + off + 2, o.z); atomicAdd(p.y + off + 3, o.w);
+                continue;
+            }
             if (p.mask) {
                 const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
                 o.x *= mk.x > 0.f ? 1.f : p.mask_slope; o.y *= mk.y > 0.f ? 1.f : p.mask_slope;
@@ -155,31 +212,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     }
 }
 
+// Deferred epilogue of a split-K launch: y = mask ? y*lrelu'(mask) : lrelu(y + bias)   (in place)
+__global__ __launch_bounds__(256) void conv_epilogue_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                            const float* __restrict__ mask, size_t npix, int Cout,
+                                                            float slope, float mask_slope)
+{
+    const int c4n = Cout >> 2;
+    const size_t total = npix * c4n;
+    float4* y4 = reinterpret_cast<float4*>(y);
+    const float4* m4 = reinterpret_cast<const float4*>(mask);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float4 o = y4[i];
+        if (mask) {
+            const float4 mk = m4[i];
+            o.x *= mk.x > 0.f ? 1.f : mask_slope; o.y *= mk.y > 0.f ? 1.f : mask_slope;
+            o.z *= mk.z > 0.f ? 1.f : mask_slope; o.w *= mk.w > 0.f ? 1.f : mask_slope;
+        } else {
+            if (bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 4 * (i % c4n));
+                o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+            }
+            o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+            o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+        }
+        y4[i] = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 struct WgP {
     const float* x; const float* gz; float* dw; float* db;
     int N, Hin, Win, Cin, Cout, Hout, Wout, pad, ups;
     float scale;
     int lgTW, lgTH, TN, tilesW, tilesH, ntiles, tiles_per_block;
+    int atomic;                 // 0: this workgroup is the only writer of its dW block -> plain +=
 };
+
+// row stride == 16 (mod 32): the two 32-lane groups of ds_read_b32 hit disjoint banks
+template <int B> struct PixStride { static constexpr int value = (B % 32 == 16) ? B : B + 16; };
 
 // dW[tap][co][ci] = sum over pixels: A = gz (row i = cout), B = shifted x (col j = cin), the MFMA
 // k index runs over PIXELS (4 per instruction).  One workgroup owns a (BCO x BCI) block of every
-// tap and a slice of the pixel tiles; partial sums are committed with fp32 atomics.
-template <int KS, int WM, int WN, int WAVES_CO, int WAVES_CI>
+// tap and a slice of the pixel tiles; its WAVES_K waves split the pixels of a tile and are reduced
+// through LDS before ONE commit per workgroup (plain += when it is the only writer, else atomics).
+template <int KS, int WM, int WN, int WAVES_CO, int WAVES_CI, int BPX>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p)
 {
     constexpr int WAVES_K = 4 / (WAVES_CO * WAVES_CI);
     constexpr int BCO = 16 * WM * WAVES_CO, BCI = 16 * WN * WAVES_CI;
-    constexpr int SZ = BCO + 16, SX = BCI + 16;      // row strides == 16 (mod 32): conflict-free b32 reads
+    constexpr int SZ = PixStride<BCO>::value, SX = PixStride<BCI>::value;
     constexpr int TAPS = KS * KS;
+    constexpr int ZV = BCO / 4, XV = BCI / 4;
+    constexpr int ZPT = (BPX * ZV + 255) / 256;
+    constexpr int XMAX = KS == 1 ? BPX : (KS == 3 ? (BPX * 9) / 4 : 16 * BPX);
+    constexpr int XPT = (XMAX * XV + 255) / 256;
     extern __shared__ __align__(16) float lds[];
 
     const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
     const int HT = TH + KS - 1, WT = TW + KS - 1;
-    const int TPIX = p.TN << (p.lgTW + p.lgTH);
-    float* gzt = lds;                        // [TPIX][SZ]
-    float* xt = lds + TPIX * SZ;             // [TN*HT*WT][SX]
+    float* gzt = lds;                        // [BPX][SZ]
+    float* xt = lds + BPX * SZ;              // [TN*HT*WT][SX]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_co = wave % WAVES_CO, wave_ci = (wave / WAVES_CO) % WAVES_CI, wave_k = wave / (WAVES_CO * WAVES_CI);
@@ -200,66 +292,150 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p)
 
     const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
     const int npix = p.TN * HT * WT;
-    constexpr int ZV = BCO / 4, XV = BCI / 4;
 
-    const int t_begin = blockIdx.x * p.tiles_per_block;
-    const int t_end = min(t_begin + p.tiles_per_block, p.ntiles);
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // ---- per-thread load descriptors: tile-relative coordinates (no div/mod in the tile loop)
+    int zq[ZPT], zc[ZPT];                    // pixel-in-tile, cout offset
+    int xq[XPT], xc[XPT], xdst[XPT];         // packed (tn,th,tw) of the halo pixel, cin offset, LDS offset
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / ZV, v = idx - q * ZV;
+        zq[i] = idx < BPX * ZV ? q : -1;
+        zc[i] = co0 + 4 * v;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / XV, v = idx - q * XV;
+        const int tw = q % WT, r2 = q / WT, th = r2 % HT, tn = r2 / HT;
+        xq[i] = q < npix ? ((tn << 20) | (th << 10) | tw) : -1;
+        xc[i] = ci0 + 4 * v;
+        xdst[i] = q * SX + 4 * v;
+    }
+    int tapoff[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) tapoff[tp] = ((tp / KS) * WT + (tp % KS)) * SX;
+
+    float4 zreg[ZPT], xreg[XPT];
+    auto fetch = [&](int tile) {
         int t = tile;
         const int tw_i = t % p.tilesW; t /= p.tilesW;
         const int th_i = t % p.tilesH; t /= p.tilesH;
         const int n0 = t * p.TN;
         const int oh0 = th_i << p.lgTH, ow0 = tw_i << p.lgTW;
-
-        for (int idx = tid; idx < TPIX * ZV; idx += 256) {
-            const int q = idx / ZV, v = idx - q * ZV;
-            const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
-            const int n = n0 + tn, co = co0 + 4 * v;
+#pragma unroll
+        for (int i = 0; i < ZPT; ++i) {
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.N && co < p.Cout)
-                val = *reinterpret_cast<const float4*>(p.gz + (((size_t)n * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * p.Cout + co);
-            *reinterpret_cast<float4*>(gzt + q * SZ + 4 * v) = val;
-        }
-        for (int idx = tid; idx < npix * XV; idx += 256) {
-            const int q = idx / XV, v = idx - q * XV;
-            const int tw = q % WT, r2 = q / WT, th = r2 % HT, tn = r2 / HT;
-            const int n = n0 + tn, ci = ci0 + 4 * v;
-            int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.N && ci < p.Cin && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
-                if (p.ups) { ih >>= 1; iw >>= 1; }
-                val = *reinterpret_cast<const float4*>(p.x + (((size_t)n * xH + ih) * xW + iw) * p.Cin + ci);
+            if (zq[i] >= 0) {
+                const int q = zq[i];
+                const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
+                const int n = n0 + tn;
+                if (n < p.N && zc[i] < p.Cout)
+                    val = *reinterpret_cast<const float4*>(p.gz + (((size_t)n * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * p.Cout + zc[i]);
             }
-            *reinterpret_cast<float4*>(xt + q * SX + 4 * v) = val;
+            zreg[i] = val;
         }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xq[i] >= 0) {
+                const int tw = xq[i] & 1023, th = (xq[i] >> 10) & 1023, tn = xq[i] >> 20;
+                const int n = n0 + tn;
+                int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
+                if (n < p.N && xc[i] < p.Cin && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
+                    if (p.ups) { ih >>= 1; iw >>= 1; }
+                    val = *reinterpret_cast<const float4*>(p.x + (((size_t)n * xH + ih) * xW + iw) * p.Cin + xc[i]);
+                }
+            }
+            xreg[i] = val;
+        }
+    };
+
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.ntiles);
+    constexpr int NSTEPS = BPX / 4;
+
+    if (t_begin < t_end) fetch(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+#pragma unroll
+        for (int i = 0; i < ZPT; ++i)
+            if (zq[i] >= 0) *reinterpret_cast<float4*>(gzt + zq[i] * SZ + (zc[i] - co0)) = zreg[i];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+            if (xq[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
         __syncthreads();
-        const int nsteps = TPIX >> 2;
-        for (int step = wave_k; step < nsteps; step += WAVES_K) {
+        if (tile + 1 < t_end) fetch(tile + 1);            // in flight while the MFMAs below run
+
+        // k-steps of this wave: step = wave_k, wave_k + WAVES_K, ...  (4 pixels each, same tile row)
+        auto frag_addr = [&](int step, int& aoff, int& boff) {
             const int q = 4 * step + kk;
             const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
-            float a[WM];
+            aoff = q * SZ + wave_co * WM * 16 + li;
+            boff = ((tn * HT + th) * WT + tw) * SX + wave_ci * WN * 16 + li;
+        };
+        float a[2][WM], b[2][TAPS][WN];
+        auto load_frags = [&](int step, float (&af)[WM], float (&bf)[TAPS][WN]) {
+            int ao, bo; frag_addr(step, ao, bo);
 #pragma unroll
-            for (int m = 0; m < WM; ++m) a[m] = gzt[q * SZ + (wave_co * WM + m) * 16 + li];
+            for (int m = 0; m < WM; ++m) af[m] = gzt[ao + m * 16];
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) bf[tp][n] = xt[bo + tapoff[tp] + n * 16];
+        };
+        auto mfmas = [&](const float (&af)[WM], const float (&bf)[TAPS][WN]) {
             if (do_bias) {
 #pragma unroll
-                for (int m = 0; m < WM; ++m) accb[m] = MFMA16(a[m], 1.0f, accb[m]);
+                for (int m = 0; m < WM; ++m) accb[m] = MFMA16(af[m], 1.0f, accb[m]);
             }
-            const float* xrow = xt + ((tn * HT + th) * WT + tw) * SX + wave_ci * WN * 16 + li;
 #pragma unroll
-            for (int kh = 0; kh < KS; ++kh)
+            for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-                for (int kw = 0; kw < KS; ++kw) {
-                    float b[WN];
+                for (int m = 0; m < WM; ++m)
 #pragma unroll
-                    for (int n = 0; n < WN; ++n) b[n] = xrow[(kh * WT + kw) * SX + n * 16];
+                    for (int n = 0; n < WN; ++n) acc[tp][m][n] = MFMA16(af[m], bf[tp][n], acc[tp][m][n]);
+        };
+        constexpr int T = NSTEPS / WAVES_K;              // even for every instantiated shape
+        static_assert(T % 2 == 0, "k-steps per wave must be even");
+        load_frags(wave_k, a[0], b[0]);
+        for (int s = 0; s < T; s += 2) {                 // ping-pong: next step's LDS reads under this step's MFMAs
+            load_frags(wave_k + (s + 1) * WAVES_K, a[1], b[1]);
+            mfmas(a[0], b[0]);
+            if (s + 2 < T) load_frags(wave_k + (s + 2) * WAVES_K, a[0], b[0]);
+            mfmas(a[1], b[1]);
+        }
+        __syncthreads();
+    }
+
+    // ---- reduce the WAVES_K partial sums through LDS (tile buffers are free now), then commit once
+    if (WAVES_K > 1) {
+        // layout: red[(wave_co,wave_ci)][tile index t = (tp*WM+m)*WN+n (+bias tiles)][lane*4+r]
+        constexpr int NT = TAPS * WM * WN + WM;
+        float* red = lds + (wave_co + WAVES_CO * wave_ci) * NT * 256;
+        for (int w = 0; w < WAVES_K; ++w) {
+            if (wave_k == w) {
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
                     for (int m = 0; m < WM; ++m)
 #pragma unroll
-                        for (int n = 0; n < WN; ++n)
-                            acc[kh * KS + kw][m][n] = MFMA16(a[m], b[n], acc[kh * KS + kw][m][n]);
+                        for (int n = 0; n < WN; ++n) {
+                            float4* r4 = reinterpret_cast<float4*>(red + (((tp * WM + m) * WN + n) * 64 + lane) * 4);
+                            float4 v = make_float4(acc[tp][m][n][0], acc[tp][m][n][1], acc[tp][m][n][2], acc[tp][m][n][3]);
+                            if (w > 0) { const float4 o = *r4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                            if (w == WAVES_K - 1) acc[tp][m][n] = f32x4{v.x, v.y, v.z, v.w}; else *r4 = v;
+                        }
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+                    float4* r4 = reinterpret_cast<float4*>(red + ((TAPS * WM * WN + m) * 64 + lane) * 4);
+                    float4 v = make_float4(accb[m][0], accb[m][1], accb[m][2], accb[m][3]);
+                    if (w > 0) { const float4 o = *r4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    if (w == WAVES_K - 1) accb[m] = f32x4{v.x, v.y, v.z, v.w}; else *r4 = v;
                 }
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        if (wave_k != WAVES_K - 1) return;
     }
 
     // commit: C/D fragment row = 4*kk + reg -> cout, col = li -> cin
@@ -274,15 +450,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + (wave_co * WM + m) * 16 + 4 * kk + r;
-                    if (co < p.Cout)
-                        atomicAdd(p.dw + ((size_t)(tp * p.Cout + co) * p.Cin + ci), acc[tp][m][n][r] * p.scale);
+                    if (co < p.Cout) {
+                        float* dst = p.dw + ((size_t)(tp * p.Cout + co) * p.Cin + ci);
+                        const float v = acc[tp][m][n][r] * p.scale;
+                        if (p.atomic) atomicAdd(dst, v); else *dst += v;
+                    }
                 }
         }
         if (do_bias && li == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + (wave_co * WM + m) * 16 + 4 * kk + r;
-                if (co < p.Cout) atomicAdd(p.db + co, accb[m][r]);
+                if (co < p.Cout) { if (p.atomic) atomicAdd(p.db + co, accb[m][r]); else p.db[co] += accb[m][r]; }
             }
         }
     }
@@ -325,62 +504,114 @@ inline TileGeom make_geom(int N, int Hout, int Wout, int BPX)
     return g;
 }
 
-template <int VEC, int WAVES_CO, int WM, int WN>
+template <typename K>
+inline int set_smem(K kern, size_t smem)
+{
+    if (smem > 160 * 1024) return PG_E_UNSUP;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <int KS, int VEC, int WAVES_CO, int WM, int WN>
 int launch_conv(ConvP& p, hipStream_t s)
 {
     constexpr int WAVES_PX = 4 / WAVES_CO;
-    constexpr int BCO = 16 * WM * WAVES_CO, BPX = 16 * WN * WAVES_PX, KCP = 4 * VEC + 4;
+    constexpr int BCO = 16 * WM * WAVES_CO, BPX = 16 * WN * WAVES_PX, KCP = RowStride<VEC>::value;
     TileGeom g = make_geom(p.N, p.Hout, p.Wout, BPX);
     p.lgTW = g.lgTW; p.lgTH = g.lgTH; p.TN = g.TN; p.tilesW = g.tilesW; p.tilesH = g.tilesH;
-    const int HT = (1 << g.lgTH) + p.KS - 1, WT = (1 << g.lgTW) + p.KS - 1;
-    const size_t smem = (size_t)(p.KS * p.KS * BCO + g.TN * HT * WT) * KCP * sizeof(float);
-    if (smem > 160 * 1024) return PG_E_UNSUP;
-    auto kern = conv_igemm_kernel<VEC, WAVES_CO, WM, WN>;
-    if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const int HT = (1 << g.lgTH) + KS - 1, WT = (1 << g.lgTW) + KS - 1;
+    constexpr int XMAX = KS == 1 ? BPX : (KS == 3 ? (BPX * 9) / 4 : 16 * BPX);
+    if (g.TN * HT * WT > XMAX) return PG_E_UNSUP;       // halo larger than the register-prefetch budget
+    const size_t smem = (size_t)(KS * KS * BCO + g.TN * HT * WT) * KCP * sizeof(float);
+    auto kern = conv_igemm_kernel<KS, VEC, WAVES_CO, WM, WN>;
+    if (int rc = set_smem(kern, smem)) return rc;
+    const int ncob = (p.Cout + BCO - 1) / BCO;
+    const int nblocks = g.ntiles * ncob;
+    const int nchunks = p.Cin / (4 * VEC);
+    int ksplit = 1;
+    if (nblocks < 192 && nchunks >= 4) {                  // too few workgroups for 256 CUs: slice K
+        ksplit = (512 + nblocks - 1) / nblocks;
+        if (ksplit > nchunks) ksplit = nchunks;
+        const int cper = (nchunks + ksplit - 1) / ksplit;
+        ksplit = (nchunks + cper - 1) / cper;
+    }
+    p.ksplit = ksplit;
+    const size_t npix = (size_t)p.N * p.Hout * p.Wout;
+    if (ksplit > 1) {
+        hipError_t e = hipMemsetAsync(p.y, 0, npix * p.Cout * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(g.ntiles, (p.Cout + BCO - 1) / BCO);
+    dim3 grid(g.ntiles, ncob, ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+    if (ksplit > 1) {
+        const size_t total = npix * (p.Cout >> 2);
+        int eg = (int)((total + 255) / 256); if (eg > 2048) eg = 2048;
+        const bool identity = !p.mask && !p.bias && p.slope == 1.0f;
+        if (!identity)
+            hipLaunchKernelGGL(conv_epilogue_kernel, dim3(eg), dim3(256), 0, s, p.y, p.bias, p.mask, npix, p.Cout,
+                               p.slope, p.mask_slope);
+    }
     return (int)hipGetLastError();
 }
 
-template <int VEC>
+template <int KS, int VEC>
 int dispatch_conv(ConvP& p, hipStream_t s)
 {
-    const long long M = (long long)p.N * p.Hout * p.Wout;
-    if (p.KS == 4 || M <= 64) {                       // few output pixels: weight-streaming shapes
-        if (M <= 16) return launch_conv<VEC, 4, 1, 1>(p, s);
-        return launch_conv<VEC, 4, 1, 4>(p, s);
+    if constexpr (KS == 4) {
+        return launch_conv<KS, VEC, 4, 1, 1>(p, s);               // 16-tap halo: keep the pixel tile small
+    } else {
+        const long long M = (long long)p.N * p.Hout * p.Wout;
+        const long long img = (long long)p.Hout * p.Wout;
+        if (p.Cout <= 16) return launch_conv<KS, VEC, 1, 1, 4>(p, s);
+        if (p.Cout <= 32) return launch_conv<KS, VEC, 1, 2, 2>(p, s);
+        // Cout >= 48: 64-cout blocks; pick the pixel tile (16 / 64 / 128) that wastes the fewest MFMA rows
+        // (tiles never straddle an image unless the image is smaller than the tile)
+        auto padded = [&](long long bpx) {
+            if (img >= bpx) return (long long)p.N * ((img + bpx - 1) / bpx) * bpx;
+            const long long tn = bpx / img;
+            return ((p.N + tn - 1) / tn) * bpx;
+        };
+        const long long p16 = padded(16), p64 = padded(64), p128 = padded(128);
+        if (M <= 16 || (p16 < p64 && p16 < p128)) return launch_conv<KS, VEC, 4, 1, 1>(p, s);
+        if (p64 < p128) return launch_conv<KS, VEC, 4, 1, 4>(p, s);
+        return launch_conv<KS, VEC, 2, 2, 4>(p, s);
     }
-    if (p.Cout <= 16) return launch_conv<VEC, 1, 1, 4>(p, s);
-    if (p.Cout <= 32) return launch_conv<VEC, 1, 2, 2>(p, s);
-    return launch_conv<VEC, 2, 2, 4>(p, s);
 }
 
-template <int KS, int WM, int WN, int WAVES_CO, int WAVES_CI>
+template <int KS>
+int dispatch_conv_vec(ConvP& p, hipStream_t s)
+{
+    if ((p.Cin & 15) == 0) return dispatch_conv<KS, 4>(p, s);
+    if ((p.Cin & 7) == 0) return dispatch_conv<KS, 2>(p, s);
+    return dispatch_conv<KS, 1>(p, s);
+}
+
+template <int KS, int WM, int WN, int WAVES_CO, int WAVES_CI, int BPX>
 int launch_wgrad(WgP& p, hipStream_t s)
 {
+    constexpr int WAVES_K = 4 / (WAVES_CO * WAVES_CI);
     constexpr int BCO = 16 * WM * WAVES_CO, BCI = 16 * WN * WAVES_CI;
-    constexpr int SZ = BCO + 16, SX = BCI + 16;
-    const long long M = (long long)p.N * p.Hout * p.Wout;
-    const int BPX = (KS == 4 || M <= 32) ? 16 : 64;
+    constexpr int SZ = PixStride<BCO>::value, SX = PixStride<BCI>::value;
     TileGeom g = make_geom(p.N, p.Hout, p.Wout, BPX);
     p.lgTW = g.lgTW; p.lgTH = g.lgTH; p.TN = g.TN; p.tilesW = g.tilesW; p.tilesH = g.tilesH; p.ntiles = g.ntiles;
     const int HT = (1 << g.lgTH) + KS - 1, WT = (1 << g.lgTW) + KS - 1;
-    const size_t smem = ((size_t)BPX * SZ + (size_t)g.TN * HT * WT * SX) * sizeof(float);
-    if (smem > 160 * 1024) return PG_E_UNSUP;
+    constexpr int XMAX = KS == 1 ? BPX : (KS == 3 ? (BPX * 9) / 4 : 16 * BPX);
+    if (g.TN * HT * WT > XMAX) return PG_E_UNSUP;
+    size_t smem = ((size_t)BPX * SZ + (size_t)g.TN * HT * WT * SX) * sizeof(float);
+    const size_t red = WAVES_K > 1 ? (size_t)WAVES_CO * WAVES_CI * (KS * KS * WM * WN + WM) * 256 * sizeof(float) : 0;
+    if (red > smem) smem = red;
     const int gy = (p.Cout + BCO - 1) / BCO, gz_ = (p.Cin + BCI - 1) / BCI;
-    int chunks = (2048 + gy * gz_ - 1) / (gy * gz_);       // aim for ~2048 workgroups
-    if (chunks > g.ntiles) chunks = g.ntiles;
+    int chunks = (512 + gy * gz_ - 1) / (gy * gz_);        // ~512 workgroups: fills 256 CUs twice over while
+    if (chunks > g.ntiles) chunks = g.ntiles;              // keeping the commit traffic (chunks x |dW|) small
     if (chunks < 1) chunks = 1;
     p.tiles_per_block = (g.ntiles + chunks - 1) / chunks;
     chunks = (g.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
-    auto kern = conv_wgrad_kernel<KS, WM, WN, WAVES_CO, WAVES_CI>;
-    if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    p.atomic = chunks > 1 ? 1 : 0;
+    auto kern = conv_wgrad_kernel<KS, WM, WN, WAVES_CO, WAVES_CI, BPX>;
+    if (int rc = set_smem(kern, smem)) return rc;
     hipLaunchKernelGGL(kern, dim3(chunks, gy, gz_), dim3(256), smem, s, p);
     return (int)hipGetLastError();
 }
@@ -388,10 +619,14 @@ int launch_wgrad(WgP& p, hipStream_t s)
 template <int KS>
 int dispatch_wgrad(WgP& p, hipStream_t s)
 {
-    if (KS == 4) return launch_wgrad<KS, 1, 1, 2, 2>(p, s);
-    if (p.Cout <= 16 && p.Cin <= 16) return launch_wgrad<KS, 1, 1, 1, 1>(p, s);
-    if (p.Cout < 64 || p.Cin < 64) return launch_wgrad<KS, (KS == 4 ? 1 : 2), (KS == 4 ? 1 : 2), 1, 1>(p, s);
-    return launch_wgrad<KS, (KS == 4 ? 1 : 2), (KS == 4 ? 1 : 2), 2, 2>(p, s);
+    if constexpr (KS == 4) {
+        return launch_wgrad<KS, 1, 1, 2, 2, 16>(p, s);                                        // 32x32 block, 16-px tiles
+    } else {
+        const long long M = (long long)p.N * p.Hout * p.Wout;
+        if (M <= 32) return launch_wgrad<KS, 1, 1, 2, 2, 16>(p, s);
+        if (p.Cout <= 16 && p.Cin <= 16) return launch_wgrad<KS, 1, 1, 1, 1, 128>(p, s);     // 16x16 block
+        return launch_wgrad<KS, 2, 1, 1, 1, 64>(p, s);     // 32(cout) x 16(cin) block, 4 waves split the pixels
+    }
 }
 
 }  // namespace
@@ -402,18 +637,23 @@ extern "C" int pg_conv2d_nhwc(const float* x, const float* w, const float* bias,
 {
     if (!x || !w || !y || N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
     if ((Cin & 3) || (Cout & 3)) return PG_E_ALIGN;
-    if (KS != 1 && KS != 3 && KS != 4) return PG_E_UNSUP;
     ConvP p;
     p.x = x; p.w = w; p.bias = bias; p.mask = mask; p.y = y;
     p.N = N; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout; p.KS = KS; p.pad = pad; p.ups = ups;
     p.Hout = Hin + 2 * pad - KS + 1; p.Wout = Win + 2 * pad - KS + 1;
     if (p.Hout <= 0 || p.Wout <= 0 || !is_pow2(p.Hout) || !is_pow2(p.Wout)) return PG_E_UNSUP;
     if (ups && ((Hin | Win) & 1)) return PG_E_ARG;
+    // 32-bit element offsets inside the kernels
+    if ((long long)N * Hin * Win * Cin >= (1ll << 31) || (long long)N * p.Hout * p.Wout * Cout >= (1ll << 31) ||
+        (long long)KS * KS * Cout * Cin >= (1ll << 31)) return PG_E_UNSUP;
     p.scale = scale; p.slope = slope; p.mask_slope = mask_slope;
     hipStream_t s = (hipStream_t)stream;
-    if ((Cin & 15) == 0) return dispatch_conv<4>(p, s);
-    if ((Cin & 7) == 0) return dispatch_conv<2>(p, s);
-    return dispatch_conv<1>(p, s);
+    switch (KS) {
+        case 1: return dispatch_conv_vec<1>(p, s);
+        case 3: return dispatch_conv_vec<3>(p, s);
+        case 4: return dispatch_conv_vec<4>(p, s);
+        default: return PG_E_UNSUP;
+    }
 }
 
 extern "C" int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, float* db,
