@@ -567,8 +567,11 @@ int dispatch_conv(ConvP& p, hipStream_t s)
         const long long img = (long long)p.Hout * p.Wout;
         if (p.Cout <= 16) return launch_conv<KS, VEC, 1, 1, 4>(p, s);
         if (p.Cout <= 32) return launch_conv<KS, VEC, 1, 2, 2>(p, s);
-        // Cout >= 48: 64-cout blocks; pick the pixel tile (16 / 64 / 128) that wastes the fewest MFMA rows
-        // (tiles never straddle an image unless the image is smaller than the tile)
+        // Cout >= 48.  (1) pixel tile (16 / 64 / 128) that wastes the fewest MFMA columns (tiles never
+        // straddle an image unless the image is smaller than the tile); (2) the widest cout block
+        // (64 / 32 / 16) that still yields >= 160 workgroups, so that weight-heavy low-resolution
+        // layers spread over the 256 CUs without paying split-K atomics; (3) split-K inside launch_conv
+        // only if even 16-cout blocks are too few.
         auto padded = [&](long long bpx) {
             if (img >= bpx) return (long long)p.N * ((img + bpx - 1) / bpx) * bpx;
             const long long tn = bpx / img;
@@ -576,8 +579,14 @@ int dispatch_conv(ConvP& p, hipStream_t s)
         };
         const long long p16 = padded(16), p64 = padded(64), p128 = padded(128);
         if (M <= 16 || (p16 < p64 && p16 < p128)) return launch_conv<KS, VEC, 4, 1, 1>(p, s);
-        if (p64 < p128) return launch_conv<KS, VEC, 4, 1, 4>(p, s);
-        return launch_conv<KS, VEC, 2, 2, 4>(p, s);
+        const bool use64 = p64 < p128;
+        const long long tiles = (use64 ? p64 / 64 : p128 / 128);
+        const long long want = 160;
+        if (tiles * ((p.Cout + 63) / 64) >= want)
+            return use64 ? launch_conv<KS, VEC, 4, 1, 4>(p, s) : launch_conv<KS, VEC, 2, 2, 4>(p, s);
+        if (tiles * ((p.Cout + 31) / 32) >= want)
+            return use64 ? launch_conv<KS, VEC, 2, 1, 2>(p, s) : launch_conv<KS, VEC, 1, 2, 2>(p, s);
+        return use64 ? launch_conv<KS, VEC, 1, 1, 1>(p, s) : launch_conv<KS, VEC, 1, 1, 2>(p, s);
     }
 }
 

@@ -38,9 +38,16 @@ class DataParallel(object):
         return 1.0 / self.world_size
 
     def broadcast_params(self, *nets):
-        """Make every rank start from rank 0's weights (one broadcast per flat buffer)."""
+        """Make every rank start from rank 0's weights: one broadcast of the flat parameter buffer plus
+        one of the per-layer equalized-lr constants ``c`` (network.py:19 — data-dependent, not a
+        parameter, so it must travel separately)."""
         for net in nets:
             dist.broadcast(net._flat_param, src=0)
+            layers = net._layers()
+            cs = torch.tensor([m.c for m in layers], dtype=torch.float64, device=net._flat_param.device)
+            dist.broadcast(cs, src=0)
+            for m, c in zip(layers, cs.tolist()):
+                m.c = float(c)
             net.mark_params_changed()
 
     def all_reduce_flat(self, flat):

@@ -1,0 +1,144 @@
+"""Data-parallel path on CPU: world_size 2, gloo.  Each rank runs the product's Trainer on its own
+shard (kernels emulated by tests/emu_ops.py — host logic only), gradients are SUM-all-reduced on the
+flat buffers and averaged inside FusedAdam.  Checked against the oracle: two independent shard
+gradients (local minibatch-stddev) averaged, then the oracle's Adam."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import emu_ops
+    import pggan_amd as pg
+    from helpers import synthetic
+    torch.set_num_threads(2)
+    for modname in ('engine', 'optim'):
+        importlib.import_module('pggan-pytorch_amd.' + modname).ops = emu_ops
+    pg.engine._check_dev = lambda t, what: t.contiguous()
+    pg.trainer._to_device = lambda t: t
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dp = pg.DataParallel()
+    assert dp.world_size == world and dp.rank == rank
+    torch.manual_seed(100 + rank)                      # deliberately different init per rank ...
+    shape = (1, 3, 16, 16)
+    kw = dict(fmap_base=64, fmap_max=16)
+    G = pg.Generator(shape, latent_size=16, **kw)
+    D = pg.Discriminator(shape, **kw)
+    dp.broadcast_params(G, D)                          # ... made identical by the broadcast from rank 0
+    G.depth = D.depth = 2
+    G.alpha = D.alpha = 0.5
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99), grad_scale=dp.grad_scale)
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99), grad_scale=dp.grad_scale)
+    n = 3
+    batches = [synthetic(pg.parallel.shard_seed(900 + 10 * it, rank), n, 3, 16, 16) for it in range(2)]
+    state = dict(it=0)
+
+    def loader():
+        while True:
+            yield batches[state['it']][0]
+
+    zs = []
+
+    def rlg():
+        b = batches[state['it']]
+        z = b[1] if len(zs) % 2 == 0 else b[2]
+        zs.append(0)
+        return z
+
+    def d_loss(Dm, Gm, real, z):
+        pg.wgan_gp_loss.set_mixing_factors(batches[state['it']][3])
+        return pg.wgan_gp_D_loss(Dm, Gm, real, z)
+
+    class DS(object):
+        model_depth, alpha = 2, 0.5
+    from helpers import reference_grads
+    first = {}
+    orig_all_reduce = dp.all_reduce_grads
+
+    def recording_all_reduce(net):
+        r = orig_all_reduce(net)
+        key = 'D' if net is D else 'G'
+        if key not in first:                               # summed (not yet averaged) gradients, iteration 0
+            first[key] = {k: v.clone() for k, v in reference_grads(net).items()}
+        return r
+    dp.all_reduce_grads = recording_all_reduce
+    tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, DS(), loader(), rlg, parallel=dp)
+    for it in range(2):
+        state['it'] = it
+        tr.train()
+    assert tr.cur_nimg == 2 * n * world               # global images: the schedule stays a function of cur_nimg
+    flat = torch.cat([G._flat_param, D._flat_param]).clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    for g in gathered:
+        assert torch.equal(g, gathered[0]), 'ranks diverged'
+    if rank == 0:
+        torch.save(dict(G=G.reference_state_dict(), D=D.reference_state_dict(), first=first), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _err(a, b):
+    """max|a-b| / max(max|b|, 1e-3): linear.bias' gradient is a cancelling sum (~5e-5) of O(1/N) terms."""
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-3))
+
+
+def test_two_rank_data_parallel_matches_oracle(tmp_path, oracle):
+    world = 2
+    out_path = str(tmp_path / 'dp.pt')
+    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    got = torch.load(out_path, weights_only=False)
+    # oracle: same start (rank 0's init), per-shard gradients averaged
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import pggan_amd as pg
+    from helpers import synthetic
+    from conftest import rel_err
+    torch.manual_seed(100)
+    shape = (1, 3, 16, 16)
+    kw = dict(fmap_base=64, fmap_max=16)
+    G = pg.Generator(shape, latent_size=16, **kw)
+    D = pg.Discriminator(shape, **kw)
+    gp, dp_ = G.reference_state_dict(), D.reference_state_dict()
+    cfg = oracle.NetCfg(16, 3, latent_size=16, **kw)
+    og, od = oracle.AdamState(), oracle.AdamState()
+    for it in range(2):
+        shards = [synthetic(pg.parallel.shard_seed(900 + 10 * it, r), 3, 3, 16, 16) for r in range(world)]
+        ds = [oracle.d_loss_and_grads(dp_, gp, cfg, real, z_d, mix, 2, 0.5) for (real, z_d, z_g, mix) in shards]
+        avg = {k: sum(d['grads'][k] for d in ds) / world for k in ds[0]['grads']}
+        if it == 0:      # the all-reduced buffer holds the SUM over ranks of the per-shard gradients
+            assert sorted(avg) == sorted(got['first']['D'])
+            for k in avg:
+                assert _err(got['first']['D'][k], avg[k] * world) < 1e-3, ('D grad', k)
+        od.step(dp_, avg, 0.001)
+        gs = [oracle.g_loss_and_grads(gp, dp_, cfg, z_g, 2, 0.5) for (real, z_d, z_g, mix) in shards]
+        avg = {k: sum(g['grads'][k] for g in gs) / world for k in gs[0]['grads']}
+        if it == 0:
+            assert sorted(avg) == sorted(got['first']['G'])
+            for k in avg:
+                assert _err(got['first']['G'][k], avg[k] * world) < 1e-3, ('G grad', k)
+        og.step(gp, avg, 0.001)
+    for name, ref, mine in (('G', gp, got['G']), ('D', dp_, got['D'])):
+        for k, v in ref.items():
+            if torch.is_tensor(v):
+                # Adam with beta1=0 is sign-like in its first steps: a gradient within round-off of zero moves
+                # a parameter by up to lr either way per step -> absolute bound 2*lr*steps on the end state
+                assert float((mine[k] - v).abs().max()) < 2 * 0.001 * 2 + 1e-4, (name, k)

@@ -1,0 +1,78 @@
+"""Condense the rocprofv3 outputs of tools/profile_round.sh into small committed summaries:
+   <out>/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, verbatim per-kernel table)
+   <out>/<tag>_pmc_summary.csv    (per kernel: calls, total ms, HBM bytes/launch, MFMA busy %, LDS conflicts)
+   <out>/<tag>_roofline.json      (what bench.py reads for roofline.traffic)
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB,
+collected in SEPARATE passes, and on gfx950 FETCH_SIZE under-reports wide coalesced reads by exactly 2x."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def short(k):
+    k = k.replace('(anonymous namespace)::', '').replace('void ', '')
+    return k.split('(')[0]
+
+
+def load_pmc(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(dict)
+    if not os.path.exists(path):
+        return agg, disp
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = short(row['Kernel_Name'])
+            agg[k][row['Counter_Name']] += float(row['Counter_Value'])
+            disp[k][row['Dispatch_Id']] = int(row['End_Timestamp']) - int(row['Start_Timestamp'])
+    return agg, disp
+
+
+ks = os.path.join(out, 'kt', 'kt_kernel_stats.csv')
+if os.path.exists(ks):
+    shutil.copy(ks, os.path.join(out, tag + '_kernel_stats.csv'))
+fetch, fd = load_pmc(os.path.join(out, 'pmc_fetch', 'p_counter_collection.csv'))
+write, wd = load_pmc(os.path.join(out, 'pmc_write', 'p_counter_collection.csv'))
+sq, sd = load_pmc(os.path.join(out, 'pmc_sq', 'p_counter_collection.csv'))
+lds, ld = load_pmc(os.path.join(out, 'pmc_lds', 'p_counter_collection.csv'))
+kernels = sorted(set(fetch) | set(write) | set(sq), key=lambda k: -sum(sd.get(k, fd.get(k, {})).values()))
+rows = []
+roof = {}
+for k in kernels:
+    calls = len(sd.get(k) or fd.get(k) or wd.get(k) or {})
+    tot_ns = sum((sd.get(k) or fd.get(k) or {}).values())
+    fcalls, wcalls = max(1, len(fd.get(k, {}))), max(1, len(wd.get(k, {})))
+    fetch_b = 2.0 * 1024.0 * fetch.get(k, {}).get('FETCH_SIZE', 0.0) / fcalls        # gfx950 x2 correction
+    write_b = 1024.0 * write.get(k, {}).get('WRITE_SIZE', 0.0) / wcalls
+    mf = sq.get(k, {}).get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
+    t_sq = sum(sd.get(k, {}).values())
+    mfma_pct = 100.0 * mf / (t_sq * 2.4 * 1024) if t_sq else 0.0
+    conf = lds.get(k, {}).get('SQ_LDS_BANK_CONFLICT', 0.0)
+    act = lds.get(k, {}).get('SQ_LDS_IDX_ACTIVE', 0.0)
+    rows.append([k, calls, '%.3f' % (tot_ns / 1e6), '%.1f' % (tot_ns / 1e3 / max(1, calls)), '%.0f' % fetch_b, '%.0f' % write_b,
+                 '%.1f' % mfma_pct, '%.3f' % (conf / act if act else 0.0),
+                 '%.3g' % sq.get(k, {}).get('SQ_INSTS_MFMA', 0), '%.3g' % sq.get(k, {}).get('SQ_INSTS_VALU', 0),
+                 '%.3f' % (sq.get(k, {}).get('SQ_WAIT_INST_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1))),
+                 '%.3f' % (sq.get(k, {}).get('SQ_WAIT_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1)))])
+    roof[k] = {'hbm_bytes_per_launch': fetch_b + write_b, 'fetch_bytes_per_launch': fetch_b,
+               'write_bytes_per_launch': write_b, 'mfma_busy_pct': mfma_pct, 'avg_launch_us': tot_ns / 1e3 / max(1, calls)}
+with open(os.path.join(out, tag + '_pmc_summary.csv'), 'w') as f:
+    w = csv.writer(f)
+    w.writerow(['kernel', 'calls', 'total_ms', 'avg_us', 'hbm_fetch_bytes_per_launch(x2 corrected)', 'hbm_write_bytes_per_launch',
+                'mfma_busy_pct', 'lds_conflict_frac', 'insts_mfma', 'insts_valu', 'wait_inst_frac', 'wait_any_frac'])
+    w.writerows(rows)
+fam = collections.defaultdict(lambda: dict(bytes=0.0, calls=0, ns=0.0))
+for k, v in roof.items():
+    base = k.split('<')[0]
+    n = len(sd.get(k) or fd.get(k) or {})
+    fam[base]['bytes'] += v['hbm_bytes_per_launch'] * n
+    fam[base]['calls'] += n
+json.dump({'tag': tag, 'per_kernel': roof,
+           'per_family': {b: {'hbm_bytes_per_launch': d['bytes'] / max(1, d['calls']), 'launches': d['calls']} for b, d in fam.items()}},
+          open(os.path.join(out, tag + '_roofline.json'), 'w'), indent=1)
+for r in rows[:14]:
+    print(r)
