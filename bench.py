@@ -58,7 +58,8 @@ class KernelTimer(object):
             out = orig(*a, **k)
             e1.record()
             layer, n, hout = hout_of(a, k)
-            self.rec.append((family, layer_flops(layer, n, hout), e0, e1,
+            sym = self.pg._lib.load().pg_debug_last_conv_kernel().decode()
+            self.rec.append((sym or family, layer_flops(layer, n, hout), e0, e1,
                              '%s %d->%d k%d @%d n%d' % (name, layer.ch_in, layer.ch_out, layer.ksize, hout, n)))
             return out
         setattr(eng, name, wrapped)
@@ -251,8 +252,14 @@ def main():
                     tag, t['launches'] / psteps, t['ms'] / psteps, t['flops'] / (t['ms'] * 1e-3) / 1e12))
         dom = max(fam, key=lambda k: fam[k]['ms'])
         d = fam[dom]
+        traffic = None
+        try:                                   # HBM bytes per launch of that symbol from the committed PMC summary
+            with open(os.path.join(ROOT, 'profiles', 'r01_roofline.json')) as f:
+                traffic = json.load(f)['per_kernel'][dom]['hbm_bytes_per_launch']
+        except Exception:
+            pass
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': MFMA_F32_PEAK / 1e12,
-                           'unit': 'TFLOP/s', 'frac': d['tflops'] * 1e12 / MFMA_F32_PEAK, 'traffic': None,
+                           'unit': 'TFLOP/s', 'frac': d['tflops'] * 1e12 / MFMA_F32_PEAK, 'traffic': traffic,
                            'avg_launch_us': d['avg_launch_us'], 'launches_per_step': d['launches_per_step'],
                            'ms_per_step_in_kernel': d['ms_per_step'],
                            'algorithmic_gflop_per_step': d['flops_per_step'] / 1e9}

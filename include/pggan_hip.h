@@ -59,6 +59,12 @@ int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, float* db,
                          int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
                          float scale, pg_stream_t stream);
 
+/* Profiling aid: symbol (as rocprofv3 prints it, e.g. "conv_igemm_kernel<3, 4, 2, 2, 4>") of the conv
+ * kernel instantiation most recently launched by the calling thread through the two entry points
+ * above ("" before the first launch).  Thread-local; lets bench.py attribute its HIP-event timings
+ * to the exact kernel symbol that rocprofv3 --kernel-trace --stats reports.                      */
+const char* pg_debug_last_conv_kernel(void);
+
 /* Repack forward weights [KS][KS][Cout][Cin] into the weights of the backward-data convolution
  * [KS][KS][Cin][Cout] (spatially flipped, channels transposed).                               */
 int pg_pack_dgrad_weights(const float* w, float* wt, int KS, int Cout, int Cin, pg_stream_t stream);

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpggan_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class PgganLibraryError(RuntimeError):
@@ -25,6 +25,7 @@ SIGNATURES = {
     'pg_abi_version': [],
     'pg_conv2d_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
+    'pg_debug_last_conv_kernel': [],
     'pg_pack_dgrad_weights': [P, P, I, I, I, P],
     'pg_fromrgb_fwd': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
     'pg_fromrgb_bwd_data': [P, P, P, I, I, I, I, I, I, I, F, P],
@@ -75,7 +76,7 @@ def load():
         except AttributeError:
             raise PgganLibraryError('symbol %s missing from %s' % (name, LIB_PATH))
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_char_p if name == 'pg_debug_last_conv_kernel' else ctypes.c_int
     v = lib.pg_abi_version()
     if v != ABI_VERSION:
         raise PgganLibraryError('ABI version mismatch: library %d, binding %d' % (v, ABI_VERSION))

@@ -23,7 +23,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+#include <cstdio>
+
 namespace {
+
+thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -39,6 +43,7 @@ struct ConvP {
     int N, Hin, Win, Cin, Cout, Hout, Wout, KS, pad, ups;
     float scale, slope, mask_slope;
     int lgTW, lgTH, TN, tilesW, tilesH;
+    unsigned mWT, mHT;          // floor(2^32/WT)+1, floor(2^32/HT)+1: exact n/d for n < 2^16 via __umulhi
     int ksplit;                 // >1: blockIdx.z owns a slice of the Cin chunks, partial sums are
                                 // committed with fp32 atomics into a pre-zeroed y (epilogue deferred)
 };
@@ -46,6 +51,13 @@ struct ConvP {
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
 //   VEC=4 (ds_read_b128, 4x16 lanes, 64 banks): 24   VEC=2 (ds_read_b64): 12   VEC=1: 8
 template <int VEC> struct RowStride { static constexpr int value = VEC == 4 ? 24 : (VEC == 2 ? 12 : 8); };
+
+// Upper bound of the halo pixels of one tile (sizes the register prefetch): KS=3 with TH,TW >= 4 needs at most
+// 2.25*BPX; tiles of >= 512 pixels are always 32 wide (make_geom), so (BPX/32+2)*34 is exact there.
+constexpr int halo_max(int KS, int BPX)
+{
+    return KS == 1 ? BPX : (KS == 4 ? 16 * BPX : (BPX >= 512 ? (BPX / 32 + 2) * 34 : (BPX * 9) / 4));
+}
 
 // One workgroup (4 waves) computes BCO couts x BPX output pixels; the pixel tile is
 // TN images x TH x TW (powers of two) so that the (KS-1)-halo of the input is staged once in LDS
@@ -59,8 +71,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     constexpr int TAPS = KS * KS;
     constexpr int WEL = TAPS * BCO * VEC;                       // float4 elements of one weight chunk
     constexpr int WPT = (WEL + 255) / 256;
-    // halo pixels of a tile: <= BPX*(1+2/TH)(1+2/TW) <= 2.25*BPX for KS=3 (TH,TW>=4); KS=4 uses BPX=16
-    constexpr int XMAX = KS == 1 ? BPX : (KS == 3 ? (BPX * 9) / 4 : 16 * BPX);
+    constexpr int XMAX = halo_max(KS, BPX);
     constexpr int XPT = (XMAX * VEC + 255) / 256;
     extern __shared__ __align__(16) float lds[];
 
@@ -106,7 +117,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     for (int i = 0; i < XPT; ++i) {
         const int idx = tid + 256 * i;
         const int q = idx / VEC, v = idx - q * VEC;
-        const int tw = q % WT, r2 = q / WT, th = r2 % HT, tn = r2 / HT;
+        const int r2 = (int)__umulhi((unsigned)q, p.mWT), tw = q - r2 * WT;       // q / WT, q % WT (q < 2^16)
+        const int tn = (int)__umulhi((unsigned)r2, p.mHT), th = r2 - tn * HT;
         const int n = n0 + tn;
         int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
         const bool in_tile = q < npix;
@@ -245,6 +257,7 @@ struct WgP {
     int N, Hin, Win, Cin, Cout, Hout, Wout, pad, ups;
     float scale;
     int lgTW, lgTH, TN, tilesW, tilesH, ntiles, tiles_per_block;
+    unsigned mWT, mHT;          // magic reciprocals of the halo tile width / height (see ConvP)
     int atomic;                 // 0: this workgroup is the only writer of its dW block -> plain +=
 };
 
@@ -307,7 +320,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p)
     for (int i = 0; i < XPT; ++i) {
         const int idx = tid + 256 * i;
         const int q = idx / XV, v = idx - q * XV;
-        const int tw = q % WT, r2 = q / WT, th = r2 % HT, tn = r2 / HT;
+        const int r2 = (int)__umulhi((unsigned)q, p.mWT), tw = q - r2 * WT;
+        const int tn = (int)__umulhi((unsigned)r2, p.mHT), th = r2 - tn * HT;
         xq[i] = q < npix ? ((tn << 20) | (th << 10) | tw) : -1;
         xc[i] = ci0 + 4 * v;
         xdst[i] = q * SX + 4 * v;
@@ -523,8 +537,9 @@ int launch_conv(ConvP& p, hipStream_t s)
     TileGeom g = make_geom(p.N, p.Hout, p.Wout, BPX);
     p.lgTW = g.lgTW; p.lgTH = g.lgTH; p.TN = g.TN; p.tilesW = g.tilesW; p.tilesH = g.tilesH;
     const int HT = (1 << g.lgTH) + KS - 1, WT = (1 << g.lgTW) + KS - 1;
-    constexpr int XMAX = KS == 1 ? BPX : (KS == 3 ? (BPX * 9) / 4 : 16 * BPX);
+    constexpr int XMAX = halo_max(KS, BPX);
     if (g.TN * HT * WT > XMAX) return PG_E_UNSUP;       // halo larger than the register-prefetch budget
+    p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     const size_t smem = (size_t)(KS * KS * BCO + g.TN * HT * WT) * KCP * sizeof(float);
     auto kern = conv_igemm_kernel<KS, VEC, WAVES_CO, WM, WN>;
     if (int rc = set_smem(kern, smem)) return rc;
@@ -545,6 +560,7 @@ int launch_conv(ConvP& p, hipStream_t s)
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid(g.ntiles, ncob, ksplit);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_igemm_kernel<%d, %d, %d, %d, %d>", KS, VEC, WAVES_CO, WM, WN);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
     if (ksplit > 1) {
         const size_t total = npix * (p.Cout >> 2);
@@ -609,6 +625,7 @@ int launch_wgrad(WgP& p, hipStream_t s)
     const int HT = (1 << g.lgTH) + KS - 1, WT = (1 << g.lgTW) + KS - 1;
     constexpr int XMAX = KS == 1 ? BPX : (KS == 3 ? (BPX * 9) / 4 : 16 * BPX);
     if (g.TN * HT * WT > XMAX) return PG_E_UNSUP;
+    p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     size_t smem = ((size_t)BPX * SZ + (size_t)g.TN * HT * WT * SX) * sizeof(float);
     const size_t red = WAVES_K > 1 ? (size_t)WAVES_CO * WAVES_CI * (KS * KS * WM * WN + WM) * 256 * sizeof(float) : 0;
     if (red > smem) smem = red;
@@ -621,6 +638,7 @@ int launch_wgrad(WgP& p, hipStream_t s)
     p.atomic = chunks > 1 ? 1 : 0;
     auto kern = conv_wgrad_kernel<KS, WM, WN, WAVES_CO, WAVES_CI, BPX>;
     if (int rc = set_smem(kern, smem)) return rc;
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_wgrad_kernel<%d, %d, %d, %d, %d, %d>", KS, WM, WN, WAVES_CO, WAVES_CI, BPX);
     hipLaunchKernelGGL(kern, dim3(chunks, gy, gz_), dim3(256), smem, s, p);
     return (int)hipGetLastError();
 }
@@ -686,6 +704,8 @@ extern "C" int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, 
         default: return PG_E_UNSUP;
     }
 }
+
+extern "C" const char* pg_debug_last_conv_kernel(void) { return g_last_kernel; }
 
 extern "C" int pg_pack_dgrad_weights(const float* w, float* wt, int KS, int Cout, int Cin, pg_stream_t stream)
 {

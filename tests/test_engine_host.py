@@ -198,7 +198,7 @@ def test_library_exports_every_declared_symbol():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, 'include', 'pggan_hip.h')).read()
-    declared = set(re.findall(r'\bint\s+(pg_\w+)\s*\(', hdr))
+    declared = set(re.findall(r'\b(?:int|const char\*)\s+(pg_\w+)\s*\(', hdr))
     assert declared == set(pg._lib.SIGNATURES), declared ^ set(pg._lib.SIGNATURES)
     if not os.path.exists(pg.LIB_PATH):
         import __graft_entry__
