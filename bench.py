@@ -208,7 +208,8 @@ def main():
 
     import pggan_amd as pg
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dp = pg.parallel.DataParallel.from_env() if world > 1 else None
+    force_dp = os.environ.get('PGGAN_FORCE_DP', '') == '1'      # one-rank RCCL group: smoke test of the DP code path
+    dp = pg.parallel.DataParallel.from_env(force=force_dp) if (world > 1 or force_dp) else None
     rank = 0 if dp is None else dp.rank
     if dp is None:
         torch.cuda.set_device(0)

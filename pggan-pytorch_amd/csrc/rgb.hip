@@ -144,6 +144,61 @@ __global__ __launch_bounds__(256) void fromrgb_wgrad_kernel(
     }
 }
 
+// Small-Cout variant (CO <= 32, the >=128^2 stages): one thread per pixel keeps all CO x (C+1) partial sums in
+// registers, reads its pixel's gz row with float4 loads (coalesced across the wave) and the image planes
+// row-contiguously; wave shuffle + LDS reduction, one atomic per output and workgroup.
+template <int CO>
+__global__ __launch_bounds__(256) void fromrgb_wgrad_small_kernel(
+    const float* __restrict__ gz, const float* __restrict__ img, float* __restrict__ dw, float* __restrict__ db,
+    int N, int C, int H, int W, int pool, float scale)
+{
+    constexpr int NV = CO * (MAXC + 1);
+    __shared__ float red[4][NV];
+    float acc[CO][MAXC + 1];
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int c = 0; c <= MAXC; ++c) acc[o][c] = 0.f;
+    const size_t total = (size_t)N * H * W;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+        const int wv = (int)(pix % W);
+        const size_t r = pix / W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        float xin[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) xin[c] = c < C ? img_fetch(img, n, c, h, wv, C, H, W, pool) : 0.f;
+        const float4* g4 = reinterpret_cast<const float4*>(gz + pix * CO);
+#pragma unroll
+        for (int o4 = 0; o4 < CO / 4; ++o4) {
+            const float4 g = g4[o4];
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) acc[4 * o4 + j][c] = fmaf(gv[j], xin[c], acc[4 * o4 + j][c]);
+                acc[4 * o4 + j][MAXC] += gv[j];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int c = 0; c <= MAXC; ++c) {
+            float v = acc[o][c];
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
+            if (lane == 0) red[wave][o * (MAXC + 1) + c] = v;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256) {
+        const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        const int o = i / (MAXC + 1), c = i % (MAXC + 1);
+        if (c < C) atomicAdd(dw + (size_t)o * C + c, v * scale);
+        else if (c == MAXC && db) atomicAdd(db + o, v);
+    }
+}
+
 // thread -> pixel: out[n,c,h,w] for all c; reads the pixel's Cin features with float4 loads.
 __global__ __launch_bounds__(256) void torgb_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -317,6 +372,14 @@ extern "C" int pg_fromrgb_wgrad(const float* gz, const float* img, float* dw, fl
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cout & 3) return PG_E_ALIGN;
     const size_t total = (size_t)N * H * W;
+    if (total >= 65536 && (Cout == 8 || Cout == 16 || Cout == 32)) {
+        const int g = grid_for(total, 256, 1024);
+        hipStream_t s = (hipStream_t)stream;
+        if (Cout == 8) hipLaunchKernelGGL(fromrgb_wgrad_small_kernel<8>, dim3(g), dim3(256), 0, s, gz, img, dw, db, N, C, H, W, pool, scale);
+        else if (Cout == 16) hipLaunchKernelGGL(fromrgb_wgrad_small_kernel<16>, dim3(g), dim3(256), 0, s, gz, img, dw, db, N, C, H, W, pool, scale);
+        else hipLaunchKernelGGL(fromrgb_wgrad_small_kernel<32>, dim3(g), dim3(256), 0, s, gz, img, dw, db, N, C, H, W, pool, scale);
+        return (int)hipGetLastError();
+    }
     int blocks = grid_for(total, 64, 1024);
     const int ppb = (int)((total + blocks - 1) / blocks);
     blocks = (int)((total + ppb - 1) / ppb);

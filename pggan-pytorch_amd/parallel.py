@@ -24,10 +24,18 @@ class DataParallel(object):
         self.device = device
 
     @staticmethod
-    def from_env():
-        """torchrun / torch.distributed.run environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*)."""
+    def from_env(force=False):
+        """torchrun / torch.distributed.run environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*).
+        ``force``: build a (degenerate) one-rank group even when WORLD_SIZE is 1 — used to smoke-test the
+        RCCL code path on a single GPU."""
         if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
-            return None
+            if not force:
+                return None
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('LOCAL_RANK', '0')
+            os.environ['WORLD_SIZE'] = '1'
         local = int(os.environ.get('LOCAL_RANK', '0'))
         if torch.cuda.is_available():
             torch.cuda.set_device(local)

@@ -100,7 +100,8 @@ def test_dgrad_is_adjoint_of_conv():
         assert abs(a - b) < 1e-4 * max(1.0, abs(a))
 
 
-RGB_CASES = [(2, 3, 16, 16), (3, 1, 8, 32), (2, 3, 4, 512), (1, 3, 64, 8), (2, 4, 8, 12)]
+RGB_CASES = [(2, 3, 16, 16), (3, 1, 8, 32), (2, 3, 4, 512), (1, 3, 64, 8), (2, 4, 8, 12), (1, 3, 256, 8), (2, 3, 256, 16),
+             (1, 1, 256, 32)]
 
 
 @pytest.mark.parametrize('N,C,H,co', RGB_CASES)
