@@ -60,7 +60,8 @@ class KernelTimer(object):
             layer, n, hout = hout_of(a, k)
             sym = self.pg._lib.load().pg_debug_last_conv_kernel().decode()
             self.rec.append((sym or family, layer_flops(layer, n, hout), e0, e1,
-                             '%s %d->%d k%d @%d n%d' % (name, layer.ch_in, layer.ch_out, layer.ksize, hout, n)))
+                             '%s %d->%d k%d @%d n%d %s' % (name, layer.ch_in, layer.ch_out, layer.ksize, hout, n,
+                                                       sym.replace('conv_', '').replace('_kernel', ''))))
             return out
         setattr(eng, name, wrapped)
 
@@ -249,7 +250,7 @@ def main():
             fam = kt.summary(psteps)
         if args.kernel_table:
             for tag, t in sorted(kt.table.items(), key=lambda kv: -kv[1]['ms']):
-                sys.stderr.write('%-44s calls/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f\n' % (
+                sys.stderr.write('%-72s calls/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f\n' % (
                     tag, t['launches'] / psteps, t['ms'] / psteps, t['flops'] / (t['ms'] * 1e-3) / 1e12))
         dom = max(fam, key=lambda k: fam[k]['ms'])
         d = fam[dom]

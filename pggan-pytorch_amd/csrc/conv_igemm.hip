@@ -573,36 +573,60 @@ int launch_conv(ConvP& p, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+// Tile-shape selection.  One 4-wave workgroup already saturates a CU's matrix pipes (f32 MFMA issues one
+// instruction per 32 cycles per SIMD), so the launch time is  ceil(workgroups / 256 CUs) x time per workgroup;
+// the candidates below are scored with that model (MFMA cycles incl. padding waste + a fixed per-workgroup and
+// per-chunk overhead) and the cheapest one is launched.  Shapes with < 192 workgroups are K-split in launch_conv.
+struct TileCand { int bpx, bco; };
+
 template <int KS, int VEC>
 int dispatch_conv(ConvP& p, hipStream_t s)
 {
     if constexpr (KS == 4) {
         return launch_conv<KS, VEC, 4, 1, 1>(p, s);               // 16-tap halo: keep the pixel tile small
     } else {
-        const long long M = (long long)p.N * p.Hout * p.Wout;
         const long long img = (long long)p.Hout * p.Wout;
-        if (p.Cout <= 16) return launch_conv<KS, VEC, 1, 1, 4>(p, s);
-        if (p.Cout <= 32) return launch_conv<KS, VEC, 1, 2, 2>(p, s);
-        // Cout >= 48.  (1) pixel tile (16 / 64 / 128) that wastes the fewest MFMA columns (tiles never
-        // straddle an image unless the image is smaller than the tile); (2) the widest cout block
-        // (64 / 32 / 16) that still yields >= 160 workgroups, so that weight-heavy low-resolution
-        // layers spread over the 256 CUs without paying split-K atomics; (3) split-K inside launch_conv
-        // only if even 16-cout blocks are too few.
-        auto padded = [&](long long bpx) {
-            if (img >= bpx) return (long long)p.N * ((img + bpx - 1) / bpx) * bpx;
+        auto ntiles = [&](long long bpx) -> long long {
+            if (img >= bpx) return (long long)p.N * ((img + bpx - 1) / bpx);
             const long long tn = bpx / img;
-            return ((p.N + tn - 1) / tn) * bpx;
+            return (p.N + tn - 1) / tn;
         };
-        const long long p16 = padded(16), p64 = padded(64), p128 = padded(128);
-        if (M <= 16 || (p16 < p64 && p16 < p128)) return launch_conv<KS, VEC, 4, 1, 1>(p, s);
-        const bool use64 = p64 < p128;
-        const long long tiles = (use64 ? p64 / 64 : p128 / 128);
-        const long long want = 160;
-        if (tiles * ((p.Cout + 63) / 64) >= want)
-            return use64 ? launch_conv<KS, VEC, 4, 1, 4>(p, s) : launch_conv<KS, VEC, 2, 2, 4>(p, s);
-        if (tiles * ((p.Cout + 31) / 32) >= want)
-            return use64 ? launch_conv<KS, VEC, 2, 1, 2>(p, s) : launch_conv<KS, VEC, 1, 2, 2>(p, s);
-        return use64 ? launch_conv<KS, VEC, 1, 1, 1>(p, s) : launch_conv<KS, VEC, 1, 1, 2>(p, s);
+        static const TileCand cands[] = {{256, 16}, {128, 64}, {128, 32}, {128, 16}, {64, 64}, {64, 32}, {64, 16}, {16, 64}};
+        const int nchunks = p.Cin / (4 * VEC);
+        double best = 1e30; int bi = 1;
+        for (int i = 0; i < 8; ++i) {
+            const TileCand c = cands[i];
+            if (c.bpx == 256 && p.Cout > 16) continue;            // 256-pixel tiles only exist for <= 16 couts
+            if (c.bco > 16 && p.Cout <= 16) continue;
+            if (c.bco > 32 && p.Cout <= 32) continue;
+            const long long blocks = ntiles(c.bpx) * ((p.Cout + c.bco - 1) / c.bco);
+            const double mfma = (double)(c.bpx / 16) * (c.bco / 16) / 4.0 * nchunks * VEC * KS * KS * 32.0;
+            double cost;
+            if (blocks >= 192) {
+                cost = (double)((blocks + 255) / 256) * (mfma + 2500.0 + 700.0 * nchunks);
+            } else {                                              // launch_conv will slice K (same rule as there)
+                long long ks = (512 + blocks - 1) / blocks;
+                if (ks > nchunks) ks = nchunks;
+                if (ks < 1) ks = 1;
+                const long long cper = (nchunks + ks - 1) / ks;
+                ks = (nchunks + cper - 1) / cper;
+                const double per_slice = mfma / (double)nchunks * (double)cper + 2500.0 + 700.0 * (double)cper +
+                                         (ks > 1 ? 5.0 * c.bpx * c.bco + 2000.0 : 0.0);   // fp32-atomic commit (~10 cycles each per CU,
+                                                                                          // two workgroups share it) + deferred epilogue
+                cost = (double)((blocks * ks + 255) / 256) * per_slice;
+            }
+            if (cost < best) { best = cost; bi = i; }
+        }
+        switch (bi) {
+            case 0: return launch_conv<KS, VEC, 1, 1, 4>(p, s);
+            case 1: return launch_conv<KS, VEC, 2, 2, 4>(p, s);
+            case 2: return launch_conv<KS, VEC, 1, 2, 2>(p, s);
+            case 3: return launch_conv<KS, VEC, 1, 1, 2>(p, s);
+            case 4: return launch_conv<KS, VEC, 4, 1, 4>(p, s);
+            case 5: return launch_conv<KS, VEC, 2, 1, 2>(p, s);
+            case 6: return launch_conv<KS, VEC, 1, 1, 1>(p, s);
+            default: return launch_conv<KS, VEC, 4, 1, 1>(p, s);
+        }
     }
 }
 
