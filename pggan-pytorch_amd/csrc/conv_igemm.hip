@@ -178,12 +178,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 #pragma unroll
                 for (int n = 0; n < WN; ++n) lds_load<VEC>(xt + pixbase[n] + tapoff[tp + 1], b[nxt][n]);
             }
+            // pin the order "issue next tap's LDS reads, THEN this tap's MFMAs": hipcc otherwise sinks the reads
+            // next to their first use and every tap starts with an exposed LDS round trip
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < VEC; ++s)
 #pragma unroll
                 for (int m = 0; m < WM; ++m)
 #pragma unroll
                     for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(a[cur][m][s], b[cur][n][s], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -414,9 +418,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p)
         load_frags(wave_k, a[0], b[0]);
         for (int s = 0; s < T; s += 2) {                 // ping-pong: next step's LDS reads under this step's MFMAs
             load_frags(wave_k + (s + 1) * WAVES_K, a[1], b[1]);
+            __builtin_amdgcn_sched_barrier(0);           // keep the reads ahead of the MFMAs (see conv_igemm_kernel)
             mfmas(a[0], b[0]);
+            __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < T) load_frags(wave_k + (s + 2) * WAVES_K, a[0], b[0]);
+            __builtin_amdgcn_sched_barrier(0);
             mfmas(a[1], b[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -510,6 +518,7 @@ inline TileGeom make_geom(int N, int Hout, int Wout, int BPX)
 {
     TileGeom g;
     int TW = Wout < 32 ? Wout : 32; if (TW > BPX) TW = BPX;
+    while (TW > 4 && BPX / TW < 4 && Hout >= 4) TW >>= 1;      // keep tiles at least 4 rows tall (halo <= 2.25x)
     int TH = BPX / TW; if (TH > Hout) TH = Hout;
     g.lgTW = ilog2(TW); g.lgTH = ilog2(TH);
     g.TN = BPX / (TW * TH);
