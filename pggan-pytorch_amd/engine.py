@@ -455,3 +455,4 @@ def g_loss_backward(state, scale=1.0):
     if scale != 1.0:
         ops.axpby_mask(G._flat_grad, a=scale, out=G._flat_grad)
     _assign_grads(G, active)
+    state['active_g'] = active

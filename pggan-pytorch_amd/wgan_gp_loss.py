@@ -12,6 +12,16 @@ from . import engine
 # wgan_gp_loss.py:4-5 keeps module-global scratch; the only state kept here is the injectable RNG.
 mixing_factors = None
 _generator = None
+_use_graphs = False
+
+
+def enable_graphs(flag=True):
+    """Replay the D-step / G-step schedules from captured hipGraphs whenever alpha == 1 (see graphs.py)."""
+    global _use_graphs
+    _use_graphs = bool(flag)
+    if not flag:
+        from . import graphs
+        graphs.clear()
 
 
 def set_mixing_factors(m):
@@ -54,6 +64,11 @@ class LossTensor(torch.Tensor):
             return func(*args, **(kwargs or {}))
 
 
+def _graphed_backward(scale):
+    if scale != 1.0:
+        raise NotImplementedError('backward(gradient != 1) is not available on the hipGraph path')
+
+
 def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
                    iwass_lambda=10.0,
                    iwass_epsilon=0.001,
@@ -69,6 +84,16 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
         mixing_factors = None
     else:                                                                # :15-17 (device RNG)
         mix = torch.rand((n, 1), device=real_images_in.device, dtype=torch.float32, generator=_generator)
+    if _use_graphs and float(D.alpha) >= 1.0 and real_images_in.is_cuda:
+        from . import graphs
+        real_c = engine._check_dev(real_images_in, 'real images')
+        z_c = engine._check_dev(fake_latents_in, 'latents')
+        d_cost, d_real_loss, d_fake_loss = graphs.d_step(D, G, real_c, z_c, mix.contiguous(), iwass_lambda,
+                                                         iwass_epsilon, iwass_target)
+        d_cost = LossTensor.wrap(d_cost, _graphed_backward)      # gradients are already in param.grad
+        if return_all:
+            return d_cost, d_real_loss, d_fake_loss
+        return d_cost
     d_cost, d_real_loss, d_fake_loss, state = engine.d_loss_forward(
         D, G, real_images_in, fake_latents_in, mix, iwass_lambda, iwass_epsilon, iwass_target)
     d_cost = LossTensor.wrap(d_cost, lambda scale: engine.d_loss_backward(state, scale))
@@ -80,5 +105,9 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
 def wgan_gp_G_loss(G, D, fake_latents_in):
     """reference wgan_gp_loss.py:68-74."""
     G.zero_grad()                                                        # :69
+    if _use_graphs and float(G.alpha) >= 1.0 and fake_latents_in.is_cuda:
+        from . import graphs
+        g_cost = graphs.g_step(G, D, engine._check_dev(fake_latents_in, 'latents'))
+        return LossTensor.wrap(g_cost, _graphed_backward)
     g_cost, state = engine.g_loss_forward(G, D, fake_latents_in)
     return LossTensor.wrap(g_cost, lambda scale: engine.g_loss_backward(state, scale))

@@ -233,3 +233,81 @@ def test_gp_is_quadratic_in_lambda_and_grad_scale_linear():
     c.backward(torch.tensor(0.5))
     g2 = D.blocks[-1].c1.conv.weight.grad
     assert rel_err(g2.cpu() * 2, g1.cpu()) < 1e-3     # atomics: run-to-run summation order differs
+
+
+def test_hipgraph_replay_matches_eager():
+    """Trainer iterations with the D-/G-step schedules replayed from captured hipGraphs (graphs.py) must
+    reproduce the eager launches: same losses, same weights after 5 iterations (atomics => tolerance)."""
+    def run(use_graphs):
+        pg.wgan_gp_loss.enable_graphs(use_graphs)
+        try:
+            torch.manual_seed(21)
+            shape = (1, 3, 32, 32)
+            kw = dict(fmap_base=256, fmap_max=64)
+            G = pg.Generator(shape, latent_size=64, **kw).to(DEV)
+            D = pg.Discriminator(shape, **kw).to(DEV)
+            G.depth = D.depth = 2
+            opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+            opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+            ds = pg.utils.SyntheticDataset(32, 3, seed=5)
+            ds.model_depth = 2
+            pg.wgan_gp_loss.manual_seed(9)
+            tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, ds.loader(8),
+                            pg.utils.device_latents(8, 64, seed=3))
+            losses = []
+
+            class Rec(pg.Plugin):
+                def __init__(self):
+                    super(Rec, self).__init__([(1, 'iteration')])
+
+                def register(self, trainer):
+                    pass
+
+                def iteration(self, i, g_cost, d_cost, d_real, d_fake):
+                    losses.append((float(g_cost), float(d_cost)))
+            tr.register_plugin(Rec())
+            for q in tr.plugin_queues.values():
+                heapq.heapify(q)
+            for _ in range(5):
+                tr.train()
+            return losses, G._flat_param.clone(), D._flat_param.clone()
+        finally:
+            pg.wgan_gp_loss.enable_graphs(False)
+    l0, g0, d0 = run(False)
+    l1, g1, d1 = run(True)
+    for (a, b), (c, d) in zip(l0, l1):
+        assert abs(a - c) < 2e-4 * max(1.0, abs(a)) and abs(b - d) < 2e-4 * max(1.0, abs(b)), (l0, l1)
+    assert float((g0 - g1).abs().max()) < 2 * 0.001 * 5 + 1e-4
+    assert float((d0 - d1).abs().max()) < 2 * 0.001 * 5 + 1e-4
+    assert rel_err(g1, g0) < 2e-2 and rel_err(d1, d0) < 2e-2
+
+
+def test_whole_module_pickle_roundtrip(tmp_path):
+    """SaverPlugin semantics (plugins.py:155-166): ``torch.save(model)`` / ``torch.load`` of whole modules must
+    preserve weights AND the equalized-lr constants c (not in the reference's state_dict), and the reloaded
+    nets must keep training (flat buffers re-linked)."""
+    torch.manual_seed(4)
+    shape = (1, 3, 16, 16)
+    kw = dict(fmap_base=128, fmap_max=32)
+    G = pg.Generator(shape, latent_size=32, **kw).to(DEV)
+    D = pg.Discriminator(shape, **kw).to(DEV)
+    G.depth = D.depth = 2
+    G.alpha = D.alpha = 0.7
+    z = torch.randn(4, 32, device=DEV)
+    out0 = G(z)
+    s0 = D(out0)
+    torch.save(G, str(tmp_path / 'g.dat'))
+    torch.save(D, str(tmp_path / 'd.dat'))
+    G2 = torch.load(str(tmp_path / 'g.dat'), weights_only=False)
+    D2 = torch.load(str(tmp_path / 'd.dat'), weights_only=False)
+    assert (G2.depth, G2.alpha, G2.block0.c1.c) == (2, 0.7, G.block0.c1.c)
+    assert torch.equal(G2(z), out0) and torch.equal(D2(out0), s0)
+    real = torch.rand(4, 3, 16, 16, device=DEV) * 2 - 1
+    opt = pg.FusedAdam(D2.parameters(), 0.001, betas=(0.0, 0.99))
+    before = D2._flat_param.clone()
+    c, _, _ = pg.wgan_gp_D_loss(D2, G2, real, z)
+    c.backward()
+    opt.step()
+    assert not torch.equal(before, D2._flat_param)
+    assert torch.isfinite(D2._flat_param).all()
+    assert D2.blocks[-1].c2.conv.weight.data_ptr() >= D2._flat_param.data_ptr()      # still views of the flat buffer
