@@ -204,12 +204,12 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-per-depth', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--no-graphs', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
+    ap.add_argument('--graphs', action='store_true', help='replay the step from captured hipGraphs (graphs.py); default is\n                    eager two-stream launching, which measured faster at every growth stage')
     ap.add_argument('--kernel-table', action='store_true', help='per-layer conv timing table on stderr')
     args = ap.parse_args()
 
     import pggan_amd as pg
-    pg.wgan_gp_loss.enable_graphs(not args.no_graphs)       # replayed whenever alpha == 1 (graphs.py)
+    pg.wgan_gp_loss.enable_graphs(args.graphs)              # replayed whenever alpha == 1 (graphs.py)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     force_dp = os.environ.get('PGGAN_FORCE_DP', '') == '1'      # one-rank RCCL group: smoke test of the DP code path
     dp = pg.parallel.DataParallel.from_env(force=force_dp) if (world > 1 or force_dp) else None
@@ -244,7 +244,7 @@ def main():
         out['step_algorithmic_gflop_per_image'] = W / 1e9
         out['step_mfma_frac'] = W * (value / n_gpus) / MFMA_F32_PEAK
 
-    out['config']['hip_graphs'] = bool(not args.no_graphs and args.alpha >= 1.0)
+    out['config']['hip_graphs'] = bool(args.graphs and args.alpha >= 1.0)
     if rank == 0 and not args.no_kernel_timing:
         psteps = 3
         pg.wgan_gp_loss.enable_graphs(False)               # per-launch HIP events need eager launches
@@ -276,7 +276,7 @@ def main():
         pg.wgan_gp_loss.enable_graphs(False)
         for _ in range(3):                                  # keep collectives matched with rank 0
             tr.train()
-    pg.wgan_gp_loss.enable_graphs(not args.no_graphs)
+    pg.wgan_gp_loss.enable_graphs(args.graphs)
 
     if not args.no_per_depth and dp is None:
         per = []

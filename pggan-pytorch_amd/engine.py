@@ -58,9 +58,57 @@ def _dgrad(net, gz, layer, N, Hout, mask=None, mask_slope=0.2):
                       layer.c, 1.0, mask=mask, mask_slope=mask_slope)
 
 
+# Weight gradients are leaves of the backward sweeps (nothing downstream reads them before the optimizer), so
+# they are launched on a second HIP stream and overlap the backward-data chain on the main stream: two
+# half-occupancy MFMA kernels share the CUs instead of running back to back.
+ASYNC_WGRAD = True
+_SIDE = {}
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
+class _on_side(object):
+    """``with _on_side(t1, t2, ...):`` runs the body on the side stream after everything queued so far on
+    the current stream; the tensors are registered with the allocator as in use on that stream."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.active = ASYNC_WGRAD and len(self.tensors) > 0 and self.tensors[0].is_cuda
+
+    def __enter__(self):
+        if not self.active:
+            return self
+        main = torch.cuda.current_stream()
+        self.side = _side_stream()
+        self.side.wait_stream(main)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if not self.active:
+            return False
+        self.ctx.__exit__(*exc)
+        for t in self.tensors:
+            t.record_stream(self.side)
+        return False
+
+
+def _join_side():
+    """Main stream waits for every weight-gradient launch (call before the optimizer / all-reduce)."""
+    if ASYNC_WGRAD and torch.cuda.is_available() and torch.cuda.current_device() in _SIDE:
+        torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
+
+
 def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False):
-    ops.conv2d_wgrad(x, gz, layer._gw, layer._gb if bias else None, N, Hin, Hin, layer.ksize, layer.pad,
-                     layer.c, ups=ups)
+    with _on_side(x, gz):
+        ops.conv2d_wgrad(x, gz, layer._gw, layer._gb if bias else None, N, Hin, Hin, layer.ksize, layer.pad,
+                         layer.c, ups=ups)
 
 
 _ONES = {}
@@ -135,20 +183,23 @@ def generator_backward(G, ctx, g_out):
     g_extra = None
     if depth == 0:
         t = b0.toRGB
-        ops.torgb_wgrad(g_out, ctx['y2'], t._gw, t._gb, N, C, 4, 4, t.c, 1.0)
+        with _on_side(g_out, ctx['y2']):
+            ops.torgb_wgrad(g_out, ctx['y2'], t._gw, t._gb, N, C, 4, 4, t.c, 1.0)
         g = ops.torgb_bwd_data(g_out, t.conv.weight.data, N, C, 4, 4, t.c)
         active.append(t)
     else:
         rec = ctx['recs'][-1]
         H = rec['H']
         t = rec['blk'].toRGB
-        ops.torgb_wgrad(g_out, rec['a2'], t._gw, t._gb, N, C, H, H, alpha * t.c, alpha)
+        with _on_side(g_out, rec['a2']):
+            ops.torgb_wgrad(g_out, rec['a2'], t._gw, t._gb, N, C, H, H, alpha * t.c, alpha)
         g = ops.torgb_bwd_data(g_out, t.conv.weight.data, N, C, H, H, alpha * t.c)
         active.append(t)
         if alpha < 1.0:
             pt = G.blocks[depth - 2].toRGB if depth > 1 else b0.toRGB
-            ops.torgb_wgrad(g_out, rec['inp'], pt._gw, pt._gb, N, C, H // 2, H // 2, (1 - alpha) * pt.c,
-                            1 - alpha, down=True)
+            with _on_side(g_out, rec['inp']):
+                ops.torgb_wgrad(g_out, rec['inp'], pt._gw, pt._gb, N, C, H // 2, H // 2, (1 - alpha) * pt.c,
+                                1 - alpha, down=True)
             g_extra = ops.torgb_bwd_data(g_out, pt.conv.weight.data, N, C, H // 2, H // 2, (1 - alpha) * pt.c, down=True)
             active.append(pt)
     for rec in reversed(ctx['recs']):
@@ -296,7 +347,8 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             if save_adjoints:
                 adj[idx]['gf'] = gf
             if full:
-                ops.fromrgb_wgrad(gf, x, fr._gw, fr._gb, NB, C, H, H, fr.c)
+                with _on_side(gf, x):
+                    ops.fromrgb_wgrad(gf, x, fr._gw, fr._gb, NB, C, H, H, fr.c)
             if want_gimg:
                 gimg = torch.empty_like(x)
                 ops.fromrgb_bwd_data(gf, fr.conv.weight.data, gimg, NB, C, H, H, fr.c)
@@ -314,7 +366,8 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                 if save_adjoints:
                     adj[idx - 1]['gpf'] = gpf
                 if full:
-                    ops.fromrgb_wgrad(gpf, x, pfr._gw, pfr._gb, NB, C, H, H, pfr.c, pool=True)
+                    with _on_side(gpf, x):
+                        ops.fromrgb_wgrad(gpf, x, pfr._gw, pfr._gb, NB, C, H, H, pfr.c, pool=True)
                 pending_prev = (gpf, pfr)
             else:
                 g = ops.avgpool2_bwd(gin, prev['a2'], 1.0, pc2.slope)
@@ -332,7 +385,8 @@ def d_tangent_wgrad(D, sub, adj, u):
     rec0 = recs[0]
     fr = rec0['blk'].fromRGB
     H = rec0['H']
-    ops.fromrgb_wgrad(adj[0]['gf'], u, fr._gw, None, N, C, H, H, fr.c)
+    with _on_side(adj[0]['gf'], u):
+        ops.fromrgb_wgrad(adj[0]['gf'], u, fr._gw, None, N, C, H, H, fr.c)
     cur = ops.fromrgb_fwd(u, fr.conv.weight.data, None, N, C, H, H, fr.c, 1.0, mask=rec0['inp'], mask_slope=fr.slope)
     hvp = None
     t2 = None
@@ -353,7 +407,8 @@ def d_tangent_wgrad(D, sub, adj, u):
             t2 = _conv(t1, c2, N, H, mask=rec['a2'], bias=False)
             if rec['first'] and alpha < 1.0:
                 nfr = recs[idx + 1]['blk'].fromRGB
-                ops.fromrgb_wgrad(adj[idx]['gpf'], u, nfr._gw, None, N, C, H // 2, H // 2, nfr.c, pool=True)
+                with _on_side(adj[idx]['gpf'], u):
+                    ops.fromrgb_wgrad(adj[idx]['gpf'], u, nfr._gw, None, N, C, H // 2, H // 2, nfr.c, pool=True)
                 tpf = ops.fromrgb_fwd(u, nfr.conv.weight.data, None, N, C, H // 2, H // 2, nfr.c, 1.0,
                                       pool=True, mask=rec['pf'], mask_slope=nfr.slope)
                 cur = ops.avgpool2_fwd(t2, tpf, alpha, 1.0 - alpha)
@@ -427,6 +482,7 @@ def d_loss_backward(state, scale=1.0):
     hvp = d_tangent_wgrad(D, state['sub'], state['adj'], state['u'])
     gs = state['gscore'][:2 * N]
     d_backward(D, ctx, gs, full=True, want_gimg=False, hvp=(2 * N,) + hvp)
+    _join_side()
     if scale != 1.0:
         ops.axpby_mask(D._flat_grad, a=scale, out=D._flat_grad)
     _assign_grads(D, d_active_params(D, ctx['depth'], ctx['alpha']), linear=True)
@@ -452,6 +508,7 @@ def g_loss_backward(state, scale=1.0):
     ops.zero_(G._flat_grad)
     gimg, _ = d_backward(D, state['dctx'], state['gscore'], full=False, want_gimg=True)
     active = generator_backward(G, state['gctx'], gimg)
+    _join_side()
     if scale != 1.0:
         ops.axpby_mask(G._flat_grad, a=scale, out=G._flat_grad)
     _assign_grads(G, active)
