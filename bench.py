@@ -167,9 +167,9 @@ def d_step_ms(tr, steps):
 
 def cpu_baseline(depth, mb):
     """The CPU oracle (a restatement of the reference's op sequence, pinned to the reference by the
-    golden fixtures) timed on this host: ONE full train iteration of the same growth stage on a
-    bounded sample (1 image; torch-CPU/oneDNN degrades with >32 threads on these convolutions, so at
-    most 32 threads are used and that is the core count reported)."""
+    golden fixtures) timed on this host: ONE full train iteration of the same workload (bounded sample,
+    ~10 s; torch-CPU/oneDNN degrades with >32 threads on these convolutions, so at most 32 threads are
+    used and that is the core count reported)."""
     from oracle import pggan_cpu as oc
     cores = os.cpu_count() or 1
     try:
@@ -177,7 +177,6 @@ def cpu_baseline(depth, mb):
     except Exception:
         pass
     cores = min(cores, 32)
-    mb = 1
     torch.set_num_threads(cores)
     res = 4 * 2 ** depth
     cfg = oc.NetCfg(1024, 3)
