@@ -31,61 +31,62 @@ REF_MINIBATCH = {6: 14, 7: 6, 8: 3}          # reference plugins.py:19-20 (defau
 F_D = [0.0841, 0.6882, 3.1047, 6.7294, 10.3548, 13.9819, 17.6120, 21.2485, 24.8975]
 
 
-def layer_flops(layer, n, hout, wgrad_or_conv='conv'):
-    """Algorithmic FLOPs of one conv launch: 2*N*Hout*Wout*Cout*Cin*taps with the reference's channel
-    counts (513, not the stored 528) and one live tap per output pixel for the 1x1->4x4 first layer."""
-    taps = layer.ksize * layer.ksize
-    if layer.ksize == 4 and layer.pad == 3:
+def conv_flops(n, hout, wout, ks, pad, c_a, c_b):
+    """Algorithmic FLOPs of one conv launch (forward, backward-data, tangent or weight gradient — all the
+    same count): 2*N*Hout*Wout*Cout*Cin*taps with the reference's channel counts (513, not the stored 528) and
+    one live tap per output pixel for the 1x1 -> 4x4 first layer of G / its transpose."""
+    c_a = 513 if c_a == 528 else c_a
+    c_b = 513 if c_b == 528 else c_b
+    taps = ks * ks
+    if ks == 4 and pad == 3:
         taps = 1
-    return 2.0 * n * hout * hout * layer.ch_out * layer.ch_in * taps
+    return 2.0 * n * hout * wout * c_a * c_b * taps
 
 
 class KernelTimer(object):
-    """HIP-event timing of every conv launch of a step (torch.cuda.Event on the current stream == the
-    stream the kernels are launched on).  Installed only for the instrumented passes."""
+    """HIP-event timing of every MFMA conv launch of a step.  The events are recorded around the C-ABI call on
+    the stream the kernel is launched on (weight gradients run on the second stream, so wrapping happens at
+    ``ops`` level, inside the stream context).  Installed only for the instrumented passes."""
 
     def __init__(self, pg):
         self.pg, self.rec, self.saved = pg, [], {}
 
-    def _wrap(self, name, family, hout_of):
-        eng = self.pg.engine
-        orig = getattr(eng, name)
+    def _wrap(self, name, describe):
+        ops = self.pg.ops
+        orig = getattr(ops, name)
         self.saved[name] = orig
+        lib = self.pg._lib.load()
 
         def wrapped(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = orig(*a, **k)
             e1.record()
-            layer, n, hout = hout_of(a, k)
-            sym = self.pg._lib.load().pg_debug_last_conv_kernel().decode()
-            self.rec.append((sym or family, layer_flops(layer, n, hout), e0, e1,
-                             '%s %d->%d k%d @%d n%d %s' % (name, layer.ch_in, layer.ch_out, layer.ksize, hout, n,
-                                                       sym.replace('conv_', '').replace('_kernel', ''))))
+            sym = lib.pg_debug_last_conv_kernel().decode()
+            fl, tag = describe(a, k)
+            self.rec.append((sym, fl, e0, e1, '%s %s' % (tag, sym.replace('conv_', '').replace('_kernel', ''))))
             return out
-        setattr(eng, name, wrapped)
+        setattr(ops, name, wrapped)
 
     def __enter__(self):
-        def conv_args(a, k):          # _conv(x, layer, N, H, ...): H is the input size (after upsample)
-            layer, n, h = a[1], a[2], a[3]
-            return layer, n, h + 2 * layer.pad - layer.ksize + 1
+        def conv_desc(a, k):          # conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, ...)
+            w, n, hin, win, ks, pad = a[1], a[3], a[4], a[5], a[6], a[7]
+            ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
+            return (conv_flops(n, ho, wo, ks, pad, w.shape[2], w.shape[3]),
+                    'conv %d->%d k%d @%d n%d%s' % (w.shape[3], w.shape[2], ks, ho, n, ' masked' if k.get('mask') is not None else ''))
 
-        def dgrad_args(a, k):         # _dgrad(net, gz, layer, N, Hout, ...): output of dgrad = layer input
-            layer, n, hout = a[2], a[3], a[4]
-            hin = hout - 2 * layer.pad + layer.ksize - 1
-            return layer, n, (hout if not (layer.ksize == 4) else max(hout, hin))
-
-        def wgrad_args(a, k):         # _wgrad(x, gz, layer, N, Hin, ...)
-            layer, n, h = a[2], a[3], a[4]
-            return layer, n, h + 2 * layer.pad - layer.ksize + 1
-        self._wrap('_conv', 'conv_igemm_kernel', conv_args)
-        self._wrap('_dgrad', 'conv_igemm_kernel', dgrad_args)
-        self._wrap('_wgrad', 'conv_wgrad_kernel', wgrad_args)
+        def wgrad_desc(a, k):         # conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=)
+            dw, n, hin, win, ks, pad = a[2], a[4], a[5], a[6], a[7], a[8]
+            ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
+            return (conv_flops(n, ho, wo, ks, pad, dw.shape[2], dw.shape[3]),
+                    'wgrad %d->%d k%d @%d n%d' % (dw.shape[3], dw.shape[2], ks, ho, n))
+        self._wrap('conv2d', conv_desc)
+        self._wrap('conv2d_wgrad', wgrad_desc)
         return self
 
     def __exit__(self, *exc):
         for name, orig in self.saved.items():
-            setattr(self.pg.engine, name, orig)
+            setattr(self.pg.ops, name, orig)
 
     def summary(self, nsteps):
         torch.cuda.synchronize()

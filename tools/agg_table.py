@@ -1,7 +1,7 @@
 import re, collections, sys
 rows=[]
 for l in open(sys.argv[1] if len(sys.argv)>1 else '/root/repo/gpurun_out/bench8.err'):
-    m=re.match(r'(_\w+) (\d+)->(\d+) k(\d) @(\d+) n(\d+)(?: \S.*?)?\s+calls/step\s+([\d.]+)\s+ms/step\s+([\d.]+)\s+TFLOP/s\s+([\d.]+)',l)
+    m=re.match(r'(\w+) (\d+)->(\d+) k(\d) @(\d+) n(\d+)(?: \S.*?)?\s+calls/step\s+([\d.]+)\s+ms/step\s+([\d.]+)\s+TFLOP/s\s+([\d.]+)',l)
     if m: rows.append((m.group(1),int(m.group(2)),int(m.group(3)),int(m.group(4)),int(m.group(5)),int(m.group(6)),float(m.group(7)),float(m.group(8)),float(m.group(9))))
 tot=sum(r[7] for r in rows); print('rows',len(rows),'total conv ms',tot)
 agg=collections.defaultdict(lambda:[0,0.0])
