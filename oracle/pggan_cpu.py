@@ -82,11 +82,11 @@ def init_generator(cfg):
     C = cfg.num_channels
     _init_pgconv(p, 'block0.c1', cfg.latent_size, cfg.nf(1), 4, 3, cfg.wscale)   # :47
     _init_pgconv(p, 'block0.c2', cfg.nf(1), cfg.nf(1), 3, 1, cfg.wscale)         # :48
-    _init_pgconv(p, 'block0.toRGB', cfg.nf(1), C, 1, 0, cfg.wscale)              # :49
+    _init_pgconv(p, 'block0.toRGB', cfg.nf(1), C, 1, 0, True)      # :49 (built without layer_settings: wscale always)
     for j, i in enumerate(range(2, cfg.R)):                                      # :107-110
         _init_pgconv(p, 'blocks.%d.c1' % j, cfg.nf(i - 1), cfg.nf(i), 3, 1, cfg.wscale)
         _init_pgconv(p, 'blocks.%d.c2' % j, cfg.nf(i), cfg.nf(i), 3, 1, cfg.wscale)
-        _init_pgconv(p, 'blocks.%d.toRGB' % j, cfg.nf(i), C, 1, 0, cfg.wscale)
+        _init_pgconv(p, 'blocks.%d.toRGB' % j, cfg.nf(i), C, 1, 0, True)
     return p
 
 
@@ -96,11 +96,11 @@ def init_discriminator(cfg):
     C = cfg.num_channels
     j = 0
     for i in range(cfg.R - 1, 1, -1):                                            # :214-216
-        _init_pgconv(p, 'blocks.%d.fromRGB' % j, C, cfg.nf(i), 1, 0, cfg.wscale)  # :145
+        _init_pgconv(p, 'blocks.%d.fromRGB' % j, C, cfg.nf(i), 1, 0, True)        # :145 (wscale always)
         _init_pgconv(p, 'blocks.%d.c1' % j, cfg.nf(i), cfg.nf(i), 3, 1, cfg.wscale)
         _init_pgconv(p, 'blocks.%d.c2' % j, cfg.nf(i), cfg.nf(i - 1), 3, 1, cfg.wscale)
         j += 1
-    _init_pgconv(p, 'blocks.%d.fromRGB' % j, C, cfg.nf(1), 1, 0, cfg.wscale)      # :160
+    _init_pgconv(p, 'blocks.%d.fromRGB' % j, C, cfg.nf(1), 1, 0, True)            # :160
     _init_pgconv(p, 'blocks.%d.c1' % j, cfg.nf(1) + 1, cfg.nf(1), 3, 1, cfg.wscale)  # :162
     _init_pgconv(p, 'blocks.%d.c2' % j, cfg.nf(1), cfg.nf(0), 4, 0, cfg.wscale)   # :163
     lin = torch.nn.Linear(cfg.nf(0), 1)                                           # :219 (plain init)
@@ -170,7 +170,7 @@ def _dblock(h, p, cfg, j, first, x=None):
     last = (j == cfg.max_depth)
     name = 'blocks.%d' % j
     if first:
-        h = pgconv(x, p, name + '.fromRGB', 0, sl, False)                         # :145,160 (lrelu, no pn)
+        h = pgconv(x, p, name + '.fromRGB', 0, 0.2, False)   # :145,160 — built WITHOUT layer_settings: always LeakyReLU(0.2), no pn
     if last:
         h = minibatch_stddev(h)                                                   # :168
         h = pgconv(h, p, name + '.c1', 1, sl, pn)
@@ -189,7 +189,7 @@ def discriminator_forward(p, cfg, x, depth, alpha):
         h = F.avg_pool2d(h, 2)                                                    # :229
         if alpha < 1.0:
             xlow = F.avg_pool2d(x, 2)                                             # :231
-            pre = pgconv(xlow, p, 'blocks.%d.fromRGB' % (nb - depth), 0, cfg.slope, False)  # :232
+            pre = pgconv(xlow, p, 'blocks.%d.fromRGB' % (nb - depth), 0, 0.2, False)   # :232 (LeakyReLU(0.2) always)
             h = h * alpha + (1 - alpha) * pre                                     # :233
     for i in range(depth, 0, -1):                                                 # :235-238
         h = _dblock(h, p, cfg, nb - i, False)

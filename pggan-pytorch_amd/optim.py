@@ -56,6 +56,26 @@ class FusedAdam(torch.optim.Optimizer):
         return entry
 
     @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Resume: the loaded moments are copied into the flat m / v buffers (views are re-created) so that
+        contiguous runs keep updating with one launch.  (The reference never saved optimizer state,
+        plugins.py:142-174; this is the 'next row' checkpoint extension of SURVEY.md §8f.)"""
+        super(FusedAdam, self).load_state_dict(state_dict)
+        self._flat = {}
+        for gi, group in enumerate(self.param_groups):
+            base, mflat, vflat = self._flat_state(gi, group)
+            for p in group['params']:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                off = (p.data_ptr() - base) // 4
+                for key, flat in (('exp_avg', mflat), ('exp_avg_sq', vflat)):
+                    v = flat[off:off + p.numel()].view(p.shape)
+                    v.copy_(st[key].to(v.device))
+                    st[key] = v
+                st['step'] = int(st['step'])
+
+    @torch.no_grad()
     def step(self, closure=None):
         for gi, group in enumerate(self.param_groups):
             lr, (b1, b2), eps = float(group['lr']), group['betas'], group['eps']

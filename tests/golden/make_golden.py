@@ -212,6 +212,37 @@ def make_tiny16_c1():
                        init_seed=7), f, indent=1)
 
 
+# ---- fixture 4b: non-default flags (ReLU, no wscale, no pixelnorm / latent normalisation), res 16 ----------
+def make_flags16():
+    shape = (1, 3, 16, 16)
+    fx = {}
+    cases = []
+    variants = [('relu', dict(leakyrelu=False), dict(leakyrelu=False)),
+                ('nowscale', dict(wscale=False), dict(wscale=False)),
+                ('nopn', dict(pixelnorm=False, normalize_latents=False), dict())]
+    for vi, (vname, gkw, dkw) in enumerate(variants):
+        torch.manual_seed(40 + vi)
+        G = quiet(network.Generator, shape, fmap_base=128, fmap_max=32, latent_size=32, **gkw)
+        D = quiet(network.Discriminator, shape, fmap_base=128, fmap_max=32, **dkw)
+        fx.update(export_params(G, vname + '/G'))
+        fx.update(export_params(D, vname + '/D'))
+        depth, alpha, n = 2, 0.45, 4
+        seed = pick_seed(G, D, depth, alpha, n, 3, 16, 32, 800 + vi)
+        real, z_d, z_g, mix = synthetic(seed, n, 3, 16, 32)
+        out, dg, gg = run_steps(G, D, depth, alpha, real, z_d, z_g, mix)
+        cases.append(dict(tag=vname, depth=depth, alpha=alpha, n=n, seed=seed, g=gkw, d=dkw))
+        for k, v in out.items():
+            fx['%s/%s' % (vname, k)] = v
+        for k, v in dg.items():
+            fx['%s/Dgrad/%s' % (vname, k)] = v
+        for k, v in gg.items():
+            fx['%s/Ggrad/%s' % (vname, k)] = v
+    np.savez_compressed(os.path.join(HERE, 'flags16.npz'), **fx)
+    with open(os.path.join(HERE, 'flags16.json'), 'w') as f:
+        json.dump(dict(cfg=dict(resolution=16, num_channels=3, latent_size=32, fmap_base=128, fmap_max=32, fmap_decay=1.0),
+                       cases=cases), f, indent=1)
+
+
 # ---- fixture 5: tiny-width 1024x1024 net (all nine growth stages exist) ------------------
 def make_thin1024():
     kw = dict(fmap_base=2048, fmap_max=16, fmap_decay=1.0)   # nf = 16 x8, 8, 4
@@ -469,7 +500,7 @@ def make_trace():
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['tiny32', 'tiny16c1', 'thin1024', 'full32', 'schedule', 'trace']
+    which = sys.argv[1:] or ['tiny32', 'tiny16c1', 'flags16', 'thin1024', 'full32', 'schedule', 'trace']
     for w in which:
         print('making', w, flush=True)
         globals()['make_' + {'tiny16c1': 'tiny16_c1'}.get(w, w)]()

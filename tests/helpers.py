@@ -55,3 +55,15 @@ def synthetic(seed, n, C, res, latent):
     z_g = rs.randn(n, latent).astype(np.float32)
     mix = rs.rand(n, 1).astype(np.float32)
     return tuple(torch.from_numpy(a) for a in (real, z_d, z_g, mix))
+
+
+def build_flag_nets(meta, case, device='cpu'):
+    c = meta['cfg']
+    shape = (1, c['num_channels'], c['resolution'], c['resolution'])
+    kw = dict(fmap_base=c['fmap_base'], fmap_max=c['fmap_max'], fmap_decay=c['fmap_decay'])
+    G = pg.Generator(shape, latent_size=c['latent_size'], **dict(kw, **case['g']))
+    D = pg.Discriminator(shape, **dict(kw, **case['d']))
+    if device != 'cpu':
+        G.to(device)
+        D.to(device)
+    return G, D

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import fixture_params, load_fixture, rel_err
-from helpers import build_nets, load_fixture_params, reference_grads, synthetic
+from helpers import build_flag_nets, build_nets, load_fixture_params, reference_grads, synthetic
 
 import pggan_amd as pg
 
@@ -311,3 +311,60 @@ def test_whole_module_pickle_roundtrip(tmp_path):
     assert not torch.equal(before, D2._flat_param)
     assert torch.isfinite(D2._flat_param).all()
     assert D2.blocks[-1].c2.conv.weight.data_ptr() >= D2._flat_param.data_ptr()      # still views of the flat buffer
+
+
+def test_non_default_flags_fixture_gpu():
+    """ReLU / no wscale / no PixelNorm variants against the reference's own run."""
+    meta, data = load_fixture('flags16')
+    for case in meta['cases']:
+        tag = case['tag']
+        G, D = build_flag_nets(meta, case, DEV)
+        load_fixture_params(G, data, tag + '/G')
+        load_fixture_params(D, data, tag + '/D')
+        _check_case(G, D, data, tag, case, meta['cfg'])
+
+
+def test_batch_size_edge_cases(oracle):
+    """Minibatch 1 and odd sizes (the reference schedule uses 3, 6, 14): D/G outputs and D_cost vs the oracle."""
+    torch.manual_seed(5)
+    shape = (1, 1, 16, 16)
+    kw = dict(fmap_base=128, fmap_max=32)
+    G = pg.Generator(shape, latent_size=32, **kw)
+    D = pg.Discriminator(shape, **kw)
+    gp, dp = G.reference_state_dict(), D.reference_state_dict()
+    G.to(DEV); D.to(DEV)
+    cfg = oracle.NetCfg(16, 1, latent_size=32, **kw)
+    G.depth = D.depth = 2
+    for n in (1, 3, 7, 14):
+        real, z_d, z_g, mix = oracle.synthetic_batch(60 + n, n, 1, 16, 32)
+        pg.wgan_gp_loss.set_mixing_factors(mix)
+        d_cost, rl, fl = pg.wgan_gp_D_loss(D, G, real.to(DEV), z_d.to(DEV))
+        d_cost.backward()
+        ref = oracle.d_loss_and_grads(dp, gp, cfg, real, z_d, mix, 2, 1.0)
+        assert rel_err(d_cost, ref['D_cost']) < OUT_TOL and rel_err(rl, ref['D_real_loss']) < OUT_TOL
+        _check_grads_loose(reference_grads(D), ref['grads'], 'D grads n=%d' % n)
+    with pytest.raises((RuntimeError, ValueError)):
+        D(torch.zeros(2, 1, 8, 8, device=DEV))            # wrong resolution for depth 2
+    with pytest.raises(RuntimeError):
+        D(torch.zeros(2, 1, 16, 16))                      # CPU tensor: no fallback
+
+
+def test_fused_adam_state_roundtrip():
+    torch.manual_seed(1)
+    D = pg.Discriminator((1, 3, 8, 8), fmap_base=64, fmap_max=16).to(DEV)
+    G = pg.Generator((1, 3, 8, 8), fmap_base=64, fmap_max=16, latent_size=16).to(DEV)
+    D.depth = G.depth = 1
+    opt = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    real, z = torch.rand(4, 3, 8, 8, device=DEV), torch.randn(4, 16, device=DEV)
+    for _ in range(2):
+        c, _, _ = pg.wgan_gp_D_loss(D, G, real, z); c.backward(); opt.step()
+    sd = opt.state_dict()
+    opt2 = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    opt2.load_state_dict(sd)
+    pg.wgan_gp_loss.set_mixing_factors(torch.full((4, 1), 0.3))
+    c, _, _ = pg.wgan_gp_D_loss(D, G, real, z); c.backward()
+    snap = D._flat_param.clone()
+    opt.step(); after1 = D._flat_param.clone()
+    D._flat_param.copy_(snap); D.mark_params_changed()
+    opt2.step()
+    assert torch.allclose(after1, D._flat_param, rtol=0, atol=1e-7)

@@ -15,7 +15,7 @@ import torch
 
 import emu_ops
 from conftest import load_fixture, rel_err
-from helpers import build_nets, load_fixture_params, reference_grads, synthetic
+from helpers import build_flag_nets, build_nets, load_fixture_params, reference_grads, synthetic
 
 import pggan_amd as pg
 
@@ -69,6 +69,46 @@ def test_schedules_match_reference(emu, name):
         assert sorted(mine.keys()) == ref
         for k in ref:
             assert rel_err(mine[k], data['%s/Ggrad/%s' % (tag, k)]) < GRAD_TOL, (tag, k)
+
+
+def test_non_default_flags_fixture(emu):
+    """ReLU / no wscale / no PixelNorm+latent-normalisation variants against the reference's own run."""
+    meta, data = load_fixture('flags16')
+    for case in meta['cases']:
+        tag = case['tag']
+        G, D = build_flag_nets(meta, case)
+        load_fixture_params(G, data, tag + '/G')
+        load_fixture_params(D, data, tag + '/D')
+        G.depth = D.depth = case['depth']
+        G.alpha = D.alpha = case['alpha']
+        real, z_d, z_g, mix = synthetic(case['seed'], case['n'], 3, 16, 32)
+        assert rel_err(G(z_d), data[tag + '/G_out']) < OUT_TOL
+        assert rel_err(D(real), data[tag + '/D_real']) < OUT_TOL
+        pg.wgan_gp_loss.set_mixing_factors(mix)
+        d_cost, _, _ = pg.wgan_gp_D_loss(D, G, real, z_d)
+        assert rel_err(d_cost, data[tag + '/D_cost']) < OUT_TOL
+        d_cost.backward()
+        mine = reference_grads(D)
+        for k in data.files:
+            if k.startswith(tag + '/Dgrad/'):
+                assert rel_err(mine[k.split('/', 2)[2]], data[k]) < GRAD_TOL, k
+        g_cost = pg.wgan_gp_G_loss(G, D, z_g)
+        assert rel_err(g_cost, data[tag + '/G_cost']) < OUT_TOL
+        g_cost.backward()
+        mine = reference_grads(G)
+        for k in data.files:
+            if k.startswith(tag + '/Ggrad/'):
+                assert rel_err(mine[k.split('/', 2)[2]], data[k]) < GRAD_TOL, k
+    # wscale=False construction keeps equalized lr on the to/fromRGB layers, like the reference
+    torch.manual_seed(41)
+    G, D = build_flag_nets(meta, meta['cases'][1])
+    for pre, net in (('nowscale/G', G), ('nowscale/D', D)):
+        for k, v in net.reference_state_dict().items():
+            ref = data['%s/%s' % (pre, k)]
+            if torch.is_tensor(v):
+                assert torch.equal(v, torch.from_numpy(ref)), k
+            else:
+                assert np.float32(v) == np.float32(ref), k
 
 
 def test_init_matches_reference_bit_exact():

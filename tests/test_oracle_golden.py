@@ -147,3 +147,46 @@ def test_trainer_trace(oracle):
         for k, v in ref.items():
             if torch.is_tensor(v):
                 assert rel_err(p[k], v) < 2e-3, k
+
+
+def _flag_cfg(oracle, meta, case):
+    c = meta['cfg']
+    g, d = case['g'], case['d']
+    return oracle.NetCfg(c['resolution'], c['num_channels'], fmap_base=c['fmap_base'], fmap_decay=c['fmap_decay'],
+                         fmap_max=c['fmap_max'], latent_size=c['latent_size'],
+                         normalize_latents=g.get('normalize_latents', True), wscale=g.get('wscale', True),
+                         g_pixelnorm=g.get('pixelnorm', True), leakyrelu=g.get('leakyrelu', True))
+
+
+def test_non_default_flags_fixture(oracle):
+    """ReLU / no wscale / no PixelNorm variants (reachable from the reference CLI, network.py:76-85,191-198)."""
+    meta, data = load_fixture('flags16')
+    for case in meta['cases']:
+        tag = case['tag']
+        cfg = _flag_cfg(oracle, meta, case)
+        gp, dp = fixture_params(data, tag + '/G'), fixture_params(data, tag + '/D')
+        real, z_d, z_g, mix = oracle.synthetic_batch(case['seed'], case['n'], 3, 16, 32)
+        d = oracle.d_loss_and_grads(dp, gp, cfg, real, z_d, mix, case['depth'], case['alpha'])
+        assert rel_err(d['D_cost'], data[tag + '/D_cost']) < TOL
+        for k in data.files:
+            if k.startswith(tag + '/Dgrad/'):
+                assert rel_err(d['grads'][k.split('/', 2)[2]], data[k]) < 5e-4, k
+        g = oracle.g_loss_and_grads(gp, dp, cfg, z_g, case['depth'], case['alpha'])
+        assert rel_err(g['G_cost'], data[tag + '/G_cost']) < TOL
+        assert rel_err(g['fake'], oracle.generator_forward(gp, cfg, z_g, case['depth'], case['alpha'])) == 0.0
+        for k in data.files:
+            if k.startswith(tag + '/Ggrad/'):
+                assert rel_err(g['grads'][k.split('/', 2)[2]], data[k]) < 5e-4, k
+    # init with wscale=False keeps wscale on the to/fromRGB layers (they are built without layer_settings)
+    torch.manual_seed(41)
+    c = meta['cfg']
+    cfg = oracle.NetCfg(16, 3, fmap_base=c['fmap_base'], fmap_max=c['fmap_max'], latent_size=32, wscale=False)
+    gp = oracle.init_generator(cfg)
+    dp = oracle.init_discriminator(cfg)
+    ref_g, ref_d = fixture_params(data, 'nowscale/G'), fixture_params(data, 'nowscale/D')
+    for mine, ref in ((gp, ref_g), (dp, ref_d)):
+        for k, v in ref.items():
+            if torch.is_tensor(v):
+                assert torch.equal(v, mine[k]), k
+            else:
+                assert np.float32(v) == np.float32(mine[k]), k
