@@ -194,6 +194,21 @@ int pg_g_loss(const float* s, float* g_cost, float* gscore, int N, pg_stream_t s
 int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
             float eps, float bc1, float bc2_sqrt, float grad_scale, pg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Steps either side of the path.
+ * Real-image input: replaces DepthDataset.__getitem__ dataset.py:54-67 (alpha_fade :109-113 when alpha < 1,
+ * adjust_dynamic_range utils.py:24-30, astype float32) for a whole uint8 batch on the device:
+ *   t = 2x2 box mean (upsampled back);  v = x + (t - x)*(1-alpha);  out = (v - min_in)*(max_out-min_out)/(max_in-min_in) + min_out
+ * evaluated in fp64 like numpy does for uint8 input, rounded once to fp32 (bit-exact).  in/out: [planes][H][W].  */
+int pg_real_prepare_u8(const uint8_t* in, float* out, int64_t planes, int H, int W, double alpha,
+                       double min_in, double max_in, double min_out, double max_out, pg_stream_t stream);
+
+/* Sample output: replaces ImageSaver.__call__ output_postprocess.py:35-62 up to the PIL hand-off: nearest
+ * upsample by `up` (utils.py:33-53), tiled grid of ceil(sqrt(n)) columns, CHW->HWC, range (min_in,max_in)->(0,255)
+ * in fp32, round-half-even, clip, uint8.  grid: [grid_h*h*up][grid_w*w*up][C].                                  */
+int pg_image_grid_u8(const float* img, uint8_t* grid, int n, int C, int h, int w, int up,
+                     float min_in, float max_in, pg_stream_t stream);
+
 /* Utility: async fill with zero bytes.                                                         */
 int pg_zero(void* p, int64_t bytes, pg_stream_t stream);
 

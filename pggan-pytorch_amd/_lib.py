@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpggan_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 4
 
 
 class PgganLibraryError(RuntimeError):
@@ -19,6 +19,7 @@ P = ctypes.c_void_p
 I = ctypes.c_int
 L = ctypes.c_int64
 F = ctypes.c_float
+D = ctypes.c_double
 
 # name -> argtypes (stream is always the last void*).  Mirrors include/pggan_hip.h 1:1.
 SIGNATURES = {
@@ -51,6 +52,8 @@ SIGNATURES = {
     'pg_d_loss': [P, P, P, P, P, P, I, F, P],
     'pg_g_loss': [P, P, P, I, P],
     'pg_adam': [P, P, P, P, L, F, F, F, F, F, F, F, P],
+    'pg_real_prepare_u8': [P, P, L, I, I, D, D, D, D, D, P],
+    'pg_image_grid_u8': [P, P, I, I, I, I, I, F, F, P],
     'pg_zero': [P, L, P],
 }
 

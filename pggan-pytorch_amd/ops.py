@@ -243,3 +243,27 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale=1.0):
 def zero_(t):
     _lib.call('pg_zero', _p(t), t.numel() * 4, _stream())
     return t
+
+
+# ------------------------------------------------------------------------- input / output steps
+def real_prepare_u8(x_u8, alpha, range_in=(0, 255), range_out=(-1, 1)):
+    """uint8 device batch [N,C,H,W] -> faded + range-adjusted fp32 batch (dataset.py:54-67 on the device)."""
+    if not x_u8.is_cuda or x_u8.dtype != torch.uint8 or not x_u8.is_contiguous():
+        raise ValueError('expected a contiguous uint8 device tensor')
+    N, C, H, W = x_u8.shape
+    out = torch.empty((N, C, H, W), device=x_u8.device, dtype=torch.float32)
+    _lib.call('pg_real_prepare_u8', x_u8.data_ptr(), _p(out), N * C, H, W, float(alpha), float(range_in[0]),
+              float(range_in[1]), float(range_out[0]), float(range_out[1]), _stream())
+    return out
+
+
+def image_grid_u8(images, drange=(-1, 1), up=1):
+    """fp32 device images [n,C,h,w] -> uint8 HWC grid (output_postprocess.py:35-62 up to the PIL hand-off)."""
+    n, C, h, w = images.shape
+    gw = 1
+    while gw * gw < n:
+        gw += 1
+    gh = (n - 1) // gw + 1
+    grid = torch.empty((gh * h * up, gw * w * up, C), device=images.device, dtype=torch.uint8)
+    _lib.call('pg_image_grid_u8', _p(images), grid.data_ptr(), n, C, h, w, up, float(drange[0]), float(drange[1]), _stream())
+    return grid

@@ -63,3 +63,42 @@ def device_latents(minibatch_size, latent_size, seed=1337, device='cuda'):
     gen = torch.Generator(device=device)
     gen.manual_seed(int(seed))
     return lambda: torch.randn((minibatch_size, latent_size), device=device, dtype=torch.float32, generator=gen)
+
+
+def prepare_real_batch(batch_u8, alpha, range_in=(0, 255), range_out=(-1, 1)):
+    """Device-side DepthDataset.__getitem__ for a whole uint8 batch [N,C,H,W] (reference dataset.py:54-67):
+    fade-in blend with the 2x2 box-filtered copy when alpha < 1, dynamic-range change, fp32.  Doing this on the
+    device also removes the reference's fork-staleness of ``dataset.alpha`` in DataLoader workers."""
+    from . import ops
+    return ops.real_prepare_u8(batch_u8, alpha, range_in, range_out)
+
+
+class DeviceImageSaver(object):
+    """Postprocessor with the reference hook signature ``proc(out, description)`` (output_postprocess.py:21-71,
+    plugins.py:188-192).  The grid / nearest upsample / range / uint8 conversion runs on the device
+    (pg_image_grid_u8); only the final uint8 grid crosses PCIe and is written as PNG."""
+
+    output_file_format = 'fakes_{}.png'
+
+    def __init__(self, samples_path='.', drange=(-1, 1), resolution=512, create_subdirs=True):
+        import os
+        self.samples_path, self.drange, self.resolution = samples_path, drange, resolution
+        if create_subdirs:
+            os.makedirs(self.samples_path, exist_ok=True)
+
+    def to_grid(self, output):
+        from . import ops
+        t = output if torch.is_tensor(output) else torch.from_numpy(np.ascontiguousarray(output, dtype=np.float32))
+        t = t.cuda().contiguous()
+        up = 1 if self.resolution is None else max(1, self.resolution // t.shape[-1])
+        return ops.image_grid_u8(t, self.drange, up)
+
+    def __call__(self, output, description):
+        import os
+        import PIL.Image
+        grid = self.to_grid(output).cpu().numpy()
+        im = PIL.Image.fromarray(grid[:, :, 0], 'L') if grid.shape[2] == 1 else PIL.Image.fromarray(grid, 'RGB')
+        fname = self.output_file_format
+        if type(description) is int:
+            fname = fname.format('{:06}')
+        im.save(os.path.join(self.samples_path, fname.format(description)))

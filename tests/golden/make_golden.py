@@ -315,6 +315,44 @@ def make_full32():
                   f, indent=1)
 
 
+# ---- fixture 6b: the steps either side of the path (dataset fade + dynamic range, ImageSaver grid) -----------
+def make_io_steps():
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        import dataset as ref_dataset
+        import output_postprocess as ref_out
+        import utils as ref_utils
+    fx = {}
+    rs = np.random.RandomState(12)
+
+    class _Self(object):
+        pass
+    for tag, shape, alpha in (('a', (3, 3, 8, 8), 0.3), ('b', (2, 1, 16, 16), 0.85), ('c', (2, 3, 4, 4), 1.0)):
+        x = rs.randint(0, 256, size=shape).astype(np.uint8)
+        me = _Self(); me.alpha = alpha
+        outs = []
+        for img in x:
+            d = img
+            if alpha < 1.0:
+                d = ref_dataset.OldH5Dataset.alpha_fade(me, d)
+            d = ref_utils.adjust_dynamic_range(d, (0, 255), (-1, 1))
+            outs.append(d.astype('float32'))
+        fx['real/%s/in' % tag] = x
+        fx['real/%s/alpha' % tag] = np.float64(alpha)
+        fx['real/%s/out' % tag] = np.stack(outs)
+    for tag, n, C, h, res in (('g6', 6, 3, 8, 32), ('g1', 1, 1, 16, 16), ('g5', 5, 1, 4, 8), ('g4', 4, 3, 16, None)):
+        imgs = (rs.randn(n, C, h, h) * 0.7).astype(np.float32)
+        imgs.reshape(-1)[::7] = np.array([-1.0, 1.0, 0.0, -0.996078431, 0.00392157])[np.arange(imgs.size)[::7] % 5]   # ties / edges
+        saver = ref_out.ImageSaver(samples_path='/tmp', drange=(-1, 1), resolution=res, create_subdirs=False)
+        out = imgs
+        if res is not None:
+            out = ref_utils.numpy_upsample_nearest(out, 2, size=res)
+        im = saver.convert_to_pil_image(saver.create_image_grid(out))
+        fx['grid/%s/in' % tag] = imgs
+        fx['grid/%s/res' % tag] = np.int64(-1 if res is None else res)
+        fx['grid/%s/out' % tag] = np.array(im)
+    np.savez_compressed(os.path.join(HERE, 'io_steps.npz'), **fx)
+
+
 # ---- fixture 7: DepthManager / LRScheduler schedule table (bit-exact) --------------------
 class _FakeNet(object):
     depth = 0
@@ -500,7 +538,7 @@ def make_trace():
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['tiny32', 'tiny16c1', 'flags16', 'thin1024', 'full32', 'schedule', 'trace']
+    which = sys.argv[1:] or ['tiny32', 'tiny16c1', 'flags16', 'thin1024', 'full32', 'io_steps', 'schedule', 'trace']
     for w in which:
         print('making', w, flush=True)
         globals()['make_' + {'tiny16c1': 'tiny16_c1'}.get(w, w)]()
