@@ -5,8 +5,10 @@ from PyTorch after 0.3, so the minimal ``Plugin`` protocol is restated here: an 
 ``trigger_interval = [(n, unit), ...]``, ``register(trainer)`` and one method per unit
 (``iteration`` / ``epoch`` / ``s`` / ``end``) — exactly what ``Trainer.call_plugins`` relies on.
 All schedule arithmetic is Python int (+ one IEEE double division for alpha): bit-exact by construction."""
+import os
 import time
 from datetime import timedelta
+from glob import glob
 
 
 class Plugin(object):
@@ -113,11 +115,15 @@ class LRScheduler(Plugin):
 
 class RampupLR(object):
     """``LambdaLR(opt, rampup).step(cur_nimg)`` without the scheduler machinery: sets
-    ``lr = base_lr * fn(cur_nimg)`` on every param group (what plugins.py:97-99 drives)."""
+    ``lr = base_lr * fn(cur_nimg)`` on every param group (what plugins.py:97-99 drives).  Like torch's
+    schedulers the base rate is kept in the group as ``initial_lr``, so it survives an optimizer
+    state_dict round trip (a resumed run must not ramp from the already-ramped rate)."""
 
     def __init__(self, optimizer, fn):
         self.optimizer, self.fn = optimizer, fn
-        self.base_lrs = [g['lr'] for g in optimizer.param_groups]
+        for g in optimizer.param_groups:
+            g.setdefault('initial_lr', g['lr'])
+        self.base_lrs = [g['initial_lr'] for g in optimizer.param_groups]
 
     def step(self, cur_nimg):
         for g, base in zip(self.optimizer.param_groups, self.base_lrs):
@@ -150,3 +156,97 @@ class ThroughputMonitor(Plugin):
         self.trainer.stats['sec']['tick'] = tick_time
         self.trainer.stats['sec']['kimg'] = tick_time / nimg * 1000
         self.trainer.stats['img/s'] = nimg / tick_time
+
+
+class SaverPlugin(Plugin):
+    """Network snapshots with the reference's file names and whole-module pickles (plugins.py:142-174):
+    ``network-snapshot-{generator|discriminator}-{kimg:06}.dat`` every ``network_snapshot_ticks`` ticks and at
+    the end.  The pickles carry the packed weights AND the equalized-lr constants ``c`` (network.py:19-20 keeps
+    ``c`` outside the state_dict, so whole-module pickling is what makes a snapshot resumable).
+
+    Addition over the reference: ``network-snapshot-trainer-{kimg:06}.dat`` with both Adam
+    states and ``cur_nimg`` — the reference restarts Adam from zero moments on resume."""
+
+    last_pattern = 'network-snapshot-{}-{}.dat'
+
+    def __init__(self, checkpoints_path, keep_old_checkpoints=False, network_snapshot_ticks=40):
+        super(SaverPlugin, self).__init__([(network_snapshot_ticks, 'epoch'), (1, 'end')])
+        self.checkpoints_path = checkpoints_path
+        self.keep_old_checkpoints = keep_old_checkpoints
+
+    def register(self, trainer):
+        self.trainer = trainer
+
+    def epoch(self, epoch_index):
+        import torch
+        tr = self.trainer
+        if tr.parallel is not None and tr.parallel.rank != 0:
+            return                                                   # replicas are identical: rank 0 writes
+        if not self.keep_old_checkpoints:
+            self._clear(self.last_pattern.format('*', '*'))
+        kimg = '{:06}'.format(tr.cur_nimg // 1000)
+        for model, name in [(tr.G, 'generator'), (tr.D, 'discriminator')]:
+            torch.save(model, os.path.join(self.checkpoints_path, self.last_pattern.format(name, kimg)))
+        state = {'cur_nimg': tr.cur_nimg, 'optimizer_d': tr.optimizer_d.state_dict(),
+                 'optimizer_g': tr.optimizer_g.state_dict()}
+        torch.save(state, os.path.join(self.checkpoints_path, self.last_pattern.format('trainer', kimg)))
+
+    def end(self, *args):
+        self.epoch(*args)
+
+    def _clear(self, pattern):
+        for file_name in glob(os.path.join(self.checkpoints_path, pattern)):
+            os.remove(file_name)
+
+
+def load_models(resume_network, result_dir, logger=None):
+    """reference train.py:60-64: ``resume_network`` is a pattern with one ``{}`` for generator/discriminator."""
+    import torch
+    if logger is not None:
+        logger.log('Resuming {}'.format(resume_network))
+    G = torch.load(os.path.join(result_dir, resume_network.format('generator')), weights_only=False)
+    D = torch.load(os.path.join(result_dir, resume_network.format('discriminator')), weights_only=False)
+    return G, D
+
+
+def load_trainer_state(resume_network, result_dir, optimizer_d, optimizer_g):
+    """Restore the Adam moments / step counts written by SaverPlugin; returns ``resume_nimg`` for Trainer."""
+    import torch
+    state = torch.load(os.path.join(result_dir, resume_network.format('trainer')), weights_only=False)
+    optimizer_d.load_state_dict(state['optimizer_d'])
+    optimizer_g.load_state_dict(state['optimizer_g'])
+    return state['cur_nimg']
+
+
+class OutputGenerator(Plugin):
+    """Sample-grid hook (plugins.py:177-195): every ``output_snapshot_ticks`` ticks run G on fresh latents and
+    hand the fp32 ``[n,C,H,W]`` array to each postprocessor as ``proc(out, kimg)``.  A postprocessor exposing
+    ``accepts_device_tensors`` (``utils.DeviceImageSaver``) gets the device tensor instead, so only the final
+    uint8 grid crosses PCIe."""
+
+    def __init__(self, sample_fn, output_postprocessors, samples_count=6, output_snapshot_ticks=3):
+        super(OutputGenerator, self).__init__([(output_snapshot_ticks, 'epoch'), (1, 'end')])
+        self.sample_fn = sample_fn
+        self.output_postprocessors = output_postprocessors
+        self.samples_count = samples_count
+
+    def register(self, trainer):
+        self.trainer = trainer
+
+    def epoch(self, epoch_index):
+        tr = self.trainer
+        if tr.parallel is not None and tr.parallel.rank != 0:
+            return
+        gen_input = self.sample_fn(self.samples_count).cuda()
+        out_dev = tr.G.forward(gen_input)
+        out_host = None
+        for proc in self.output_postprocessors:
+            if getattr(proc, 'accepts_device_tensors', False):
+                proc(out_dev, tr.cur_nimg // 1000)
+            else:
+                if out_host is None:
+                    out_host = out_dev.cpu().numpy()
+                proc(out_host, tr.cur_nimg // 1000)
+
+    def end(self, *args):
+        self.epoch(*args)

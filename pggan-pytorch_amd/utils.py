@@ -79,6 +79,7 @@ class DeviceImageSaver(object):
     (pg_image_grid_u8); only the final uint8 grid crosses PCIe and is written as PNG."""
 
     output_file_format = 'fakes_{}.png'
+    accepts_device_tensors = True            # plugins.OutputGenerator then skips the D2H copy of the fp32 samples
 
     def __init__(self, samples_path='.', drange=(-1, 1), resolution=512, create_subdirs=True):
         import os
@@ -102,3 +103,21 @@ class DeviceImageSaver(object):
         if type(description) is int:
             fname = fname.format('{:06}')
         im.save(os.path.join(self.samples_path, fname.format(description)))
+
+
+def output_samples(generator_path, num_samples, postprocessors, description):
+    """reference generate.py:18-30: load a whole-module generator snapshot, sample, run the postprocessors."""
+    G = torch.load(generator_path, weights_only=False)
+    G.cuda()
+    latent_size = getattr(G, 'latent_size', 512)
+    gen_input = random_latents(num_samples, latent_size).cuda()
+    out_dev = G.forward(gen_input)
+    out_host = None
+    for proc in postprocessors:
+        if getattr(proc, 'accepts_device_tensors', False):
+            proc(out_dev, description)
+        else:
+            if out_host is None:
+                out_host = out_dev.cpu().numpy()
+            proc(out_host, description)
+    return out_dev

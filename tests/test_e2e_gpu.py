@@ -371,3 +371,74 @@ def test_fused_adam_state_roundtrip():
     D._flat_param.copy_(snap); D.mark_params_changed()
     opt2.step()
     assert torch.allclose(after1, D._flat_param, rtol=0, atol=1e-7)
+
+
+def test_fmap_decay_and_latent_size_none(oracle):
+    """fmap_decay != 1 and latent_size=None (-> nf(0), network.py:97-98) vs the oracle."""
+    torch.manual_seed(9)
+    shape = (1, 3, 16, 16)
+    kw = dict(fmap_base=1024, fmap_decay=2.0, fmap_max=64)           # nf(0..3) = 64, 64, 64, 16
+    G = pg.Generator(shape, latent_size=None, **kw)
+    D = pg.Discriminator(shape, **kw)
+    assert G.latent_size == 64
+    gp, dp = G.reference_state_dict(), D.reference_state_dict()
+    G.to(DEV); D.to(DEV)
+    cfg = oracle.NetCfg(16, 3, latent_size=None, **kw)
+    assert cfg.latent_size == 64 and cfg.nf(3) == 16
+    G.depth = D.depth = 2
+    G.alpha = D.alpha = 0.4
+    real, z_d, z_g, mix = oracle.synthetic_batch(77, 4, 3, 16, 64)
+    pg.wgan_gp_loss.set_mixing_factors(mix)
+    d_cost, rl, fl = pg.wgan_gp_D_loss(D, G, real.to(DEV), z_d.to(DEV))
+    d_cost.backward()
+    ref = oracle.d_loss_and_grads(dp, gp, cfg, real, z_d, mix, 2, 0.4)
+    assert rel_err(d_cost, ref['D_cost']) < OUT_TOL
+    _check_grads_loose(reference_grads(D), ref['grads'], 'D grads fmap_decay')
+    g_cost = pg.wgan_gp_G_loss(G, D, z_g.to(DEV))
+    g_cost.backward()
+    refg = oracle.g_loss_and_grads(gp, dp, cfg, z_g, 2, 0.4)
+    assert rel_err(g_cost, refg['G_cost']) < OUT_TOL
+    _check_grads_loose(reference_grads(G), refg['grads'], 'G grads fmap_decay')
+
+
+def test_d_training_repeats(oracle):
+    """Trainer(D_training_repeats=2) (trainer.py:17,90-103): two D steps on fresh real batches / latents per G
+    step, cur_nimg advanced per D step; two iterations against the oracle's op sequence."""
+    torch.manual_seed(11)
+    shape = (1, 3, 8, 8)
+    kw = dict(fmap_base=64, fmap_max=16)
+    G = pg.Generator(shape, latent_size=16, **kw)
+    D = pg.Discriminator(shape, **kw)
+    gp, dp = G.reference_state_dict(), D.reference_state_dict()
+    G.to(DEV); D.to(DEV)
+    G.depth = D.depth = 1
+    cfg = oracle.NetCfg(8, 3, latent_size=16, **kw)
+    rs = np.random.RandomState(3)
+    reals = [torch.from_numpy(rs.rand(4, 3, 8, 8).astype(np.float32) * 2 - 1) for _ in range(4)]
+    zs = [torch.from_numpy(rs.randn(4, 16).astype(np.float32)) for _ in range(6)]
+    mixes = [torch.from_numpy(rs.rand(4, 1).astype(np.float32)) for _ in range(4)]
+    it_r, it_z, it_m = iter(reals), iter(zs), iter(mixes)
+
+    def d_loss(Dm, Gm, real, z):
+        pg.wgan_gp_loss.set_mixing_factors(next(it_m))
+        return pg.wgan_gp_D_loss(Dm, Gm, real, z)
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, None, it_r, lambda: next(it_z), D_training_repeats=2)
+    tr.train(); tr.train()
+    assert tr.cur_nimg == 16 and tr.iterations == 2
+    # oracle: same sequence
+    og, od = oracle.AdamState(), oracle.AdamState()
+    r, z, m = iter(reals), iter(zs), iter(mixes)
+    for _ in range(2):
+        lat = next(z)
+        for _ in range(2):
+            d = oracle.d_loss_and_grads(dp, gp, cfg, next(r), lat, next(m), 1, 1.0)
+            od.step(dp, d['grads'], 0.001)
+            lat = next(z)
+        g = oracle.g_loss_and_grads(gp, dp, cfg, lat, 1, 1.0)
+        og.step(gp, g['grads'], 0.001)
+    for net, ref in ((G, gp), (D, dp)):
+        for k, v in net.reference_state_dict().items():
+            if torch.is_tensor(v):
+                assert rel_err(v.cpu(), ref[k]) < 5e-3, k
