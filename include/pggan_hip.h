@@ -65,6 +65,11 @@ int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, float* db,
  * to the exact kernel symbol that rocprofv3 --kernel-trace --stats reports.                      */
 const char* pg_debug_last_conv_kernel(void);
 
+/* Tuning aid (tools/microbench_conv.py): force a tile configuration for the calling thread's next launches.
+ * key 0: conv tile candidate, key 1: weight-gradient configuration, key 2: conv split-K factor; value -1 restores
+ * the built-in choice. */
+int pg_debug_set_tuning(int key, int value);
+
 /* Repack forward weights [KS][KS][Cout][Cin] into the weights of the backward-data convolution
  * [KS][KS][Cin][Cout] (spatially flipped, channels transposed).                               */
 int pg_pack_dgrad_weights(const float* w, float* wt, int KS, int Cout, int Cin, pg_stream_t stream);

@@ -7,8 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpggan_hip.so')
-ABI_VERSION = 4
+LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
+ABI_VERSION = 5
 
 
 class PgganLibraryError(RuntimeError):
@@ -27,6 +27,7 @@ SIGNATURES = {
     'pg_conv2d_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
     'pg_debug_last_conv_kernel': [],
+    'pg_debug_set_tuning': [I, I],
     'pg_pack_dgrad_weights': [P, P, I, I, I, P],
     'pg_fromrgb_fwd': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
     'pg_fromrgb_bwd_data': [P, P, P, I, I, I, I, I, I, I, F, P],

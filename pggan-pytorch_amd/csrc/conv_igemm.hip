@@ -25,9 +25,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include <cstdio>
 
+#ifndef PG_EXP
+#define PG_EXP 0
+#endif
+
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -157,12 +162,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 
     if (kc_begin < kc_end) fetch(kc_begin);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
+#if PG_EXP >= 3
+        if (kc == kc_begin) {
+#endif
 #pragma unroll
         for (int i = 0; i < WPT; ++i) if (wdst[i] >= 0) *reinterpret_cast<float4*>(wt + wdst[i]) = wreg[i];
 #pragma unroll
         for (int i = 0; i < XPT; ++i) if (xdst[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
+#if PG_EXP >= 3
+        }
+#endif
+#if PG_EXP != 1
         __syncthreads();
+#endif
+#if PG_EXP != 2 && PG_EXP < 3
         if (kc + 1 < kc_end) fetch(kc + 1);              // in flight while the MFMAs below run
+#endif
 
         float a[2][WM][VEC], b[2][WN][VEC];
 #pragma unroll
@@ -172,7 +187,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) {
             const int cur = tp & 1, nxt = cur ^ 1;
+#if PG_EXP == 4
+            if (tp + 1 < TAPS && tp < 1) {
+#elif PG_EXP == 5
+            if (tp + 1 < TAPS && (tp & 1)) {
+#else
             if (tp + 1 < TAPS) {
+#endif
 #pragma unroll
                 for (int m = 0; m < WM; ++m) lds_load<VEC>(wt + (tp + 1) * BCO * KCP + wbase[m], a[nxt][m]);
 #pragma unroll
@@ -189,7 +210,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
                     for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(a[cur][m][s], b[cur][n][s], acc[m][n]);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if PG_EXP != 1
         __syncthreads();
+#endif
     }
 
     // epilogue: lane holds couts cb..cb+3 of pixel j
@@ -556,7 +579,11 @@ int launch_conv(ConvP& p, hipStream_t s)
     const int nblocks = g.ntiles * ncob;
     const int nchunks = p.Cin / (4 * VEC);
     int ksplit = 1;
-    if (nblocks < 192 && nchunks >= 4) {                  // too few workgroups for 256 CUs: slice K
+    if (g_tune[2] > 0) {
+        ksplit = g_tune[2] > nchunks ? nchunks : g_tune[2];
+        const int cper = (nchunks + ksplit - 1) / ksplit;
+        ksplit = (nchunks + cper - 1) / cper;
+    } else if (nblocks < 192 && nchunks >= 4) {           // too few workgroups for 256 CUs: slice K
         ksplit = (512 + nblocks - 1) / nblocks;
         if (ksplit > nchunks) ksplit = nchunks;
         const int cper = (nchunks + ksplit - 1) / ksplit;
@@ -582,10 +609,13 @@ int launch_conv(ConvP& p, hipStream_t s)
     return (int)hipGetLastError();
 }
 
-// Tile-shape selection.  One 4-wave workgroup already saturates a CU's matrix pipes (f32 MFMA issues one
-// instruction per 32 cycles per SIMD), so the launch time is  ceil(workgroups / 256 CUs) x time per workgroup;
-// the candidates below are scored with that model (MFMA cycles incl. padding waste + a fixed per-workgroup and
-// per-chunk overhead) and the cheapest one is launched.  Shapes with < 192 workgroups are K-split in launch_conv.
+// Tile-shape selection.  A workgroup (4 waves, one per SIMD) runs for  L = chunks x (MFMA cycles per chunk + per-chunk
+// overhead) + fixed cycles  when it has the CU to itself; r workgroups are resident per CU (LDS / VGPR limited) and
+// share the matrix pipes, so a batch of r workgroups takes max(L, r x MFMA cycles) and the launch takes
+// (batches over 256 CUs) x that.  Small tiles have a longer MFMA-free fraction per workgroup but far more residents,
+// which is what wins on the 256/512-channel layers at minibatch 3; the constants were fitted to a sweep of every
+// candidate over every layer shape of the schedule (tools/sweep_conv_all.py, tools/fit_cost_model.py: 0.7 % regret).
+// Shapes with < 192 workgroups are K-split in launch_conv (memset + atomics + deferred epilogue: fixed penalty).
 struct TileCand { int bpx, bco; };
 
 template <int KS, int VEC>
@@ -594,13 +624,13 @@ int dispatch_conv(ConvP& p, hipStream_t s)
     if constexpr (KS == 4) {
         return launch_conv<KS, VEC, 4, 1, 1>(p, s);               // 16-tap halo: keep the pixel tile small
     } else {
-        const long long img = (long long)p.Hout * p.Wout;
-        auto ntiles = [&](long long bpx) -> long long {
-            if (img >= bpx) return (long long)p.N * ((img + bpx - 1) / bpx);
-            const long long tn = bpx / img;
-            return (p.N + tn - 1) / tn;
-        };
         static const TileCand cands[] = {{256, 16}, {128, 64}, {128, 32}, {128, 16}, {64, 64}, {64, 32}, {64, 16}, {16, 64}};
+        // registers per lane of each instantiation (hipcc 7.2, KS = 3): residency = min(LDS, 512 / vgpr)
+        static const int vgpr4[] = {160, 200, 128, 100, 164, 100, 68, 92};
+        static const int vgpr2[] = {120, 144, 92, 76, 120, 76, 52, 60};
+        static const int vgpr1[] = {88, 112, 72, 52, 88, 56, 32, 48};
+        const int* vg = VEC == 4 ? vgpr4 : (VEC == 2 ? vgpr2 : vgpr1);
+        constexpr int KCP = RowStride<VEC>::value;
         const int nchunks = p.Cin / (4 * VEC);
         double best = 1e30; int bi = 1;
         for (int i = 0; i < 8; ++i) {
@@ -608,24 +638,36 @@ int dispatch_conv(ConvP& p, hipStream_t s)
             if (c.bpx == 256 && p.Cout > 16) continue;            // 256-pixel tiles only exist for <= 16 couts
             if (c.bco > 16 && p.Cout <= 16) continue;
             if (c.bco > 32 && p.Cout <= 32) continue;
-            const long long blocks = ntiles(c.bpx) * ((p.Cout + c.bco - 1) / c.bco);
-            const double mfma = (double)(c.bpx / 16) * (c.bco / 16) / 4.0 * nchunks * VEC * KS * KS * 32.0;
-            double cost;
-            if (blocks >= 192) {
-                cost = (double)((blocks + 255) / 256) * (mfma + 2500.0 + 700.0 * nchunks);
-            } else {                                              // launch_conv will slice K (same rule as there)
-                long long ks = (512 + blocks - 1) / blocks;
+            const TileGeom g = make_geom(p.N, p.Hout, p.Wout, c.bpx);
+            const int halo = g.TN * ((1 << g.lgTH) + KS - 1) * ((1 << g.lgTW) + KS - 1);
+            const long long lds = (long long)(KS * KS * c.bco + halo) * KCP * 4;
+            long long r = 160 * 1024 / lds;
+            if (r > 512 / vg[i]) r = 512 / vg[i];
+            if (r > 8) r = 8;
+            if (r < 1) r = 1;
+            const long long blocks = (long long)g.ntiles * ((p.Cout + c.bco - 1) / c.bco);
+            long long ks = 1;
+            if (blocks < 192 && nchunks >= 4) {                   // same rule as launch_conv
+                ks = (512 + blocks - 1) / blocks;
                 if (ks > nchunks) ks = nchunks;
-                if (ks < 1) ks = 1;
-                const long long cper = (nchunks + ks - 1) / ks;
-                ks = (nchunks + cper - 1) / cper;
-                const double per_slice = mfma / (double)nchunks * (double)cper + 2500.0 + 700.0 * (double)cper +
-                                         (ks > 1 ? 5.0 * c.bpx * c.bco + 2000.0 : 0.0);   // fp32-atomic commit (~10 cycles each per CU,
-                                                                                          // two workgroups share it) + deferred epilogue
-                cost = (double)((blocks * ks + 255) / 256) * per_slice;
+                const long long cp = (nchunks + ks - 1) / ks;
+                ks = (nchunks + cp - 1) / cp;
             }
+            const long long cper = (nchunks + ks - 1) / ks;
+            const long long wgs = blocks * ks;
+            const double mfma_chunk = (double)(c.bpx / 16) * (c.bco / 16) / 4.0 * VEC * KS * KS * 32.0;
+            const double mfma_wg = mfma_chunk * (double)cper;
+            const double L = (double)cper * (mfma_chunk + 300.0) + 1500.0 + (ks > 1 ? 5.0 * c.bpx * c.bco + 2000.0 : 0.0);
+            const long long full = wgs / (256 * r), rem = wgs % (256 * r);
+            double cost = (double)full * (L > r * mfma_wg ? L : r * mfma_wg);
+            if (rem) {
+                const double rr = (double)((rem + 255) / 256);
+                cost += L > rr * mfma_wg ? L : rr * mfma_wg;
+            }
+            if (ks > 1) cost += 8000.0;
             if (cost < best) { best = cost; bi = i; }
         }
+        if (g_tune[0] >= 0) bi = g_tune[0];
         switch (bi) {
             case 0: return launch_conv<KS, VEC, 1, 1, 4>(p, s);
             case 1: return launch_conv<KS, VEC, 2, 2, 4>(p, s);
@@ -685,6 +727,22 @@ int dispatch_wgrad(WgP& p, hipStream_t s)
         const long long M = (long long)p.N * p.Hout * p.Wout;
         if (M <= 32) return launch_wgrad<KS, 1, 1, 2, 2, 16>(p, s);
         if (p.Cout <= 16 && p.Cin <= 16) return launch_wgrad<KS, 1, 1, 1, 1, 128>(p, s);     // 16x16 block
+        if constexpr (KS == 3) {
+            switch (g_tune[1]) {                                                               // tuning sweep only
+                case 1: return launch_wgrad<KS, 2, 1, 1, 1, 128>(p, s);
+                case 3: return launch_wgrad<KS, 2, 1, 2, 1, 64>(p, s);
+                default: break;
+            }
+        }
+        if constexpr (KS == 3) {
+            // measured (tools/sweep_wgrad.py): with >= ~4e8 MACs per tap the 64-cout block (two K-waves) wins on
+            // >= 64 input channels and 128-pixel tiles win on the narrow layers; small launches keep 32x16 / 64 px
+            const double macs = (double)M * p.Cout * p.Cin;
+            if (g_tune[1] < 0 && macs >= 4e8) {
+                if (p.Cin >= 64) return launch_wgrad<KS, 2, 1, 2, 1, 64>(p, s);
+                return launch_wgrad<KS, 2, 1, 1, 1, 128>(p, s);
+            }
+        }
         return launch_wgrad<KS, 2, 1, 1, 1, 64>(p, s);     // 32(cout) x 16(cin) block, 4 waves split the pixels
     }
 }
@@ -739,6 +797,13 @@ extern "C" int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, 
 }
 
 extern "C" const char* pg_debug_last_conv_kernel(void) { return g_last_kernel; }
+
+extern "C" int pg_debug_set_tuning(int key, int value)
+{
+    if (key < 0 || key >= 4) return PG_E_ARG;
+    g_tune[key] = value;
+    return 0;
+}
 
 extern "C" int pg_pack_dgrad_weights(const float* w, float* wt, int KS, int Cout, int Cin, pg_stream_t stream)
 {
