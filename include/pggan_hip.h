@@ -146,13 +146,15 @@ int pg_pixelnorm_lrelu_bwd(const float* gy, const float* y, const float* r, floa
 /* ---------------------------------------------------------------------------------------------
  * Minibatch stddev (network.py:174-187): ONE scalar per group over the whole [n,H,W,C] tensor.
  * x: [NB][HW][C]   y: [NB][HW][CP] (CP >= C+1, CP % 4 == 0; channels > C are zero-filled)
- * NB = G groups of n consecutive images.  stats[g] = {mu, sigma}.
+ * NB = G groups of n consecutive images.  stats: G rows of PG_MBSTD_STATS_STRIDE floats, row g = {mu, sigma,
+ * workspace of the multi-workgroup reduction...} (caller-owned, no allocation inside).
  *   y[...,:C] = x;  y[...,C] = sigma_g = sqrt(mean((x-mu)^2) + 1e-8)                           */
+#define PG_MBSTD_STATS_STRIDE 136
 int pg_mbstd_fwd(const float* x, float* y, float* stats, int G, int n, int HW, int C, int CP,
                  pg_stream_t stream);
 
 /* Tangent (forward-mode) of the above, used by the gradient-penalty second-order pass:
- *   ty[...,:C] = tx;  ty[...,C] = <x-mu, tx> / (M*sigma);  tstats[g] = {mean(tx), <x-mu,tx>}    */
+ *   ty[...,:C] = tx;  ty[...,C] = <x-mu, tx> / (M*sigma);  tstats row g = {mean(tx), <x-mu,tx>, workspace} (same stride) */
 int pg_mbstd_tangent(const float* x, const float* tx, const float* stats, float* ty, float* tstats,
                      int G, int n, int HW, int C, int CP, pg_stream_t stream);
 

@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
-thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -512,6 +512,207 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The two 4x4 layers at the 1x1 <-> 4x4 boundary (GFirstBlock.c1 network.py:47, DLastBlock.c2 :163) are dense
+// layers in disguise: every output pixel of the pad-3 conv over a 1x1 input sees exactly ONE tap, and the valid
+// 4x4 conv of a 4x4 input is one K = 16*Cin dot product.  Run through the generic halo kernel they execute 16x
+// the useful MFMAs (pad-3 case) or leave most CUs idle; these skinny-GEMM kernels stream the 16*Cout*Cin
+// weights once, straight from global memory into MFMA operands (no LDS: nothing is reused inside a workgroup).
+__device__ __forceinline__ void k4_epilogue(const ConvP& p, const f32x4& acc, size_t off, int cb)
+{
+    float4 o = make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+    if (p.mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
+        o.x *= mk.x > 0.f ? 1.f : p.mask_slope; o.y *= mk.y > 0.f ? 1.f : p.mask_slope;
+        o.z *= mk.z > 0.f ? 1.f : p.mask_slope; o.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+    } else {
+        if (p.bias) { const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+        o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
+        o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+    }
+    *reinterpret_cast<float4*>(p.y + off) = o;
+}
+
+// 1x1 -> 4x4 (KS 4, pad 3):  y[n][pix][co] = epi(scale * sum_ci w[15-pix][co][ci] * x[n][ci]).
+// One wave per (pixel, 16 couts); NT tiles of 16 samples share the weight fragment.
+template <int NT>
+__global__ __launch_bounds__(256) void conv_k4_expand_kernel(ConvP p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int tiles_co = p.Cout >> 4;
+    const int wid = blockIdx.x * 4 + wave;
+    const int pix = wid / tiles_co, co0 = (wid - pix * tiles_co) << 4;
+    if (pix >= 16) return;
+    const float* wrow = p.w + ((size_t)(15 - pix) * p.Cout + co0 + li) * p.Cin + 4 * kk;
+    for (int nb = blockIdx.y * 16 * NT; nb < p.N; nb += gridDim.y * 16 * NT) {
+        f32x4 acc[NT];
+        const float* xrow[NT];
+        bool ok[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int n = nb + 16 * t + li;
+            ok[t] = n < p.N;
+            xrow[t] = p.x + (size_t)(ok[t] ? n : 0) * p.Cin + 4 * kk;
+        }
+#pragma unroll 4
+        for (int c = 0; c < p.Cin; c += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(wrow + c);
+            float4 b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                b[t] = ok[t] ? *reinterpret_cast<const float4*>(xrow[t] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = MFMA16(a.x, b[t].x, acc[t]); acc[t] = MFMA16(a.y, b[t].y, acc[t]);
+                acc[t] = MFMA16(a.z, b[t].z, acc[t]); acc[t] = MFMA16(a.w, b[t].w, acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = nb + 16 * t + li;
+            if (n < p.N) k4_epilogue(p, acc[t], ((size_t)n * 16 + pix) * p.Cout + co0 + 4 * kk, co0 + 4 * kk);
+        }
+    }
+}
+
+// 4x4 -> 1x1 (KS 4, pad 0):  y[n][co] = epi(scale * sum_pix sum_ci w[pix][co][ci] * x[n][pix][ci]).
+// One 16-wave workgroup per (16 couts, NT*16 samples): wave = input pixel, partial sums reduced through LDS.
+template <int NT>
+__global__ __launch_bounds__(1024) void conv_k4_reduce_kernel(ConvP p)
+{
+    __shared__ float red[16 * NT * 256];
+    const int lane = threadIdx.x & 63, pix = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int co0 = blockIdx.x << 4;
+    const int nb = blockIdx.y * 16 * NT;
+    const float* wrow = p.w + ((size_t)pix * p.Cout + co0 + li) * p.Cin + 4 * kk;
+    f32x4 acc[NT];
+    const float* xrow[NT];
+    bool ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = nb + 16 * t + li;
+        ok[t] = n < p.N;
+        xrow[t] = p.x + ((size_t)(ok[t] ? n : 0) * 16 + pix) * p.Cin + 4 * kk;
+    }
+#pragma unroll 4
+    for (int c = 0; c < p.Cin; c += 16) {
+        const float4 a = *reinterpret_cast<const float4*>(wrow + c);
+        float4 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            b[t] = ok[t] ? *reinterpret_cast<const float4*>(xrow[t] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = MFMA16(a.x, b[t].x, acc[t]); acc[t] = MFMA16(a.y, b[t].y, acc[t]);
+            acc[t] = MFMA16(a.z, b[t].z, acc[t]); acc[t] = MFMA16(a.w, b[t].w, acc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        *reinterpret_cast<float4*>(red + ((pix * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    if (pix < NT) {                                   // wave t finishes tile t (fixed summation order)
+        const int t = pix;
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(red + ((q * NT + t) * 64 + lane) * 4);
+            sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+        }
+        const int n = nb + 16 * t + li;
+        if (n < p.N) k4_epilogue(p, sum, (size_t)n * p.Cout + co0 + 4 * kk, co0 + 4 * kk);
+    }
+}
+
+// Weight gradient of both layers: per tap an outer-product GEMM with K = N (the minibatch):
+//   EXPAND: dW[tap][co][ci] += scale * sum_n gz[n][15-tap][co] * x[n][ci]        (x: [N][Cin], gz: [N][16][Cout])
+//   else  : dW[tap][co][ci] += scale * sum_n gz[n][co]         * x[n][tap][ci]   (x: [N][16][Cin], gz: [N][Cout])
+// One wave per (tap, 16 couts, 64 cins): HBM-bound on the 16*Cout*Cin read-modify-write of dW.
+template <bool EXPAND>
+__global__ __launch_bounds__(256) void conv_k4_wgrad_kernel(WgP p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int tiles_co = p.Cout >> 4, groups_ci = (p.Cin + 63) >> 6;
+    int wid = blockIdx.x * 4 + wave;
+    const int cig = wid % groups_ci; wid /= groups_ci;
+    const int cot = wid % tiles_co; const int tap = wid / tiles_co;
+    if (tap >= 16) return;
+    const int co0 = cot << 4, ci0 = cig << 6;
+    const int gstride = EXPAND ? 16 * p.Cout : p.Cout, goff = EXPAND ? (15 - tap) * p.Cout : 0;
+    const int xstride = EXPAND ? p.Cin : 16 * p.Cin, xoff = EXPAND ? 0 : tap * p.Cin;
+    const bool do_bias = p.db != nullptr && cig == 0 && (EXPAND || tap == 0);
+    f32x4 acc[4], accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int n0 = 0; n0 < p.N; n0 += 4) {
+        const int n = n0 + kk;
+        const bool okn = n < p.N;
+        const float a = okn ? p.gz[(size_t)n * gstride + goff + co0 + li] : 0.f;
+        float b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            b[t] = (okn && ci0 + 16 * t + li < p.Cin) ? p.x[(size_t)n * xstride + xoff + ci0 + 16 * t + li] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a, b[t], acc[t]);
+        if (do_bias) accb = MFMA16(a, 1.0f, accb);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ci = ci0 + 16 * t + li;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* dst = p.dw + ((size_t)(tap * p.Cout + co0 + 4 * kk + r) * p.Cin + ci);
+            *dst += acc[t][r] * p.scale;                       // this wave is the only writer of the element
+        }
+    }
+    if (do_bias && li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(p.db + co0 + 4 * kk + r, accb[r]);
+    }
+}
+
+inline bool k4_dense_ok(int Cin, int Cout) { return (Cin & 15) == 0 && (Cout & 15) == 0; }
+
+int launch_k4_conv(ConvP& p, hipStream_t s)
+{
+    if (p.pad == 3) {                                        // 1x1 -> 4x4
+        const int nt = p.N <= 16 ? 1 : (p.N <= 32 ? 2 : 4);
+        int gy = (p.N + 16 * nt - 1) / (16 * nt); if (gy > 8) gy = 8;
+        dim3 grid((16 * (p.Cout >> 4) + 3) / 4, gy);
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_k4_expand_kernel<%d>", nt);
+        if (nt == 1) hipLaunchKernelGGL(conv_k4_expand_kernel<1>, grid, dim3(256), 0, s, p);
+        else if (nt == 2) hipLaunchKernelGGL(conv_k4_expand_kernel<2>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_k4_expand_kernel<4>, grid, dim3(256), 0, s, p);
+    } else {                                                 // 4x4 -> 1x1
+        const int nt = p.N <= 16 ? 1 : 2;
+        dim3 grid(p.Cout >> 4, (p.N + 16 * nt - 1) / (16 * nt));
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_k4_reduce_kernel<%d>", nt);
+        if (nt == 1) hipLaunchKernelGGL(conv_k4_reduce_kernel<1>, grid, dim3(1024), 0, s, p);
+        else hipLaunchKernelGGL(conv_k4_reduce_kernel<2>, grid, dim3(1024), 0, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_k4_wgrad(WgP& p, hipStream_t s)
+{
+    const int waves = 16 * (p.Cout >> 4) * ((p.Cin + 63) >> 6);
+    dim3 grid((waves + 3) / 4);
+    if (p.pad == 3) {
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_k4_wgrad_kernel<true>");
+        hipLaunchKernelGGL(conv_k4_wgrad_kernel<true>, grid, dim3(256), 0, s, p);
+    } else {
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_k4_wgrad_kernel<false>");
+        hipLaunchKernelGGL(conv_k4_wgrad_kernel<false>, grid, dim3(256), 0, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
 // wt[KS-1-kh][KS-1-kw][ci][co] = w[kh][kw][co][ci]
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wt, int KS, int Cout, int Cin)
 {
@@ -766,6 +967,9 @@ extern "C" int pg_conv2d_nhwc(const float* x, const float* w, const float* bias,
         (long long)KS * KS * Cout * Cin >= (1ll << 31)) return PG_E_UNSUP;
     p.scale = scale; p.slope = slope; p.mask_slope = mask_slope;
     hipStream_t s = (hipStream_t)stream;
+    if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
+        ((pad == 3 && Hin == 1 && Win == 1) || (pad == 0 && Hin == 4 && Win == 4)))
+        return launch_k4_conv(p, s);
     switch (KS) {
         case 1: return dispatch_conv_vec<1>(p, s);
         case 3: return dispatch_conv_vec<3>(p, s);
@@ -788,6 +992,9 @@ extern "C" int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, 
     if (ups && ((Hin | Win) & 1)) return PG_E_ARG;
     p.scale = scale;
     hipStream_t s = (hipStream_t)stream;
+    if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
+        ((pad == 3 && Hin == 1 && Win == 1) || (pad == 0 && Hin == 4 && Win == 4)))
+        return launch_k4_wgrad(p, s);
     switch (KS) {
         case 1: return dispatch_wgrad<1>(p, s);
         case 3: return dispatch_wgrad<3>(p, s);

@@ -197,96 +197,150 @@ __global__ __launch_bounds__(256) void pixelnorm_lrelu_bwd_kernel(const float* _
 inline int pick_lpp(int C) { int c4 = C >> 2; int l = 1; while (l < c4 && l < 64) l <<= 1; return l; }
 
 // ------------------------------------------------------------------------------ minibatch stddev
-// One 1024-thread workgroup per group (the tensor is n*HW*C <= a few 100 K floats, L2-resident).
-__global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                         float* __restrict__ stats, int n, int HW, int C, int CP)
+// The tensor of one group is n*HW*C <= a few 100 K floats (L2 resident).  MB_PARTS workgroups per group:
+// a statistics launch leaves per-slice partials in the stats row, the writer launch merges them (every
+// workgroup redundantly, in the same order -> identical mu/sigma everywhere) and streams its slice.
+// stats row (PG_MBSTD_STATS_STRIDE floats): [mu, sigma, partials...];  tstats row: [mean(tx), <x-mu,tx>, partials...]
+constexpr int MB_PARTS = 32;
+constexpr int MB_STRIDE = PG_MBSTD_STATS_STRIDE;
+static_assert(MB_STRIDE >= 2 + 4 * MB_PARTS, "stats row too small for the partials");
+
+__device__ __forceinline__ void mb_slice(size_t M4, size_t& b, size_t& e)
+{
+    const size_t per = (M4 + MB_PARTS - 1) / MB_PARTS;
+    b = (size_t)blockIdx.x * per; e = b + per < M4 ? b + per : M4;
+    if (b > M4) b = M4;
+}
+
+// partial {count, mean, M2} of this workgroup's slice (two passes over the slice: exact local mean first)
+__global__ __launch_bounds__(256) void mbstd_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                          int n, int HW, int C)
 {
     __shared__ float sh[16];
-    const int g = blockIdx.x;
-    const size_t M = (size_t)n * HW * C;
-    const float* xg = x + (size_t)g * M;
-    const float4* x4 = reinterpret_cast<const float4*>(xg);
-    const size_t M4 = M >> 2;
+    const int g = blockIdx.y;
+    const size_t M = (size_t)n * HW * C, M4 = M >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)g * M);
+    size_t b, e; mb_slice(M4, b, e);
     float s = 0.f;
-    for (size_t i = threadIdx.x; i < M4; i += blockDim.x) { const float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
-    const float mu = block_sum(s, sh) / (float)M;
+#pragma unroll 4
+    for (size_t i = b + threadIdx.x; i < e; i += 256) { const float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
+    const float cnt = (float)(4 * (e - b));
+    const float mean = cnt > 0.f ? block_sum(s, sh) / cnt : 0.f;
     float q = 0.f;
-    for (size_t i = threadIdx.x; i < M4; i += blockDim.x) {
+#pragma unroll 4
+    for (size_t i = b + threadIdx.x; i < e; i += 256) {
         const float4 v = x4[i];
-        const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
-        q += (a * a + b * b) + (c * c + d * d);
+        const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
-    const float sigma = sqrtf(block_sum(q, sh) / (float)M + 1.0e-8f);
-    if (threadIdx.x == 0) { stats[2 * g] = mu; stats[2 * g + 1] = sigma; }
-    // write y: copy + sigma channel + zero padding
-    const int C4 = C >> 2, CP4 = CP >> 2;
+    const float m2 = block_sum(q, sh);
+    if (threadIdx.x == 0) {
+        float* pr = stats + (size_t)g * MB_STRIDE + 2 + 4 * blockIdx.x;
+        pr[0] = cnt; pr[1] = mean; pr[2] = m2;
+    }
+}
+
+// Chan's pairwise merge of the partials, sequential and identical in every workgroup
+__device__ __forceinline__ void mb_merge(const float* __restrict__ row, float M, float& mu, float& sigma)
+{
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int i = 0; i < MB_PARTS; ++i) {
+        const float c = row[2 + 4 * i], m = row[3 + 4 * i], q = row[4 + 4 * i];
+        if (c > 0.f) {
+            const float tot = cnt + c, d = m - mean;
+            mean += d * (c / tot);
+            m2 += q + d * d * (cnt * c / tot);
+            cnt = tot;
+        }
+    }
+    mu = mean;
+    sigma = sqrtf(m2 / M + 1.0e-8f);
+}
+
+template <bool TANGENT>
+__global__ __launch_bounds__(256) void mbstd_write_kernel(const float* __restrict__ src, float* __restrict__ y,
+                                                          float* __restrict__ stats, const float* __restrict__ xstats,
+                                                          int n, int HW, int C, int CP)
+{
+    const int g = blockIdx.y;
     const size_t rows = (size_t)n * HW;
+    const size_t M = rows * C;
+    float* row = stats + (size_t)g * MB_STRIDE;
+    float extra;                                             // value of channel C
+    if (!TANGENT) {
+        float mu, sigma; mb_merge(row, (float)M, mu, sigma);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { row[0] = mu; row[1] = sigma; }
+        extra = sigma;
+    } else {
+        float ts = 0.f, dot = 0.f;
+        for (int i = 0; i < MB_PARTS; ++i) { ts += row[2 + 4 * i]; dot += row[3 + 4 * i]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { row[0] = ts / (float)M; row[1] = dot; }
+        extra = dot / ((float)M * xstats[(size_t)g * MB_STRIDE + 1]);
+    }
+    const int C4 = C >> 2, CP4 = CP >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)g * M);
     float4* y4 = reinterpret_cast<float4*>(y + (size_t)g * rows * CP);
-    for (size_t i = threadIdx.x; i < rows * CP4; i += blockDim.x) {
-        const size_t row = i / CP4; const int c = (int)(i % CP4);
+    const size_t total = rows * CP4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / CP4; const int c = (int)(i % CP4);
         float4 v;
-        if (c < C4) v = x4[row * C4 + c];
-        else if (c == C4) v = make_float4(sigma, 0.f, 0.f, 0.f);
+        if (c < C4) v = s4[r * C4 + c];
+        else if (c == C4) v = make_float4(extra, 0.f, 0.f, 0.f);
         else v = make_float4(0.f, 0.f, 0.f, 0.f);
         y4[i] = v;
     }
 }
 
-__global__ __launch_bounds__(1024) void mbstd_tangent_kernel(const float* __restrict__ x, const float* __restrict__ tx,
-                                                             const float* __restrict__ stats, float* __restrict__ ty,
-                                                             float* __restrict__ tstats, int n, int HW, int C, int CP)
+// partial {sum tx, <x-mu, tx>} of this workgroup's slice
+__global__ __launch_bounds__(256) void mbstd_tangent_stats_kernel(const float* __restrict__ x, const float* __restrict__ tx,
+                                                                  const float* __restrict__ stats, float* __restrict__ tstats,
+                                                                  int n, int HW, int C)
 {
     __shared__ float sh[16];
-    const int g = blockIdx.x;
+    const int g = blockIdx.y;
     const size_t M = (size_t)n * HW * C, M4 = M >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)g * M);
     const float4* t4 = reinterpret_cast<const float4*>(tx + (size_t)g * M);
-    const float mu = stats[2 * g], sigma = stats[2 * g + 1];
+    const float mu = stats[(size_t)g * MB_STRIDE];
+    size_t b, e; mb_slice(M4, b, e);
     float s = 0.f, d = 0.f;
-    for (size_t i = threadIdx.x; i < M4; i += blockDim.x) {
+#pragma unroll 4
+    for (size_t i = b + threadIdx.x; i < e; i += 256) {
         const float4 v = x4[i], t = t4[i];
         s += (t.x + t.y) + (t.z + t.w);
         d += (v.x - mu) * t.x + (v.y - mu) * t.y + (v.z - mu) * t.z + (v.w - mu) * t.w;
     }
-    const float tmean = block_sum(s, sh) / (float)M;
-    const float dot = block_sum(d, sh);
-    const float tsigma = dot / ((float)M * sigma);
-    if (threadIdx.x == 0) { tstats[2 * g] = tmean; tstats[2 * g + 1] = dot; }
-    const int C4 = C >> 2, CP4 = CP >> 2;
-    const size_t rows = (size_t)n * HW;
-    float4* y4 = reinterpret_cast<float4*>(ty + (size_t)g * rows * CP);
-    for (size_t i = threadIdx.x; i < rows * CP4; i += blockDim.x) {
-        const size_t row = i / CP4; const int c = (int)(i % CP4);
-        float4 v;
-        if (c < C4) v = t4[row * C4 + c];
-        else if (c == C4) v = make_float4(tsigma, 0.f, 0.f, 0.f);
-        else v = make_float4(0.f, 0.f, 0.f, 0.f);
-        y4[i] = v;
+    s = block_sum(s, sh);
+    d = block_sum(d, sh);
+    if (threadIdx.x == 0) {
+        float* pr = tstats + (size_t)g * MB_STRIDE + 2 + 4 * blockIdx.x;
+        pr[0] = s; pr[1] = d;
     }
 }
 
-__global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                         const float* __restrict__ stats, const float* __restrict__ tx,
-                                                         const float* __restrict__ tstats, const float* __restrict__ gy_first,
-                                                         float* __restrict__ gx, int n, int HW, int C, int CP,
-                                                         int apply_mask, float mask_slope)
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                        const float* __restrict__ stats, const float* __restrict__ tx,
+                                                        const float* __restrict__ tstats, const float* __restrict__ gy_first,
+                                                        float* __restrict__ gx, int n, int HW, int C, int CP,
+                                                        int apply_mask, float mask_slope)
 {
     __shared__ float sh[16];
-    const int g = blockIdx.x;
+    const int g = blockIdx.y;
     const size_t rows = (size_t)n * HW;
     const size_t M = rows * C;
-    const float mu = stats[2 * g], sigma = stats[2 * g + 1];
+    const float mu = stats[(size_t)g * MB_STRIDE], sigma = stats[(size_t)g * MB_STRIDE + 1];
+    // Gs over the (few hundred) rows: recomputed by every workgroup, same order -> same value
     float gs = 0.f, gs1 = 0.f;
-    if (gy) for (size_t r = threadIdx.x; r < rows; r += blockDim.x) gs += gy[((size_t)g * rows + r) * CP + C];
-    if (tx) for (size_t r = threadIdx.x; r < rows; r += blockDim.x) gs1 += gy_first[((size_t)g * rows + r) * CP + C];
+    if (gy) for (size_t r = threadIdx.x; r < rows; r += 256) gs += gy[((size_t)g * rows + r) * CP + C];
+    if (tx) for (size_t r = threadIdx.x; r < rows; r += 256) gs1 += gy_first[((size_t)g * rows + r) * CP + C];
     const float Gs = gy ? block_sum(gs, sh) : 0.f;
     const float Gs1 = tx ? block_sum(gs1, sh) : 0.f;
     const float invMs = 1.f / ((float)M * sigma);
     const float k1 = Gs * invMs;
     float tmean = 0.f, k2 = 0.f, k3 = 0.f;
     if (tx) {
-        tmean = tstats[2 * g];
-        const float dot = tstats[2 * g + 1];
+        tmean = tstats[(size_t)g * MB_STRIDE];
+        const float dot = tstats[(size_t)g * MB_STRIDE + 1];
         k2 = Gs1 * invMs;                                   // multiplies (tx - mean tx)
         k3 = k2 * dot / ((float)M * sigma * sigma);         // multiplies (x - mu)
     }
@@ -294,12 +348,12 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const float* __restrict
     const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)g * M);
     const float4* t4 = tx ? reinterpret_cast<const float4*>(tx + (size_t)g * M) : nullptr;
     float4* o4 = reinterpret_cast<float4*>(gx + (size_t)g * M);
-    for (size_t i = threadIdx.x; i < rows * C4; i += blockDim.x) {
+    const float kx = k1 - k3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < rows * C4; i += (size_t)gridDim.x * 256) {
         const size_t row = i / C4; const int c = (int)(i % C4);
         const float4 xv = x4[i];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gy) v = *reinterpret_cast<const float4*>(gy + ((size_t)g * rows + row) * CP + 4 * c);
-        const float kx = k1 - k3;
         v.x += kx * (xv.x - mu); v.y += kx * (xv.y - mu); v.z += kx * (xv.z - mu); v.w += kx * (xv.w - mu);
         if (tx) {
             const float4 t = t4[i];
@@ -529,7 +583,10 @@ extern "C" int pg_mbstd_fwd(const float* x, float* y, float* stats, int G, int n
 {
     if (!x || !y || !stats || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
     if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
-    LAUNCH(mbstd_fwd_kernel, dim3(G), dim3(1024), 0, stream, x, y, stats, n, HW, C, CP);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mbstd_stats_kernel, dim3(MB_PARTS, G), dim3(256), 0, s, x, stats, n, HW, C);
+    hipLaunchKernelGGL(mbstd_write_kernel<false>, dim3(MB_PARTS, G), dim3(256), 0, s, x, y, stats, (const float*)nullptr, n, HW, C, CP);
+    return (int)hipGetLastError();
 }
 
 extern "C" int pg_mbstd_tangent(const float* x, const float* tx, const float* stats, float* ty, float* tstats,
@@ -537,7 +594,10 @@ extern "C" int pg_mbstd_tangent(const float* x, const float* tx, const float* st
 {
     if (!x || !tx || !stats || !ty || !tstats || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
     if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
-    LAUNCH(mbstd_tangent_kernel, dim3(G), dim3(1024), 0, stream, x, tx, stats, ty, tstats, n, HW, C, CP);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mbstd_tangent_stats_kernel, dim3(MB_PARTS, G), dim3(256), 0, s, x, tx, stats, tstats, n, HW, C);
+    hipLaunchKernelGGL(mbstd_write_kernel<true>, dim3(MB_PARTS, G), dim3(256), 0, s, tx, ty, tstats, stats, n, HW, C, CP);
+    return (int)hipGetLastError();
 }
 
 extern "C" int pg_mbstd_bwd(const float* gy, const float* x, const float* stats,
@@ -549,7 +609,7 @@ extern "C" int pg_mbstd_bwd(const float* gy, const float* x, const float* stats,
     if (!gy && !tx) return PG_E_ARG;
     if (tx && (!tstats || !gy_first)) return PG_E_ARG;
     if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
-    LAUNCH(mbstd_bwd_kernel, dim3(G), dim3(1024), 0, stream, gy, x, stats, tx, tstats, gy_first, gx, n, HW, C, CP, apply_mask, mask_slope);
+    LAUNCH(mbstd_bwd_kernel, dim3(MB_PARTS, G), dim3(256), 0, stream, gy, x, stats, tx, tstats, gy_first, gx, n, HW, C, CP, apply_mask, mask_slope);
 }
 
 extern "C" int pg_linear1_fwd(const float* h, const float* w, const float* b, float* s, int N, int C, pg_stream_t stream)

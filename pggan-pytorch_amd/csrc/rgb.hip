@@ -329,6 +329,90 @@ __global__ __launch_bounds__(256) void torgb_wgrad_kernel(
     }
 }
 
+// ---- wide-channel variants (>= 256 feature channels: the 4x4 .. 32x32 stages, a few hundred pixels): one wave
+// per pixel, each lane strides over the channels in float4 steps, xor-shuffle reduction.  The thread-per-pixel
+// kernels above would leave all but 1-3 workgroups idle there and walk 2 KB rows serially.
+__device__ __forceinline__ float wave_sum64(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void torgb_fwd_wide_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ prev, float* __restrict__ out,
+    int N, int C, int H, int W, int Cin, float scale, float out_mul, float prev_mul)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t total = (size_t)N * H * W;
+    const int c4n = Cin >> 2;
+    for (size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < total; pix += (size_t)gridDim.x * 4) {
+        const float4* xp = reinterpret_cast<const float4*>(x + pix * Cin);
+        float a[MAXC] = {0.f, 0.f, 0.f, 0.f};
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            const float4 xv = xp[c4];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)c * Cin + 4 * c4);
+                a[c] += (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) a[c] = wave_sum64(a[c]);
+        if (lane == 0) {
+            const int wv = (int)(pix % W);
+            const size_t r = pix / W;
+            const int h = (int)(r % H), n = (int)(r / H);
+            for (int c = 0; c < C; ++c) {
+                float v = (a[c] * scale + (bias ? bias[c] : 0.f)) * out_mul;
+                if (prev) v += prev_mul * prev[(((size_t)n * C + c) * (H >> 1) + (h >> 1)) * (W >> 1) + (wv >> 1)];
+                out[(((size_t)n * C + c) * H + h) * W + wv] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fromrgb_bwd_data_wide_kernel(
+    const float* __restrict__ gz, const float* __restrict__ w, float* __restrict__ gimg,
+    int N, int C, int H, int W, int Cout, int pool, int accumulate, float scale)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t total = (size_t)N * H * W;
+    const int c4n = Cout >> 2;
+    for (size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < total; pix += (size_t)gridDim.x * 4) {
+        const float4* gp = reinterpret_cast<const float4*>(gz + pix * Cout);
+        float a[MAXC] = {0.f, 0.f, 0.f, 0.f};
+        for (int c4 = lane; c4 < c4n; c4 += 64) {
+            const float4 gv = gp[c4];
+            const float* wr = w + (size_t)4 * c4 * C;             // w[co][c], 4 consecutive couts
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C)
+                a[c] += (gv.x * wr[c] + gv.y * wr[C + c]) + (gv.z * wr[2 * C + c] + gv.w * wr[3 * C + c]);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) a[c] = wave_sum64(a[c]);
+        if (lane == 0) {
+            const int wv = (int)(pix % W);
+            const size_t r = pix / W;
+            const int h = (int)(r % H), n = (int)(r / H);
+            for (int c = 0; c < C; ++c) {
+                if (!pool) {
+                    float* o = gimg + (((size_t)n * C + c) * H + h) * W + wv;
+                    const float v = a[c] * scale;
+                    *o = accumulate ? *o + v : v;
+                } else {
+                    const int H2 = 2 * H, W2 = 2 * W;
+                    float* o = gimg + (((size_t)n * C + c) * H2 + 2 * h) * W2 + 2 * wv;
+                    const float v = a[c] * scale * 0.25f;
+                    if (accumulate) { o[0] += v; o[1] += v; o[W2] += v; o[W2 + 1] += v; }
+                    else { o[0] = v; o[1] = v; o[W2] = v; o[W2 + 1] = v; }
+                }
+            }
+        }
+    }
+}
+
 inline int grid_for(size_t total, int block = 256, int cap = 256 * 16)
 {
     size_t g = (total + block - 1) / block;
@@ -360,6 +444,11 @@ extern "C" int pg_fromrgb_bwd_data(const float* gz, const float* w, float* gimg,
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cout & 3) return PG_E_ALIGN;
     const size_t total = (size_t)N * H * W;
+    if (Cout >= 256 && total <= 65536) {
+        hipLaunchKernelGGL(fromrgb_bwd_data_wide_kernel, dim3(grid_for(total, 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                           gz, w, gimg, N, C, H, W, Cout, pool, accumulate, scale);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(fromrgb_bwd_data_kernel, dim3(grid_for(total)), dim3(256), (size_t)Cout * C * sizeof(float),
                        (hipStream_t)stream, gz, w, gimg, N, C, H, W, Cout, pool, accumulate, scale);
     return (int)hipGetLastError();
@@ -380,7 +469,7 @@ extern "C" int pg_fromrgb_wgrad(const float* gz, const float* img, float* dw, fl
         else hipLaunchKernelGGL(fromrgb_wgrad_small_kernel<32>, dim3(g), dim3(256), 0, s, gz, img, dw, db, N, C, H, W, pool, scale);
         return (int)hipGetLastError();
     }
-    int blocks = grid_for(total, 64, 1024);
+    int blocks = grid_for(total, 4, 1024);        // >= 4 pixels per workgroup: the 4x4 / 8x8 stages still fill the chip
     const int ppb = (int)((total + blocks - 1) / blocks);
     blocks = (int)((total + ppb - 1) / ppb);
     hipLaunchKernelGGL(fromrgb_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -396,6 +485,11 @@ extern "C" int pg_torgb_fwd(const float* x, const float* w, const float* bias, c
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cin & 3) return PG_E_ALIGN;
     const size_t total = (size_t)N * H * W;
+    if (Cin >= 256 && total <= 65536) {
+        hipLaunchKernelGGL(torgb_fwd_wide_kernel, dim3(grid_for(total, 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                           x, w, bias, prev, out, N, C, H, W, Cin, scale, out_mul, prev_mul);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(torgb_fwd_kernel, dim3(grid_for(total, 256, 256 * 8)), dim3(256), (size_t)C * Cin * sizeof(float),
                        (hipStream_t)stream, x, w, bias, prev, out, N, C, H, W, Cin, scale, out_mul, prev_mul);
     return (int)hipGetLastError();
@@ -421,7 +515,7 @@ extern "C" int pg_torgb_wgrad(const float* g, const float* x, float* dw, float* 
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cin & 3) return PG_E_ALIGN;
     const size_t total = (size_t)N * H * W;
-    int blocks = grid_for(total, 64, 1024);
+    int blocks = grid_for(total, 4, 1024);
     const int ppb = (int)((total + blocks - 1) / blocks);
     blocks = (int)((total + ppb - 1) / ppb);
     hipLaunchKernelGGL(torgb_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,

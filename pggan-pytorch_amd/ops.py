@@ -141,10 +141,13 @@ def pixelnorm_lrelu_bwd(gy, y, r, slope, inplace=False):
 
 
 # -------------------------------------------------------------------------------------- mbstd
+MBSTD_STATS_STRIDE = 136        # PG_MBSTD_STATS_STRIDE (include/pggan_hip.h): [mu, sigma, reduction workspace]
+
+
 def mbstd_fwd(x, groups, cp):
     NB, H, W, C = x.shape
     y = torch.empty((NB, H, W, cp), device=x.device, dtype=torch.float32)
-    stats = torch.empty((groups, 2), device=x.device, dtype=torch.float32)
+    stats = torch.empty((groups, MBSTD_STATS_STRIDE), device=x.device, dtype=torch.float32)
     _lib.call('pg_mbstd_fwd', _p(x), _p(y), _p(stats), groups, NB // groups, H * W, C, cp, _stream())
     return y, stats
 
@@ -153,7 +156,7 @@ def mbstd_tangent(x, tx, stats, cp):
     NB, H, W, C = x.shape
     groups = stats.shape[0]
     ty = torch.empty((NB, H, W, cp), device=x.device, dtype=torch.float32)
-    tstats = torch.empty((groups, 2), device=x.device, dtype=torch.float32)
+    tstats = torch.empty((groups, MBSTD_STATS_STRIDE), device=x.device, dtype=torch.float32)
     _lib.call('pg_mbstd_tangent', _p(x), _p(tx), _p(stats), _p(ty), _p(tstats), groups, NB // groups, H * W, C, cp, _stream())
     return ty, tstats
 

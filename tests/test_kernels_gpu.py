@@ -37,7 +37,8 @@ CONV_CASES = [
     (5, 4, 32, 16, 3, 1, 0), (3, 4, 48, 64, 3, 1, 0), (7, 4, 16, 16, 4, 0, 0), (48, 4, 64, 64, 4, 0, 0),
     (6, 1, 16, 32, 4, 3, 0), (20, 1, 64, 64, 4, 3, 0), (2, 16, 32, 32, 1, 0, 0), (2, 16, 16, 16, 3, 1, 1),
     (3, 8, 64, 32, 3, 1, 1), (3, 8, 528, 512, 3, 1, 0), (1, 256, 8, 8, 3, 1, 0), (2, 128, 16, 32, 3, 1, 1),
-    (70, 1, 32, 32, 4, 3, 0), (130, 4, 16, 16, 4, 0, 0),
+    (70, 1, 32, 32, 4, 3, 0), (130, 4, 16, 16, 4, 0, 0), (16, 1, 512, 512, 4, 3, 0), (48, 4, 512, 512, 4, 0, 0),
+    (33, 1, 128, 48, 4, 3, 0), (9, 4, 80, 32, 4, 0, 0),
 ]
 
 
@@ -101,7 +102,7 @@ def test_dgrad_is_adjoint_of_conv():
 
 
 RGB_CASES = [(2, 3, 16, 16), (3, 1, 8, 32), (2, 3, 4, 512), (1, 3, 64, 8), (2, 4, 8, 12), (1, 3, 256, 8), (2, 3, 256, 16),
-             (1, 1, 256, 32)]
+             (1, 1, 256, 32), (16, 3, 4, 512), (5, 1, 8, 256), (3, 4, 16, 512)]
 
 
 @pytest.mark.parametrize('N,C,H,co', RGB_CASES)
@@ -186,12 +187,12 @@ def test_mbstd(G, n, C):
     y, st = ops.mbstd_fwd(dev(x), G, cp)
     ry, rst = E.mbstd_fwd(x, G, cp)
     check('mbstd fwd', y, ry)
-    check('mbstd stats', st, rst)
+    check('mbstd stats', st[:, :2], rst)
     tx = rnd(G * n, 4, 4, C, seed=1)
     ty, ts = ops.mbstd_tangent(dev(x), dev(tx), st, cp)
     rty, rts = E.mbstd_tangent(x, tx, rst, cp)
     check('mbstd tangent', ty, rty)
-    check('mbstd tstats', ts, rts, 1e-4)
+    check('mbstd tstats', ts[:, :2], rts, 1e-4)
     gy, gf = rnd(G * n, 4, 4, cp, seed=2), rnd(G * n, 4, 4, cp, seed=3)
     for am in (False, True):
         check('mbstd bwd mask=%s' % am, ops.mbstd_bwd(dev(gy), dev(x), st, cp, am, 0.2), E.mbstd_bwd(gy, x, rst, cp, am, 0.2))
