@@ -291,8 +291,8 @@ def main():
         for d in range(0, 9):
             m = REF_MINIBATCH.get(d, 16)
             t = make_trainer(pg, 1024, d, 1.0, m, 1337, None)
-            k = 20 if d <= 5 else (8 if d <= 7 else 5)
-            tt = timed_steps(t, k, 3, None)
+            k = 100 if d <= 1 else (40 if d <= 3 else (20 if d <= 5 else (8 if d <= 7 else 5)))
+            tt = timed_steps(t, k, 5 if d <= 3 else 3, None)
             dms = d_step_ms(t, k)
             Wd = 18 * F_D[d] * 1e9
             per.append({'depth': d, 'res': 4 * 2 ** d, 'minibatch': m, 'images_per_sec': m * k / tt,
