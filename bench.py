@@ -45,10 +45,9 @@ def conv_flops(n, hout, wout, ks, pad, c_a, c_b):
 
 class KernelTimer(object):
     """HIP-event timing of every MFMA conv launch of a step, recorded around the C-ABI call on the stream the
-    kernel is launched on.  The instrumented passes run with the second (weight-gradient) stream switched off:
-    two kernels sharing the CUs would each see an inflated duration (and HIP event pairs on a stream that is
-    released by a cross-stream wait under-report), so per-kernel roofline numbers are taken serially; the
-    headline ``value`` is measured separately with both streams on."""
+    kernel is launched on (weight gradients run on the second stream, so wrapping happens at ``ops`` level, inside
+    the stream context).  The durations are the ones inside the two-stream step — what rocprofv3 --kernel-trace
+    reports for the same command; ``--serial-kernel-timing`` switches the second stream off for isolated numbers."""
 
     def __init__(self, pg):
         self.pg, self.rec, self.saved = pg, [], {}
@@ -207,6 +206,8 @@ def main():
     ap.add_argument('--no-per-depth', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--graphs', action='store_true', help='replay the step from captured hipGraphs (graphs.py); default is\n                    eager two-stream launching, which measured faster at every growth stage')
+    ap.add_argument('--serial-kernel-timing', action='store_true', help='instrumented passes with the weight-gradient stream off '
+                    '(isolated per-kernel durations instead of the durations inside the two-stream step)')
     ap.add_argument('--kernel-table', action='store_true', help='per-layer conv timing table on stderr')
     args = ap.parse_args()
 
@@ -250,7 +251,9 @@ def main():
     if rank == 0 and not args.no_kernel_timing:
         psteps = 3
         pg.wgan_gp_loss.enable_graphs(False)               # per-launch HIP events need eager launches
-        async_wgrad, pg.engine.ASYNC_WGRAD = pg.engine.ASYNC_WGRAD, False
+        async_wgrad = pg.engine.ASYNC_WGRAD
+        if args.serial_kernel_timing:
+            pg.engine.ASYNC_WGRAD = False
         try:
             with KernelTimer(pg) as kt:
                 for _ in range(psteps):
