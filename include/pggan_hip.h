@@ -143,6 +143,18 @@ int pg_pixelnorm_fwd(const float* x, float* y, float* r, int64_t P, int C, float
 int pg_pixelnorm_lrelu_bwd(const float* gy, const float* y, const float* r, float* gz,
                            int64_t P, int C, float slope, pg_stream_t stream);
 
+/* Discriminator(pixelnorm=True) (network.py:191-198 flag) under the gradient penalty: PixelNorm is not
+ * piecewise linear, so the double backward of wgan_gp_loss.py:25-31 gets a Hessian-vector term per layer.
+ * With P(h) = r (I - y y^T / C) (Jacobian == adjoint of y = h*r(h)), t the tangent at the PixelNorm input and
+ * a the FIRST-backward adjoint at the PixelNorm output:
+ *   ty  = P t;    inj = grad_h <t, P(h) a> = -(r^2 S / C) y - (r / C) P[(a.y) t + (t.y) a],  S = t.a - (t.y)(a.y)/C
+ * `inj` is added to the adjoint of the PixelNorm input in the ordinary backward of the mixed samples:
+ *   gz = (r * (gy - y * mean_c(gy*y)) + inj) * (y>0 ? 1 : slope)                                   */
+int pg_pixelnorm_tangent(const float* t, const float* y, const float* r, const float* a, float* ty, float* inj,
+                         int64_t P, int C, pg_stream_t stream);
+int pg_pixelnorm_lrelu_bwd_inj(const float* gy, const float* y, const float* r, const float* inj, float* gz,
+                               int64_t P, int C, float slope, pg_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Minibatch stddev (network.py:174-187): ONE scalar per group over the whole [n,H,W,C] tensor.
  * x: [NB][HW][C]   y: [NB][HW][CP] (CP >= C+1, CP % 4 == 0; channels > C are zero-filled)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PgganLibraryError(RuntimeError):
@@ -41,6 +41,8 @@ SIGNATURES = {
     'pg_axpby_mask': [P, P, P, P, L, F, F, F, P],
     'pg_pixelnorm_fwd': [P, P, P, L, I, F, P],
     'pg_pixelnorm_lrelu_bwd': [P, P, P, P, L, I, F, P],
+    'pg_pixelnorm_tangent': [P, P, P, P, P, P, L, I, P],
+    'pg_pixelnorm_lrelu_bwd_inj': [P, P, P, P, P, L, I, F, P],
     'pg_mbstd_fwd': [P, P, P, I, I, I, I, I, P],
     'pg_mbstd_tangent': [P, P, P, P, P, I, I, I, I, I, P],
     'pg_mbstd_bwd': [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],

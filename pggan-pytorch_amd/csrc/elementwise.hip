@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
 
 template <int LPP>
 __global__ __launch_bounds__(256) void pixelnorm_lrelu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                                  const float* __restrict__ r, float* __restrict__ gz,
-                                                                  size_t P, int C, float slope)
+                                                                  const float* __restrict__ r, const float* __restrict__ inj,
+                                                                  float* __restrict__ gz, size_t P, int C, float slope)
 {
     const int C4 = C >> 2;
     const int sub = threadIdx.x % LPP;
@@ -182,14 +182,64 @@ __global__ __launch_bounds__(256) void pixelnorm_lrelu_bwd_kernel(const float* _
         const float rr = r ? r[pix] : 1.f;
         const float mean = r ? s / (float)C : 0.f;
         float4* op = reinterpret_cast<float4*>(gz + pix * C);
+        const float4* ip = inj ? reinterpret_cast<const float4*>(inj + pix * C) : nullptr;
         for (int c = sub; c < C4; c += LPP) {
             const float4 g = gp[c], v = yp[c];
             float4 o;
-            o.x = rr * (g.x - v.x * mean) * (v.x > 0.f ? 1.f : slope);
-            o.y = rr * (g.y - v.y * mean) * (v.y > 0.f ? 1.f : slope);
-            o.z = rr * (g.z - v.z * mean) * (v.z > 0.f ? 1.f : slope);
-            o.w = rr * (g.w - v.w * mean) * (v.w > 0.f ? 1.f : slope);
+            o.x = rr * (g.x - v.x * mean); o.y = rr * (g.y - v.y * mean);
+            o.z = rr * (g.z - v.z * mean); o.w = rr * (g.w - v.w * mean);
+            if (ip) { const float4 j = ip[c]; o.x += j.x; o.y += j.y; o.z += j.z; o.w += j.w; }
+            o.x *= v.x > 0.f ? 1.f : slope; o.y *= v.y > 0.f ? 1.f : slope;
+            o.z *= v.z > 0.f ? 1.f : slope; o.w *= v.w > 0.f ? 1.f : slope;
             op[c] = o;
+        }
+    }
+}
+
+// Second-order companion of PixelNorm for the gradient penalty (Discriminator(pixelnorm=True)):
+// with P(h) = r (I - y y^T / C) the Jacobian (== adjoint) of y = h * r(h):
+//   ty  = P t                                                   tangent through the layer
+//   inj = grad_h < t, P(h) a >  =  -(r^2 S / C) y - (r / C) P[(a.y) t + (t.y) a],   S = t.a - (t.y)(a.y)/C
+// t: tangent at the PixelNorm input, a: first-backward adjoint at the PixelNorm output, y/r: saved forward.
+template <int LPP>
+__global__ __launch_bounds__(256) void pixelnorm_tangent_kernel(const float* __restrict__ t, const float* __restrict__ y,
+                                                                const float* __restrict__ r, const float* __restrict__ a,
+                                                                float* __restrict__ ty, float* __restrict__ inj,
+                                                                size_t P, int C)
+{
+    const int C4 = C >> 2;
+    const int sub = threadIdx.x % LPP;
+    const size_t pstride = (size_t)gridDim.x * (256 / LPP);
+    const float invC = 1.f / (float)C;
+    for (size_t pix = (size_t)blockIdx.x * (256 / LPP) + threadIdx.x / LPP; pix < P; pix += pstride) {
+        const float4* tp = reinterpret_cast<const float4*>(t + pix * C);
+        const float4* yp = reinterpret_cast<const float4*>(y + pix * C);
+        const float4* ap = reinterpret_cast<const float4*>(a + pix * C);
+        float ty_ = 0.f, ay_ = 0.f, ta_ = 0.f;
+        for (int c = sub; c < C4; c += LPP) {
+            const float4 tv = tp[c], yv = yp[c], av = ap[c];
+            ty_ += tv.x * yv.x + tv.y * yv.y + tv.z * yv.z + tv.w * yv.w;
+            ay_ += av.x * yv.x + av.y * yv.y + av.z * yv.z + av.w * yv.w;
+            ta_ += tv.x * av.x + tv.y * av.y + tv.z * av.z + tv.w * av.w;
+        }
+        ty_ = group_sum<LPP>(ty_); ay_ = group_sum<LPP>(ay_); ta_ = group_sum<LPP>(ta_);
+        const float rr = r[pix];
+        const float S = ta_ - ty_ * ay_ * invC;
+        const float k_y = -(rr * rr * S * invC);            // coefficient of y from the d r term
+        const float yv_dot = 2.f * ay_ * ty_;                // y . [(a.y) t + (t.y) a]
+        const float kp = -(rr * invC) * rr;                  // -(r/C) * r  (outer r of P)
+        float4* typ = reinterpret_cast<float4*>(ty + pix * C);
+        float4* ip = reinterpret_cast<float4*>(inj + pix * C);
+        for (int c = sub; c < C4; c += LPP) {
+            const float4 tv = tp[c], yv = yp[c], av = ap[c];
+            float4 o, j;
+            o.x = rr * (tv.x - yv.x * ty_ * invC); o.y = rr * (tv.y - yv.y * ty_ * invC);
+            o.z = rr * (tv.z - yv.z * ty_ * invC); o.w = rr * (tv.w - yv.w * ty_ * invC);
+            j.x = k_y * yv.x + kp * (ay_ * tv.x + ty_ * av.x - yv.x * yv_dot * invC);
+            j.y = k_y * yv.y + kp * (ay_ * tv.y + ty_ * av.y - yv.y * yv_dot * invC);
+            j.z = k_y * yv.z + kp * (ay_ * tv.z + ty_ * av.z - yv.z * yv_dot * invC);
+            j.w = k_y * yv.w + kp * (ay_ * tv.w + ty_ * av.w - yv.w * yv_dot * invC);
+            typ[c] = o; ip[c] = j;
         }
     }
 }
@@ -515,7 +565,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__); \
     return (int)hipGetLastError()
 
-extern "C" int pg_abi_version(void) { return 5; }
+extern "C" int pg_abi_version(void) { return 6; }
 
 extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
                                float a, float b, pg_stream_t stream)
@@ -572,7 +622,39 @@ extern "C" int pg_pixelnorm_lrelu_bwd(const float* gy, const float* y, const flo
     const int grid = grid_for((size_t)P * lpp);
     hipStream_t s = (hipStream_t)stream;
     switch (lpp) {
-#define CASE(L) case L: hipLaunchKernelGGL(pixelnorm_lrelu_bwd_kernel<L>, dim3(grid), dim3(256), 0, s, gy, y, r, gz, (size_t)P, C, slope); break;
+#define CASE(L) case L: hipLaunchKernelGGL(pixelnorm_lrelu_bwd_kernel<L>, dim3(grid), dim3(256), 0, s, gy, y, r, (const float*)nullptr, gz, (size_t)P, C, slope); break;
+        CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
+#undef CASE
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_pixelnorm_lrelu_bwd_inj(const float* gy, const float* y, const float* r, const float* inj, float* gz,
+                                          int64_t P, int C, float slope, pg_stream_t stream)
+{
+    if (!gy || !y || !r || !inj || !gz || P <= 0 || C <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    const int lpp = pick_lpp(C);
+    const int grid = grid_for((size_t)P * lpp);
+    hipStream_t s = (hipStream_t)stream;
+    switch (lpp) {
+#define CASE(L) case L: hipLaunchKernelGGL(pixelnorm_lrelu_bwd_kernel<L>, dim3(grid), dim3(256), 0, s, gy, y, r, inj, gz, (size_t)P, C, slope); break;
+        CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
+#undef CASE
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_pixelnorm_tangent(const float* t, const float* y, const float* r, const float* a, float* ty, float* inj,
+                                    int64_t P, int C, pg_stream_t stream)
+{
+    if (!t || !y || !r || !a || !ty || !inj || P <= 0 || C <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    const int lpp = pick_lpp(C);
+    const int grid = grid_for((size_t)P * lpp);
+    hipStream_t s = (hipStream_t)stream;
+    switch (lpp) {
+#define CASE(L) case L: hipLaunchKernelGGL(pixelnorm_tangent_kernel<L>, dim3(grid), dim3(256), 0, s, t, y, r, a, ty, inj, (size_t)P, C); break;
         CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
 #undef CASE
     }

@@ -237,6 +237,7 @@ def d_forward(D, x, groups=1):
     nb = len(D.blocks)
     e = nb - 1 - depth                                                        # blocks[-(depth+1)]  (:227)
     ctx = dict(NB=NB, groups=groups, depth=depth, alpha=alpha, x=x, recs=[])
+    pn = bool(getattr(D, 'pixelnorm', False))
     fr = D.blocks[e].fromRGB
     cur = ops.fromrgb_fwd(x, fr.conv.weight.data, fr.conv.bias.data, NB, C, r, r, fr.c, fr.slope)
     H = r
@@ -248,11 +249,19 @@ def d_forward(D, x, groups=1):
         if last:
             mb, stats = ops.mbstd_fwd(cur, groups, blk.c1.cin_store)          # :168
             a1 = _conv(mb, blk.c1, NB, H)
+            if pn:
+                a1, rec['r1'] = ops.pixelnorm_fwd(a1, inplace=True)
             a2 = _conv(a1, blk.c2, NB, H)                                     # 4x4 pad 0 -> 1x1
+            if pn:
+                a2, rec['r2'] = ops.pixelnorm_fwd(a2, inplace=True)
             rec.update(mb=mb, stats=stats, a1=a1, a2=a2)
         else:
             a1 = _conv(cur, blk.c1, NB, H)
+            if pn:                                                            # a1/a2 hold the NORMALISED outputs
+                a1, rec['r1'] = ops.pixelnorm_fwd(a1, inplace=True)
             a2 = _conv(a1, blk.c2, NB, H)
+            if pn:
+                a2, rec['r2'] = ops.pixelnorm_fwd(a2, inplace=True)
             rec.update(a1=a1, a2=a2)
             if k == 0 and alpha < 1.0:                                        # :230-233
                 nfr = D.blocks[j + 1].fromRGB
@@ -276,6 +285,10 @@ def _slice_ctx(ctx, a, b, g0, g1):
         for k in ('inp', 'a1', 'a2', 'mb', 'pf'):
             if k in rec:
                 r2[k] = rec[k][a:b]
+        for k in ('r1', 'r2'):                       # PixelNorm scales, one per pixel: [NB*h*w]
+            if k in rec:
+                per = rec[k].numel() // ctx['NB']
+                r2[k] = rec[k][a * per:b * per]
         if 'stats' in rec:
             r2['stats'] = rec['stats'][g0:g1]
         sub['recs'].append(r2)
@@ -290,6 +303,8 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
     hvp         : (n_head, tx, tstats, gy_first) — the last ``NB-n_head`` images form one extra group
                   whose score gradient is zero and which only receives the minibatch-stddev
                   Hessian-vector injection; ``gscore`` then has n_head entries."""
+    if getattr(D, 'pixelnorm', False):
+        return _d_backward_pn(D, ctx, gscore, full, want_gimg, save_adjoints, hvp)
     D._ensure_buffers()
     NB, alpha = ctx['NB'], ctx['alpha']
     x = ctx['x']
@@ -374,6 +389,114 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
     return gimg, adj
 
 
+def _pn_bwd(gy, y, r, slope, nh, inj):
+    """(LeakyReLU -> PixelNorm) adjoint on a batch whose images [nh:] additionally receive the
+    gradient-penalty Hessian-vector injection ``inj`` (None: plain adjoint on the whole batch)."""
+    if inj is None:
+        return ops.pixelnorm_lrelu_bwd(gy, y, r, slope, inplace=True)
+    per = r.numel() // y.shape[0]
+    if nh > 0:
+        ops.pixelnorm_lrelu_bwd(gy[:nh], y[:nh], r[:nh * per], slope, inplace=True)
+    ops.pixelnorm_lrelu_bwd(gy[nh:], y[nh:], r[nh * per:], slope, inj=inj, out=gy[nh:])
+    return gy
+
+
+def _d_backward_pn(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
+    """``d_backward`` for Discriminator(pixelnorm=True): every c1/c2 is conv -> LeakyReLU -> PixelNorm
+    (network.py:32-41), so the masks can no longer be fused into the backward-data convs; the adjoint of each
+    (LeakyReLU, PixelNorm) pair is one ``pixelnorm_lrelu_bwd`` launch.  With ``hvp`` the mixed images [nh:]
+    take the minibatch-stddev AND the per-layer PixelNorm Hessian-vector injections (hvp[4] = list of dicts)."""
+    D._ensure_buffers()
+    NB, alpha = ctx['NB'], ctx['alpha']
+    x = ctx['x']
+    C = D.num_channels
+    recs = ctx['recs']
+    adj = [dict() for _ in recs]
+    lastrec = recs[-1]
+    nh = NB if hvp is None else hvp[0]
+    injs = None if hvp is None else hvp[4]
+    a2 = lastrec['a2']
+    gtop = ops.linear1_bwd_data(gscore, D.linear.weight.data, None, (nh,) + tuple(a2.shape[1:]))
+    if nh < NB:                                      # mixed images: zero score gradient, injections only
+        g = torch.zeros_like(a2)
+        g[:nh].copy_(gtop)
+    else:
+        g = gtop
+    if full:
+        ops.linear1_wgrad(gscore, a2[:nh], D._lin_gw, D._lin_gb)
+    gimg = None
+    pending_prev = None
+    for idx in range(len(recs) - 1, -1, -1):
+        rec = recs[idx]
+        blk, H = rec['blk'], rec['H']
+        c1, c2 = blk.c1, blk.c2
+        fr_slope = blk.fromRGB.slope
+        inj = injs[idx] if injs is not None else {}
+        if save_adjoints:
+            adj[idx]['gy2'] = g.clone()
+        gz2 = _pn_bwd(g, rec['a2'], rec['r2'], c2.slope, nh, inj.get('inj2'))
+        Hc2 = 1 if rec['last'] else H
+        if full:
+            _wgrad(rec['a1'], gz2, c2, NB, H)
+        gy1 = _dgrad(D, gz2, c2, NB, Hc2)
+        if save_adjoints:
+            adj[idx]['gy1'] = gy1.clone()
+        gz1 = _pn_bwd(gy1, rec['a1'], rec['r1'], c1.slope, nh, inj.get('inj1'))
+        if rec['last']:
+            mb, inp = rec['mb'], rec['inp']
+            if full:
+                _wgrad(mb, gz1, c1, NB, H)
+            gmb = _dgrad(D, gz1, c1, NB, H)                                   # [NB,4,4,CP]
+            cp = c1.cin_store
+            if hvp is None:
+                gin = ops.mbstd_bwd(gmb, inp, rec['stats'], cp, rec['first'], fr_slope)
+            else:
+                _, tx, tstats, gy_first = hvp[:4]
+                gin = torch.empty_like(inp)
+                ng = rec['stats'].shape[0] - 1
+                ops.mbstd_bwd(gmb[:nh], inp[:nh], rec['stats'][:ng], cp, rec['first'], fr_slope, out=gin[:nh])
+                ops.mbstd_bwd(gmb[nh:], inp[nh:], rec['stats'][ng:], cp, rec['first'], fr_slope,
+                              tx=tx, tstats=tstats, gy_first=gy_first, out=gin[nh:])
+            if save_adjoints:
+                adj[idx].update(gz2=gz2, gz1=gz1, gmb=gmb)
+        else:
+            if full:
+                _wgrad(rec['inp'], gz1, c1, NB, H)
+            gin = _dgrad(D, gz1, c1, NB, H, mask=rec['inp'] if rec['first'] else None, mask_slope=fr_slope)
+            if save_adjoints:
+                adj[idx].update(gz2=gz2, gz1=gz1)
+        if rec['first']:
+            gf = gin
+            fr = blk.fromRGB
+            if save_adjoints:
+                adj[idx]['gf'] = gf
+            if full:
+                with _on_side(gf, x):
+                    ops.fromrgb_wgrad(gf, x, fr._gw, fr._gb, NB, C, H, H, fr.c)
+            if want_gimg:
+                gimg = torch.empty_like(x)
+                ops.fromrgb_bwd_data(gf, fr.conv.weight.data, gimg, NB, C, H, H, fr.c)
+                if pending_prev is not None:
+                    gpf, pfr = pending_prev
+                    ops.fromrgb_bwd_data(gpf, pfr.conv.weight.data, gimg, NB, C, H // 2, H // 2, pfr.c,
+                                         pool=True, accumulate=True)
+        else:
+            prev = recs[idx - 1]
+            if prev['first'] and alpha < 1.0:
+                g = ops.avgpool2_bwd(gin, None, alpha)                        # adjoint wrt the NORMALISED a2
+                pfr = blk.fromRGB
+                gpf = ops.axpby_mask(gin, mask=prev['pf'], a=1.0 - alpha, mask_slope=pfr.slope)
+                if save_adjoints:
+                    adj[idx - 1]['gpf'] = gpf
+                if full:
+                    with _on_side(gpf, x):
+                        ops.fromrgb_wgrad(gpf, x, pfr._gw, pfr._gb, NB, C, H, H, pfr.c, pool=True)
+                pending_prev = (gpf, pfr)
+            else:
+                g = ops.avgpool2_bwd(gin, None, 1.0)
+    return gimg, adj
+
+
 def d_tangent_wgrad(D, sub, adj, u):
     """Gradient-penalty second-order term, steps (i)+(ii): push the seed ``u`` (NCHW, same shape as the
     mixed batch) through the masked linear maps of D and accumulate, per layer,
@@ -390,6 +513,8 @@ def d_tangent_wgrad(D, sub, adj, u):
     cur = ops.fromrgb_fwd(u, fr.conv.weight.data, None, N, C, H, H, fr.c, 1.0, mask=rec0['inp'], mask_slope=fr.slope)
     hvp = None
     t2 = None
+    pn = bool(getattr(D, 'pixelnorm', False))
+    injs = [dict() for _ in recs] if pn else None
     for idx, rec in enumerate(recs):
         blk, H = rec['blk'], rec['H']
         c1, c2 = blk.c1, blk.c2
@@ -398,13 +523,21 @@ def d_tangent_wgrad(D, sub, adj, u):
             hvp = (cur, tstats, adj[idx]['gmb'])
             _wgrad(tmb, adj[idx]['gz1'], c1, N, H, bias=False)
             t1 = _conv(tmb, c1, N, H, mask=rec['a1'], bias=False)
+            if pn:
+                t1, injs[idx]['inj1'] = ops.pixelnorm_tangent(t1, rec['a1'], rec['r1'], adj[idx]['gy1'])
             _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False)
             t2 = _conv(t1, c2, N, H, mask=rec['a2'], bias=False)
+            if pn:
+                t2, injs[idx]['inj2'] = ops.pixelnorm_tangent(t2, rec['a2'], rec['r2'], adj[idx]['gy2'])
         else:
             _wgrad(cur, adj[idx]['gz1'], c1, N, H, bias=False)
             t1 = _conv(cur, c1, N, H, mask=rec['a1'], bias=False)
+            if pn:
+                t1, injs[idx]['inj1'] = ops.pixelnorm_tangent(t1, rec['a1'], rec['r1'], adj[idx]['gy1'])
             _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False)
             t2 = _conv(t1, c2, N, H, mask=rec['a2'], bias=False)
+            if pn:
+                t2, injs[idx]['inj2'] = ops.pixelnorm_tangent(t2, rec['a2'], rec['r2'], adj[idx]['gy2'])
             if rec['first'] and alpha < 1.0:
                 nfr = recs[idx + 1]['blk'].fromRGB
                 with _on_side(adj[idx]['gpf'], u):
@@ -416,7 +549,7 @@ def d_tangent_wgrad(D, sub, adj, u):
                 cur = ops.avgpool2_fwd(t2)
     # Linear: d/dw <ones, w . t2> = sum_n t2[n]
     ops.linear1_wgrad(_ones(N, u.device), t2, D._lin_gw, None)
-    return hvp
+    return hvp + (injs,) if pn else hvp
 
 
 def d_active_params(D, depth, alpha):

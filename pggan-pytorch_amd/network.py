@@ -344,9 +344,7 @@ class Discriminator(_FlatParamsMixin, nn.Module):
         R = int(np.log2(resolution))
         assert resolution == 2 ** R and resolution >= 4
         self.R = R
-        if pixelnorm:
-            raise NotImplementedError('Discriminator(pixelnorm=True) needs the PixelNorm double-backward, '
-                                      'which is outside the accelerated path (SURVEY.md §8f row 4)')
+        self.pixelnorm = bool(pixelnorm)    # engine: PixelNorm after c1/c2 + its gradient-penalty Hessian-vector terms
 
         def nf(stage):
             return min(int(fmap_base / (2.0 ** (stage * fmap_decay))), fmap_max)

@@ -132,12 +132,24 @@ def pixelnorm_fwd(x, eps=1e-8, inplace=False):
     return y, r
 
 
-def pixelnorm_lrelu_bwd(gy, y, r, slope, inplace=False):
+def pixelnorm_lrelu_bwd(gy, y, r, slope, inplace=False, inj=None, out=None):
     C = y.shape[-1]
     P = y.numel() // C
-    gz = gy if inplace else torch.empty_like(gy)
-    _lib.call('pg_pixelnorm_lrelu_bwd', _p(gy), _p(y), _p(r), _p(gz), P, C, slope, _stream())
+    gz = out if out is not None else (gy if inplace else torch.empty_like(gy))
+    if inj is None:
+        _lib.call('pg_pixelnorm_lrelu_bwd', _p(gy), _p(y), _p(r), _p(gz), P, C, slope, _stream())
+    else:
+        _lib.call('pg_pixelnorm_lrelu_bwd_inj', _p(gy), _p(y), _p(r), _p(inj), _p(gz), P, C, slope, _stream())
     return gz
+
+
+def pixelnorm_tangent(t, y, r, a):
+    """(ty, inj) of pg_pixelnorm_tangent: tangent through PixelNorm and its Hessian-vector injection."""
+    C = y.shape[-1]
+    P = y.numel() // C
+    ty, inj = torch.empty_like(t), torch.empty_like(t)
+    _lib.call('pg_pixelnorm_tangent', _p(t), _p(y), _p(r), _p(a), _p(ty), _p(inj), P, C, _stream())
+    return ty, inj
 
 
 # -------------------------------------------------------------------------------------- mbstd

@@ -164,17 +164,34 @@ def pixelnorm_fwd(x, eps=1e-8, inplace=False):
     return y, r.reshape(-1)
 
 
-def pixelnorm_lrelu_bwd(gy, y, r, slope, inplace=False):
+def pixelnorm_lrelu_bwd(gy, y, r, slope, inplace=False, inj=None, out=None):
     if r is not None:
         rr = r.view(y.shape[:-1]).unsqueeze(-1)
         gh = rr * (gy - y * (gy * y).mean(dim=-1, keepdim=True))
     else:
         gh = gy
+    if inj is not None:
+        gh = gh + inj
     gz = _maskmul(gh, y, slope)
+    if out is not None:
+        out.copy_(gz)
+        return out
     if inplace:
         gy.copy_(gz)
         return gy
     return gz
+
+
+def pixelnorm_tangent(t, y, r, a):
+    C = y.shape[-1]
+    rr = r.view(y.shape[:-1]).unsqueeze(-1)
+    ty_, ay_, ta_ = [(u * v).sum(dim=-1, keepdim=True) for u, v in ((t, y), (a, y), (t, a))]
+
+    def proj(v):
+        return rr * (v - y * (y * v).sum(dim=-1, keepdim=True) / C)
+    S = ta_ - ty_ * ay_ / C
+    inj = -(rr * rr * S / C) * y - (rr / C) * proj(ay_ * t + ty_ * a)
+    return proj(t), inj
 
 
 def mbstd_fwd(x, groups, cp):
