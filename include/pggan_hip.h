@@ -222,6 +222,12 @@ int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, f
 int pg_real_prepare_u8(const uint8_t* in, float* out, int64_t planes, int H, int W, double alpha,
                        double min_in, double max_in, double min_out, double max_out, pg_stream_t stream);
 
+/* One level of the multi-depth image pyramid: replaces DefaultImageFolderDataset.create_datapoint_from_depth
+ * dataset.py:243-250 for a uint8 batch: out[y][x] = uint8(clip(rint(mean of in[y*s + {0,1}][x*s + {0,1}]), min_in, max_in)),
+ * s = 2^depthdiff (the reference's sampling: a 2x2 box for depthdiff 1).  in [planes][H][W] -> out [planes][H/s][W/s]. */
+int pg_pyramid_level_u8(const uint8_t* in, uint8_t* out, int64_t planes, int H, int W, int depthdiff,
+                        float min_in, float max_in, pg_stream_t stream);
+
 /* Sample output: replaces ImageSaver.__call__ output_postprocess.py:35-62 up to the PIL hand-off: nearest
  * upsample by `up` (utils.py:33-53), tiled grid of ceil(sqrt(n)) columns, CHW->HWC, range (min_in,max_in)->(0,255)
  * in fp32, round-half-even, clip, uint8.  grid: [grid_h*h*up][grid_w*w*up][C].                                  */

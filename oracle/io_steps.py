@@ -54,3 +54,17 @@ def image_grid_u8(images, drange=(-1, 1), resolution=None):
     image = grid[0] if channels == 1 else grid.transpose(1, 2, 0)                    # :51-56
     image = adjust_dynamic_range(image, drange, (0, 255))                            # :58
     return image.round().clip(0, 255).astype(np.uint8)                               # :60
+
+
+def create_datapoint_from_depth(datapoint, depthdiff, range_in=(0, 255), scale_factor=2):
+    """reference dataset.py:243-250: one level of the multi-depth pyramid from a uint8 image [C,H,W].  The
+    reference adds the scale_factor^2 sub-grids taken with stride scale_factor**depthdiff (a 2x2 box mean for
+    depthdiff 1, a 4-sample subsampling for larger differences), divides, rounds half-to-even, clips, uint8."""
+    d = datapoint.astype(np.float32)
+    st = scale_factor ** depthdiff
+    acc = 0
+    for a in range(scale_factor):
+        for b in range(scale_factor):
+            acc = acc + d[:, a::st, b::st]
+    acc = acc / (scale_factor ** 2)
+    return np.uint8(np.clip(np.round(acc), range_in[0], range_in[1]))

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class PgganLibraryError(RuntimeError):
@@ -57,6 +57,7 @@ SIGNATURES = {
     'pg_adam': [P, P, P, P, L, F, F, F, F, F, F, F, P],
     'pg_real_prepare_u8': [P, P, L, I, I, D, D, D, D, D, P],
     'pg_image_grid_u8': [P, P, I, I, I, I, I, F, F, P],
+    'pg_pyramid_level_u8': [P, P, L, I, I, I, F, F, P],
     'pg_zero': [P, L, P],
 }
 

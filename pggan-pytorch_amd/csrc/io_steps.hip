@@ -79,7 +79,38 @@ inline int grid_for(long long total, int block = 256, int cap = 4096)
     return (int)g;
 }
 
+// One pyramid level (dataset.py:243-250): out[y][x] = uint8(clip(rint((p00 + p01 + p10 + p11) / 4))) with the four
+// samples at (y*st + {0,1}, x*st + {0,1}), st = 2^depthdiff.  Sums of four bytes are exact in fp32, /4 is exact,
+// rintf is round-half-even like np.round -> bit-exact.
+__global__ __launch_bounds__(256) void pyramid_level_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                               long long planes, int H, int W, int st, float lo, float hi)
+{
+    const int Ho = H / st, Wo = W / st;
+    const long long total = planes * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        long long r = i / Wo;
+        const int y = (int)(r % Ho); const long long pl = r / Ho;
+        const uint8_t* p = in + (pl * H + (long long)y * st) * W + (long long)x * st;
+        float v = (((float)p[0] + (float)p[1]) + (float)p[W]) + (float)p[W + 1];
+        v = rintf(v * 0.25f);
+        v = fminf(fmaxf(v, lo), hi);
+        out[i] = (uint8_t)v;
+    }
+}
+
 }  // namespace
+
+extern "C" int pg_pyramid_level_u8(const uint8_t* in, uint8_t* out, int64_t planes, int H, int W, int depthdiff,
+                                   float min_in, float max_in, pg_stream_t stream)
+{
+    if (!in || !out || planes <= 0 || H <= 0 || W <= 0 || depthdiff < 1 || depthdiff > 16) return PG_E_ARG;
+    const int st = 1 << depthdiff;
+    if ((H % st) || (W % st)) return PG_E_ALIGN;
+    hipLaunchKernelGGL(pyramid_level_u8_kernel, dim3(grid_for(planes * (H / st) * (W / st))), dim3(256), 0, (hipStream_t)stream,
+                       in, out, (long long)planes, H, W, st, min_in, max_in);
+    return (int)hipGetLastError();
+}
 
 extern "C" int pg_real_prepare_u8(const uint8_t* in, float* out, int64_t planes, int H, int W, double alpha,
                                   double min_in, double max_in, double min_out, double max_out, pg_stream_t stream)

@@ -282,3 +282,17 @@ def image_grid_u8(images, drange=(-1, 1), up=1):
     grid = torch.empty((gh * h * up, gw * w * up, C), device=images.device, dtype=torch.uint8)
     _lib.call('pg_image_grid_u8', _p(images), grid.data_ptr(), n, C, h, w, up, float(drange[0]), float(drange[1]), _stream())
     return grid
+
+
+def pyramid_level_u8(batch_u8, depthdiff, range_in=(0, 255)):
+    """uint8 device batch [..., H, W] -> the pyramid level ``depthdiff`` below it (dataset.py:243-250)."""
+    require_gpu()
+    if batch_u8.dtype != torch.uint8 or not batch_u8.is_cuda:
+        raise RuntimeError('pyramid_level_u8 expects a uint8 tensor on the device')
+    x = batch_u8.contiguous()
+    H, W = x.shape[-2], x.shape[-1]
+    st = 2 ** int(depthdiff)
+    out = torch.empty(tuple(x.shape[:-2]) + (H // st, W // st), device=x.device, dtype=torch.uint8)
+    _lib.call('pg_pyramid_level_u8', x.data_ptr(), out.data_ptr(), x.numel() // (H * W), H, W, int(depthdiff),
+              float(range_in[0]), float(range_in[1]), _stream())
+    return out

@@ -73,6 +73,14 @@ def prepare_real_batch(batch_u8, alpha, range_in=(0, 255), range_out=(-1, 1)):
     return ops.real_prepare_u8(batch_u8, alpha, range_in, range_out)
 
 
+def build_pyramid(batch_u8, max_depth_diff, range_in=(0, 255)):
+    """Device-side multi-depth pyramid of a uint8 batch (DefaultImageFolderDataset.load / create_datapoint_from_depth,
+    dataset.py:205-216,243-250): returns [level 0 (= input), level 1, ...], level d derived from the full-resolution
+    image with depth difference d exactly like the reference does."""
+    from . import ops
+    return [batch_u8] + [ops.pyramid_level_u8(batch_u8, d, range_in) for d in range(1, max_depth_diff + 1)]
+
+
 class DeviceImageSaver(object):
     """Postprocessor with the reference hook signature ``proc(out, description)`` (output_postprocess.py:21-71,
     plugins.py:188-192).  The grid / nearest upsample / range / uint8 conversion runs on the device

@@ -350,6 +350,15 @@ def make_io_steps():
         fx['grid/%s/in' % tag] = imgs
         fx['grid/%s/res' % tag] = np.int64(-1 if res is None else res)
         fx['grid/%s/out' % tag] = np.array(im)
+    # multi-depth pyramid (dataset.py:243-250), incl. the reference's stride-2^diff sampling for depthdiff > 1
+    me = _Self(); me.scale_factor = 2; me.range_in = (0, 255)
+    for tag, shape, diff in (('p1', (3, 16, 16), 1), ('p2', (1, 32, 32), 2), ('p3', (3, 64, 64), 3), ('p1b', (2, 8, 8), 1)):
+        x = rs.randint(0, 256, size=shape).astype(np.uint8)
+        x.reshape(-1)[::5] = np.array([0, 255, 1, 2, 254], dtype=np.uint8)[np.arange(x.size)[::5] % 5]      # .5 ties
+        out = ref_dataset.DefaultImageFolderDataset.create_datapoint_from_depth(me, x, diff, 0)
+        fx['pyr/%s/in' % tag] = x
+        fx['pyr/%s/diff' % tag] = np.int64(diff)
+        fx['pyr/%s/out' % tag] = out
     np.savez_compressed(os.path.join(HERE, 'io_steps.npz'), **fx)
 
 

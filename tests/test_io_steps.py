@@ -25,6 +25,9 @@ def test_oracle_matches_reference_bit_exact():
         res = int(fx['grid/%s/res' % tag])
         out = oio.image_grid_u8(fx['grid/%s/in' % tag], (-1, 1), None if res < 0 else res)
         assert out.dtype == np.uint8 and np.array_equal(out, fx['grid/%s/out' % tag])
+    for tag in ('p1', 'p2', 'p3', 'p1b'):
+        out = oio.create_datapoint_from_depth(fx['pyr/%s/in' % tag], int(fx['pyr/%s/diff' % tag]))
+        assert out.dtype == np.uint8 and np.array_equal(out, fx['pyr/%s/out' % tag])
 
 
 @pytest.mark.gpu
@@ -42,6 +45,15 @@ def test_kernels_match_oracle_bit_exact():
         grid = pg.ops.image_grid_u8(torch.from_numpy(imgs).cuda(), (-1, 1), up).cpu().numpy()
         ref = fx['grid/%s/out' % tag]
         assert np.array_equal(grid.reshape(ref.shape), ref), tag
+    for tag in ('p1', 'p2', 'p3', 'p1b'):
+        x = torch.from_numpy(fx['pyr/%s/in' % tag]).cuda()
+        out = pg.ops.pyramid_level_u8(x, int(fx['pyr/%s/diff' % tag]))
+        assert np.array_equal(out.cpu().numpy(), fx['pyr/%s/out' % tag]), tag
+    big = np.random.RandomState(3).randint(0, 256, size=(2, 3, 1024, 1024)).astype(np.uint8)
+    levels = pg.utils.build_pyramid(torch.from_numpy(big).cuda(), 3)
+    for d in (1, 2, 3):
+        ref = np.stack([oio.create_datapoint_from_depth(im, d) for im in big])
+        assert np.array_equal(levels[d].cpu().numpy(), ref), d
     # full-size property checks against the oracle: 1024x1024 batch (sizes of BASELINE config 5)
     rs = np.random.RandomState(0)
     x = rs.randint(0, 256, size=(3, 3, 1024, 1024)).astype(np.uint8)
