@@ -212,6 +212,9 @@ def main():
     args = ap.parse_args()
 
     import pggan_amd as pg
+    if os.environ.get('PGGAN_TUNE'):                       # kernel A/B aid: "key=value,..." -> pg_debug_set_tuning
+        for kv in os.environ['PGGAN_TUNE'].split(','):
+            pg._lib.load().pg_debug_set_tuning(*[int(v) for v in kv.split('=')])
     pg.wgan_gp_loss.enable_graphs(args.graphs)              # replayed whenever alpha == 1 (graphs.py)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     force_dp = os.environ.get('PGGAN_FORCE_DP', '') == '1'      # one-rank RCCL group: smoke test of the DP code path

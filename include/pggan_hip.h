@@ -59,6 +59,18 @@ int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, float* db,
                          int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
                          float scale, pg_stream_t stream);
 
+/* The same convolution with the 2x2 average pool that follows every DBlock (network.py:229,238) and the fade-in
+ * blend (network.py:233) fused into its epilogue:
+ *   y     = act(conv)                                  [N][Hout][Wout][Cout]   (left UNWRITTEN when pool_only != 0
+ *                                                       and the fused path is taken; always pass a valid buffer)
+ *   ypool = pool_a * avgpool2(y) + pool_b * pool_other  [N][Hout/2][Wout/2][Cout]   (pool_other may be NULL)
+ * Bit-identical to pg_conv2d_nhwc followed by pg_avgpool2_fwd (same summation order); split-K and non-3x3
+ * launches fall back to exactly that pair internally.                                              */
+int pg_conv2d_pool_nhwc(const float* x, const float* w, const float* bias, const float* mask, float* y,
+                        float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
+                        int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
+                        float scale, float slope, float mask_slope, pg_stream_t stream);
+
 /* Profiling aid: symbol (as rocprofv3 prints it, e.g. "conv_igemm_kernel<3, 4, 2, 2, 4>") of the conv
  * kernel instantiation most recently launched by the calling thread through the two entry points
  * above ("" before the first launch).  Thread-local; lets bench.py attribute its HIP-event timings

@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
-thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 3: unfused pooling
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -51,6 +51,8 @@ struct ConvP {
     unsigned mWT, mHT;          // floor(2^32/WT)+1, floor(2^32/HT)+1: exact n/d for n < 2^16 via __umulhi
     int ksplit;                 // >1: blockIdx.z owns a slice of the Cin chunks, partial sums are
                                 // committed with fp32 atomics into a pre-zeroed y (epilogue deferred)
+    // fused 2x2 average pool of the activated output (pg_conv2d_pool_nhwc): ypool = pool_a * avgpool2(y) + pool_b * pool_other
+    float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
 };
 
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
@@ -216,18 +218,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     }
 
     // epilogue: lane holds couts cb..cb+3 of pixel j
+    const bool pooling = p.ypool != nullptr && p.ksplit == 1;
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         const int cb = co0 + (wave_co * WM + m) * 16 + 4 * kk;
-        if (cb >= p.Cout) continue;
+        const bool cvalid = cb < p.Cout;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + cb);
+        if (p.bias && cvalid) bv = *reinterpret_cast<const float4*>(p.bias + cb);
+        float4 ov[WN];
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
+            ov[n] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int j = (wave_px * WN + n) * 16 + li;
             const int tw = j & (TW - 1), th = (j >> p.lgTW) & (TH - 1), tn = j >> (p.lgTW + p.lgTH);
             const int ni = n0 + tn;
-            if (ni >= p.N) continue;
+            if (!cvalid || ni >= p.N) continue;
             const size_t off = (((size_t)ni * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * p.Cout + cb;
             float4 o;
             o.x = acc[m][n][0] * p.scale; o.y = acc[m][n][1] * p.scale;
@@ -246,7 +251,61 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
                 o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
                 o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
             }
-            *reinterpret_cast<float4*>(p.y + off) = o;
+            if (!(pooling && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
+            ov[n] = o;
+        }
+        if (pooling) {
+            // 2x2 mean inside the wave: the horizontal neighbour is lane^1; the vertical neighbour is lane^TW for
+            // tiles <= 8 wide, the next 16-pixel group (TW 16) or the one after (TW 32) otherwise -- launch_conv
+            // restricts TW so that this group belongs to the same wave.  Same summation order as pg_avgpool2_fwd.
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                ov[n].x += __shfl_xor(ov[n].x, 1, 64); ov[n].y += __shfl_xor(ov[n].y, 1, 64);
+                ov[n].z += __shfl_xor(ov[n].z, 1, 64); ov[n].w += __shfl_xor(ov[n].w, 1, 64);
+            }
+            bool rowlead[WN];
+            if (p.lgTW <= 3) {
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    ov[n].x += __shfl_xor(ov[n].x, TW, 64); ov[n].y += __shfl_xor(ov[n].y, TW, 64);
+                    ov[n].z += __shfl_xor(ov[n].z, TW, 64); ov[n].w += __shfl_xor(ov[n].w, TW, 64);
+                    rowlead[n] = (li & TW) == 0;
+                }
+            } else if (p.lgTW == 4) {
+#pragma unroll
+                for (int n = 0; n < WN; ++n) rowlead[n] = (n & 1) == 0;
+                if constexpr (WN >= 2) {
+#pragma unroll
+                    for (int n = 0; n < WN; n += 2) {
+                        ov[n].x += ov[n + 1].x; ov[n].y += ov[n + 1].y; ov[n].z += ov[n + 1].z; ov[n].w += ov[n + 1].w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < WN; ++n) rowlead[n] = (n & 2) == 0;
+                if constexpr (WN >= 4) {
+#pragma unroll
+                    for (int n = 0; n < WN; n += 4) {
+                        ov[n].x += ov[n + 2].x; ov[n].y += ov[n + 2].y; ov[n].z += ov[n + 2].z; ov[n].w += ov[n + 2].w;
+                        ov[n + 1].x += ov[n + 3].x; ov[n + 1].y += ov[n + 3].y; ov[n + 1].z += ov[n + 3].z; ov[n + 1].w += ov[n + 3].w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                const int j = (wave_px * WN + n) * 16 + li;
+                const int tw = j & (TW - 1), th = (j >> p.lgTW) & (TH - 1), tn = j >> (p.lgTW + p.lgTH);
+                const int ni = n0 + tn;
+                if (!cvalid || ni >= p.N || !rowlead[n] || (li & 1)) continue;
+                const size_t poff = (((size_t)ni * (p.Hout >> 1) + ((oh0 + th) >> 1)) * (p.Wout >> 1) + ((ow0 + tw) >> 1)) * p.Cout + cb;
+                float4 v = make_float4(ov[n].x * 0.25f, ov[n].y * 0.25f, ov[n].z * 0.25f, ov[n].w * 0.25f);
+                if (p.pool_other) {
+                    const float4 q = *reinterpret_cast<const float4*>(p.pool_other + poff);
+                    v.x = fmaf(v.x, p.pool_a, p.pool_b * q.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * q.y);   // same form as
+                    v.z = fmaf(v.z, p.pool_a, p.pool_b * q.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * q.w);   // avgpool2_fwd_kernel
+                } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
+                *reinterpret_cast<float4*>(p.ypool + poff) = v;
+            }
         }
     }
 }
@@ -738,10 +797,10 @@ inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 struct TileGeom { int lgTW, lgTH, TN, tilesW, tilesH, ntiles; };
 
-inline TileGeom make_geom(int N, int Hout, int Wout, int BPX)
+inline TileGeom make_geom(int N, int Hout, int Wout, int BPX, int max_tw = 32)
 {
     TileGeom g;
-    int TW = Wout < 32 ? Wout : 32; if (TW > BPX) TW = BPX;
+    int TW = Wout < max_tw ? Wout : max_tw; if (TW > BPX) TW = BPX;
     while (TW > 4 && BPX / TW < 4 && Hout >= 4) TW >>= 1;      // keep tiles at least 4 rows tall (halo <= 2.25x)
     int TH = BPX / TW; if (TH > Hout) TH = Hout;
     g.lgTW = ilog2(TW); g.lgTH = ilog2(TH);
@@ -767,7 +826,10 @@ int launch_conv(ConvP& p, hipStream_t s)
 {
     constexpr int WAVES_PX = 4 / WAVES_CO;
     constexpr int BCO = 16 * WM * WAVES_CO, BPX = 16 * WN * WAVES_PX, KCP = RowStride<VEC>::value;
-    TileGeom g = make_geom(p.N, p.Hout, p.Wout, BPX);
+    // fused pooling needs the vertical 2x2 partner inside the wave: <= 8-wide tiles always work (lane ^ TW),
+    // 16-wide ones need two, 32-wide ones four 16-pixel groups per wave
+    const int max_tw = p.ypool ? (WN >= 4 ? 32 : (WN >= 2 ? 16 : 8)) : 32;
+    TileGeom g = make_geom(p.N, p.Hout, p.Wout, BPX, max_tw);
     p.lgTW = g.lgTW; p.lgTH = g.lgTH; p.TN = g.TN; p.tilesW = g.tilesW; p.tilesH = g.tilesH;
     const int HT = (1 << g.lgTH) + KS - 1, WT = (1 << g.lgTW) + KS - 1;
     constexpr int XMAX = halo_max(KS, BPX);
@@ -950,9 +1012,13 @@ int dispatch_wgrad(WgP& p, hipStream_t s)
 
 }  // namespace
 
-extern "C" int pg_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* mask, float* y,
-                              int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
-                              float scale, float slope, float mask_slope, pg_stream_t stream)
+extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
+                               float a, float b, pg_stream_t stream);
+
+static int conv2d_impl(const float* x, const float* w, const float* bias, const float* mask, float* y,
+                       float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
+                       int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
+                       float scale, float slope, float mask_slope, pg_stream_t stream)
 {
     if (!x || !w || !y || N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
     if ((Cin & 3) || (Cout & 3)) return PG_E_ALIGN;
@@ -962,20 +1028,48 @@ extern "C" int pg_conv2d_nhwc(const float* x, const float* w, const float* bias,
     p.Hout = Hin + 2 * pad - KS + 1; p.Wout = Win + 2 * pad - KS + 1;
     if (p.Hout <= 0 || p.Wout <= 0 || !is_pow2(p.Hout) || !is_pow2(p.Wout)) return PG_E_UNSUP;
     if (ups && ((Hin | Win) & 1)) return PG_E_ARG;
+    if (ypool && ((p.Hout | p.Wout) & 1)) return PG_E_ARG;
     // 32-bit element offsets inside the kernels
     if ((long long)N * Hin * Win * Cin >= (1ll << 31) || (long long)N * p.Hout * p.Wout * Cout >= (1ll << 31) ||
         (long long)KS * KS * Cout * Cin >= (1ll << 31)) return PG_E_UNSUP;
     p.scale = scale; p.slope = slope; p.mask_slope = mask_slope;
+    p.ksplit = 1;
+    const bool fuse_pool = ypool != nullptr && KS == 3 && g_tune[3] != 3;
+    p.ypool = fuse_pool ? ypool : nullptr; p.pool_other = pool_other; p.pool_a = pool_a; p.pool_b = pool_b;
+    p.pool_only = pool_only;
     hipStream_t s = (hipStream_t)stream;
+    int rc;
     if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
         ((pad == 3 && Hin == 1 && Win == 1) || (pad == 0 && Hin == 4 && Win == 4)))
-        return launch_k4_conv(p, s);
-    switch (KS) {
-        case 1: return dispatch_conv_vec<1>(p, s);
-        case 3: return dispatch_conv_vec<3>(p, s);
-        case 4: return dispatch_conv_vec<4>(p, s);
+        rc = launch_k4_conv(p, s);
+    else switch (KS) {
+        case 1: rc = dispatch_conv_vec<1>(p, s); break;
+        case 3: rc = dispatch_conv_vec<3>(p, s); break;
+        case 4: rc = dispatch_conv_vec<4>(p, s); break;
         default: return PG_E_UNSUP;
     }
+    if (rc) return rc;
+    if (ypool && !(fuse_pool && p.ksplit == 1))          // split-K / non-3x3 launches pool in a second pass over y
+        return pg_avgpool2_fwd(y, pool_other, ypool, N, p.Hout >> 1, p.Wout >> 1, Cout, pool_a, pool_b, stream);
+    return 0;
+}
+
+extern "C" int pg_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* mask, float* y,
+                              int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
+                              float scale, float slope, float mask_slope, pg_stream_t stream)
+{
+    return conv2d_impl(x, w, bias, mask, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, ups,
+                       scale, slope, mask_slope, stream);
+}
+
+extern "C" int pg_conv2d_pool_nhwc(const float* x, const float* w, const float* bias, const float* mask, float* y,
+                                   float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
+                                   int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
+                                   float scale, float slope, float mask_slope, pg_stream_t stream)
+{
+    if (!ypool) return PG_E_ARG;
+    return conv2d_impl(x, w, bias, mask, y, ypool, pool_other, pool_a, pool_b, pool_only, N, Hin, Win, Cin, Cout, KS, pad, ups,
+                       scale, slope, mask_slope, stream);
 }
 
 extern "C" int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, float* db,

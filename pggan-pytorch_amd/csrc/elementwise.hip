@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restri
         v.z = ((p0.z + p1.z) + (p2.z + p3.z)) * 0.25f; v.w = ((p0.w + p1.w) + (p2.w + p3.w)) * 0.25f;
         if (other) {
             const float4 q = o4[idx];
-            v.x = v.x * a + b * q.x; v.y = v.y * a + b * q.y; v.z = v.z * a + b * q.z; v.w = v.w * a + b * q.w;
+            v.x = fmaf(v.x, a, b * q.x); v.y = fmaf(v.y, a, b * q.y); v.z = fmaf(v.z, a, b * q.z); v.w = fmaf(v.w, a, b * q.w);
         } else if (a != 1.f) { v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
         y4[idx] = v;
     }
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__); \
     return (int)hipGetLastError()
 
-extern "C" int pg_abi_version(void) { return 7; }
+extern "C" int pg_abi_version(void) { return 8; }
 
 extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
                                float a, float b, pg_stream_t stream)

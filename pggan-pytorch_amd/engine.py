@@ -259,18 +259,22 @@ def d_forward(D, x, groups=1):
             a1 = _conv(cur, blk.c1, NB, H)
             if pn:                                                            # a1/a2 hold the NORMALISED outputs
                 a1, rec['r1'] = ops.pixelnorm_fwd(a1, inplace=True)
-            a2 = _conv(a1, blk.c2, NB, H)
-            if pn:
-                a2, rec['r2'] = ops.pixelnorm_fwd(a2, inplace=True)
-            rec.update(a1=a1, a2=a2)
+            pf = None
             if k == 0 and alpha < 1.0:                                        # :230-233
                 nfr = D.blocks[j + 1].fromRGB
                 pf = ops.fromrgb_fwd(x, nfr.conv.weight.data, nfr.conv.bias.data, NB, C, H // 2, H // 2,
                                      nfr.c, nfr.slope, pool=True)
-                cur = ops.avgpool2_fwd(a2, pf, alpha, 1.0 - alpha)
                 rec['pf'] = pf
-            else:
-                cur = ops.avgpool2_fwd(a2)                                    # :229,238
+            pa, pb = (alpha, 1.0 - alpha) if pf is not None else (1.0, 0.0)
+            if pn:
+                a2 = _conv(a1, blk.c2, NB, H)
+                a2, rec['r2'] = ops.pixelnorm_fwd(a2, inplace=True)
+                cur = ops.avgpool2_fwd(a2, pf, pa, pb)                        # :229,238
+            else:                                                             # pool (+ fade-in blend) in the conv epilogue
+                c2 = blk.c2
+                a2, cur = ops.conv2d_pool(a1, c2.conv.weight.data, c2.conv.bias.data, NB, H, H, c2.ksize, c2.pad, c2.c,
+                                          c2.slope, other=pf, a=pa, b=pb)
+            rec.update(a1=a1, a2=a2)
             H //= 2
         ctx['recs'].append(rec)
     s = ops.linear1_fwd(a2, D.linear.weight.data, D.linear.bias.data)         # :239
@@ -535,18 +539,21 @@ def d_tangent_wgrad(D, sub, adj, u):
             if pn:
                 t1, injs[idx]['inj1'] = ops.pixelnorm_tangent(t1, rec['a1'], rec['r1'], adj[idx]['gy1'])
             _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False)
-            t2 = _conv(t1, c2, N, H, mask=rec['a2'], bias=False)
-            if pn:
-                t2, injs[idx]['inj2'] = ops.pixelnorm_tangent(t2, rec['a2'], rec['r2'], adj[idx]['gy2'])
+            tpf = None
             if rec['first'] and alpha < 1.0:
                 nfr = recs[idx + 1]['blk'].fromRGB
                 with _on_side(adj[idx]['gpf'], u):
                     ops.fromrgb_wgrad(adj[idx]['gpf'], u, nfr._gw, None, N, C, H // 2, H // 2, nfr.c, pool=True)
                 tpf = ops.fromrgb_fwd(u, nfr.conv.weight.data, None, N, C, H // 2, H // 2, nfr.c, 1.0,
                                       pool=True, mask=rec['pf'], mask_slope=nfr.slope)
-                cur = ops.avgpool2_fwd(t2, tpf, alpha, 1.0 - alpha)
-            else:
-                cur = ops.avgpool2_fwd(t2)
+            pa, pb = (alpha, 1.0 - alpha) if tpf is not None else (1.0, 0.0)
+            if pn:
+                t2 = _conv(t1, c2, N, H, mask=rec['a2'], bias=False)
+                t2, injs[idx]['inj2'] = ops.pixelnorm_tangent(t2, rec['a2'], rec['r2'], adj[idx]['gy2'])
+                cur = ops.avgpool2_fwd(t2, tpf, pa, pb)
+            else:                                                 # only the pooled tangent is needed downstream
+                t2, cur = ops.conv2d_pool(t1, c2.conv.weight.data, None, N, H, H, c2.ksize, c2.pad, c2.c, 1.0,
+                                          mask=rec['a2'], mask_slope=c2.slope, other=tpf, a=pa, b=pb, pool_only=True)
     # Linear: d/dw <ones, w . t2> = sum_n t2[n]
     ops.linear1_wgrad(_ones(N, u.device), t2, D._lin_gw, None)
     return hvp + (injs,) if pn else hvp

@@ -41,6 +41,19 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
     return y
 
 
+def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
+                pool_only=False):
+    """conv2d with the following 2x2 average pool (+ fade-in blend a*pool + b*other) fused into the epilogue.
+    Returns (y, ypool); with ``pool_only`` the full-resolution y may be left unwritten (do not read it)."""
+    cout, cin = w.shape[2], w.shape[3]
+    ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
+    y = torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
+    yp = torch.empty((N, ho // 2, wo // 2, cout), device=x.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_pool_nhwc', _p(x), _p(w), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
+              N, Hin, Win, cin, cout, ks, pad, 0, scale, slope, mask_slope, _stream())
+    return y, yp
+
+
 def conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=False):
     """Accumulates into dw [ks,ks,Cout,Cin] (and db [Cout] if given)."""
     cout, cin = dw.shape[2], dw.shape[3]

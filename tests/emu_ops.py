@@ -57,6 +57,12 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
     return _ret(y, out)
 
 
+def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
+                pool_only=False):
+    y = conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=slope, mask=mask, mask_slope=mask_slope)
+    return y, avgpool2_fwd(y, other, a, b)
+
+
 def conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=False):
     xi = _nchw(x)
     if ups:

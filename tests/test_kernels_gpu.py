@@ -57,6 +57,38 @@ def test_conv2d_fwd_and_masked(case):
     check('conv linear %s' % (case,), y, E.conv2d(x, w, b, N, H, H, ks, pad, 1.0, slope=1.0, ups=bool(ups)))
 
 
+POOL_CASES = [(2, 32, 64, 64), (3, 16, 128, 96), (2, 64, 16, 16), (1, 64, 8, 8), (2, 32, 8, 16), (2, 16, 12, 20), (5, 4, 32, 16),
+              (3, 8, 528, 512), (1, 256, 8, 16), (3, 128, 16, 32), (2, 64, 32, 64), (9, 16, 256, 256), (3, 32, 256, 512), (1, 8, 64, 32),
+              (2, 2, 16, 16)]
+
+
+@pytest.mark.parametrize('case', POOL_CASES)
+@pytest.mark.parametrize('cand', [-1, 0, 1, 2, 3, 4, 5, 6, 7])
+def test_conv2d_pool_fused(case, cand):
+    """Fused conv + 2x2 pool (+ fade-in blend) == conv followed by avgpool, bit for bit, for every tile shape."""
+    N, H, ci, co = case
+    lib = pg._lib.load()
+    x, w, b = rnd(N, H, H, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    other, m = rnd(N, H // 2, H // 2, co, seed=4), rnd(N, H, H, co, seed=3)
+    lib.pg_debug_set_tuning(0, cand)
+    try:
+        try:
+            y, yp = ops.conv2d_pool(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.37, slope=0.2, other=dev(other), a=0.6, b=0.4)
+        except RuntimeError:
+            pytest.skip('tile candidate not available for this shape')
+        lib.pg_debug_set_tuning(0, -1)
+        ry = ops.conv2d(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.37, slope=0.2)
+        check('conv+pool y %s' % (case,), y, E.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2))
+        assert torch.equal(yp, ops.avgpool2_fwd(y, dev(other), 0.6, 0.4)), 'pooled output differs from the unfused pair'
+        lib.pg_debug_set_tuning(0, cand)
+        _, yp2 = ops.conv2d_pool(dev(x), dev(w), None, N, H, H, 3, 1, 0.37, mask=dev(m), mask_slope=0.2, pool_only=True)
+        lib.pg_debug_set_tuning(0, -1)
+        ym = ops.conv2d(dev(x), dev(w), None, N, H, H, 3, 1, 0.37, mask=dev(m), mask_slope=0.2)
+        check('conv+pool masked, pooled only %s' % (case,), yp2, ops.avgpool2_fwd(ym).cpu())   # other tile / split-K: fp32 order
+    finally:
+        lib.pg_debug_set_tuning(0, -1)
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv2d_wgrad(case):
     N, H, ci, co, ks, pad, ups = case
