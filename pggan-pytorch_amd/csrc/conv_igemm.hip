@@ -981,6 +981,210 @@ int launch_wgrad(WgP& p, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Weight gradient of the 8-channel layers (8->8, 8->16, 16->8 at 1024^2): a 16x16x4 MFMA tile would be 75 % / 50 %
+// zero padding.  v_mfma_f32_4x4x1_16B_f32 computes SIXTEEN independent 4x4 outer products per instruction at the
+// same FLOP rate: the CO x CI outer product of one pixel is NB = (CO/4)*(CI/4) blocks, so one instruction takes
+// 16/NB pixels (4 for 8x8, 2 for 8x16) with every lane doing useful work.  Lane l: block b = l>>2, A row / B col
+// = l&3; D register r of lane 4b+j is element [r][j] of block b.  Blocks of the same (co-quad, ci-quad) but
+// different pixel slot are separate accumulators, summed by xor-shuffles before the workgroup reduction.
+template <int CO, int CI, int BPX>
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
+{
+    constexpr int KS = 3, TAPS = 9;
+    constexpr int QO = CO / 4, QI = CI / 4, NB = QO * QI, PPM = 16 / NB;     // pixels per MFMA
+    constexpr int SZ = PixStride<CO>::value, SX = PixStride<CI>::value;
+    constexpr int ZV = CO / 4, XV = CI / 4;
+    constexpr int ZPT = (BPX * ZV + 255) / 256;
+    constexpr int XMAX = (BPX * 9) / 4;
+    constexpr int XPT = (XMAX * XV + 255) / 256;
+    extern __shared__ __align__(16) float lds[];
+
+    const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
+    const int HT = TH + KS - 1, WT = TW + KS - 1;
+    float* gzt = lds;                        // [BPX][SZ]
+    float* xt = lds + BPX * SZ;              // [TN*HT*WT][SX]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = lane >> 2, i4 = lane & 3;
+    const int hi = blk % QI, ho = (blk / QI) % QO, slot = blk / NB;
+    const bool do_bias = p.db != nullptr;
+
+    f32x4 acc[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const int npix = p.TN * HT * WT;
+    const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
+    int zq[ZPT], zc[ZPT];
+    int xq[XPT], xc[XPT], xdst[XPT];
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / ZV, v = idx - q * ZV;
+        zq[i] = idx < BPX * ZV ? q : -1;
+        zc[i] = 4 * v;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / XV, v = idx - q * XV;
+        const int r2 = (int)__umulhi((unsigned)q, p.mWT), tw = q - r2 * WT;
+        const int tn = (int)__umulhi((unsigned)r2, p.mHT), th = r2 - tn * HT;
+        xq[i] = q < npix ? ((tn << 20) | (th << 10) | tw) : -1;
+        xc[i] = 4 * v;
+        xdst[i] = q * SX + 4 * v;
+    }
+    int tapoff[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) tapoff[tp] = ((tp / KS) * WT + (tp % KS)) * SX;
+
+    float4 zreg[ZPT], xreg[XPT];
+    auto fetch = [&](int tile) {
+        int t = tile;
+        const int tw_i = t % p.tilesW; t /= p.tilesW;
+        const int th_i = t % p.tilesH; t /= p.tilesH;
+        const int n0 = t * p.TN;
+        const int oh0 = th_i << p.lgTH, ow0 = tw_i << p.lgTW;
+#pragma unroll
+        for (int i = 0; i < ZPT; ++i) {
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zq[i] >= 0) {
+                const int q = zq[i];
+                const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
+                const int n = n0 + tn;
+                if (n < p.N)
+                    val = *reinterpret_cast<const float4*>(p.gz + (((size_t)n * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * CO + zc[i]);
+            }
+            zreg[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xq[i] >= 0) {
+                const int tw = xq[i] & 1023, th = (xq[i] >> 10) & 1023, tn = xq[i] >> 20;
+                const int n = n0 + tn;
+                int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
+                if (n < p.N && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
+                    if (p.ups) { ih >>= 1; iw >>= 1; }                       // nearest-x2 upsample fused into the gather
+                    val = *reinterpret_cast<const float4*>(p.x + (((size_t)n * xH + ih) * xW + iw) * CI + xc[i]);
+                }
+            }
+            xreg[i] = val;
+        }
+    };
+
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.ntiles);
+    constexpr int NSTEPS = BPX / PPM, T = NSTEPS / 4;            // k-steps per tile / per wave
+
+    if (t_begin < t_end) fetch(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+#pragma unroll
+        for (int i = 0; i < ZPT; ++i)
+            if (zq[i] >= 0) *reinterpret_cast<float4*>(gzt + zq[i] * SZ + zc[i]) = zreg[i];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+            if (xq[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
+        __syncthreads();
+        if (tile + 1 < t_end) fetch(tile + 1);
+
+        auto load_frags = [&](int step, float& af, float (&bf)[TAPS]) {
+            const int q = PPM * step + slot;
+            const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
+            af = gzt[q * SZ + 4 * ho + i4];
+            const int bo = ((tn * HT + th) * WT + tw) * SX + 4 * hi + i4;
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) bf[tp] = xt[bo + tapoff[tp]];
+        };
+        auto mfmas = [&](float af, const float (&bf)[TAPS]) {
+            bsum += af;
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) acc[tp] = __builtin_amdgcn_mfma_f32_4x4x1f32(af, bf[tp], acc[tp], 0, 0, 0);
+        };
+        float a[2], b[2][TAPS];
+        static_assert(T % 2 == 0, "k-steps per wave must be even");
+        load_frags(wave, a[0], b[0]);
+        for (int s2 = 0; s2 < T; s2 += 2) {
+            load_frags(wave + (s2 + 1) * 4, a[1], b[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a[0], b[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s2 + 2 < T) load_frags(wave + (s2 + 2) * 4, a[0], b[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a[1], b[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- sum the pixel slots (lanes 4*NB apart), then the 4 waves through LDS, then ONE commit per workgroup
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[tp][r];
+            if (PPM >= 2) v += __shfl_xor(v, 32, 64);
+            if (PPM >= 4) v += __shfl_xor(v, 16, 64);
+            acc[tp][r] = v;
+        }
+    if (PPM >= 2) bsum += __shfl_xor(bsum, 32, 64);
+    if (PPM >= 4) bsum += __shfl_xor(bsum, 16, 64);
+    constexpr int NL = 4 * NB;                                   // lanes holding distinct results
+    float* red = lds;                                            // [wave][TAPS*4 + 1][NL]
+    if (lane < NL) {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * (TAPS * 4 + 1) + tp * 4 + r) * NL + lane] = acc[tp][r];
+        red[(wave * (TAPS * 4 + 1) + TAPS * 4) * NL + lane] = bsum;
+    }
+    __syncthreads();
+    // thread t < (TAPS*4+1)*NL sums the four waves and commits one element
+    for (int e = tid; e < (TAPS * 4 + 1) * NL; e += 256) {
+        const int l = e % NL, slot_e = e / NL;                   // slot_e = tp*4 + r, or TAPS*4 for the bias
+        const float v = (red[e] + red[e + (TAPS * 4 + 1) * NL]) + (red[e + 2 * (TAPS * 4 + 1) * NL] + red[e + 3 * (TAPS * 4 + 1) * NL]);
+        const int b_ = l >> 2, j = l & 3;
+        const int hi_ = b_ % QI, ho_ = (b_ / QI) % QO;
+        if (slot_e < TAPS * 4) {
+            const int tp = slot_e >> 2, r = slot_e & 3;
+            float* dst = p.dw + ((size_t)(tp * CO + 4 * ho_ + r) * CI + 4 * hi_ + j);
+            if (p.atomic) atomicAdd(dst, v * p.scale); else *dst += v * p.scale;
+        } else if (do_bias && hi_ == 0) {                        // lane (ho, hi = 0, i) carries sum_p gz[p][4*ho + i]
+            float* dst = p.db + 4 * ho_ + j;
+            if (p.atomic) atomicAdd(dst, v); else *dst += v;
+        }
+    }
+}
+
+template <int BPX>
+int launch_wgrad_thin(WgP& p, hipStream_t s)
+{
+    TileGeom g = make_geom(p.N, p.Hout, p.Wout, BPX);
+    p.lgTW = g.lgTW; p.lgTH = g.lgTH; p.TN = g.TN; p.tilesW = g.tilesW; p.tilesH = g.tilesH; p.ntiles = g.ntiles;
+    const int HT = (1 << g.lgTH) + 2, WT = (1 << g.lgTW) + 2;
+    if (g.TN * HT * WT > (BPX * 9) / 4) return PG_E_UNSUP;
+    p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
+    const int sz = p.Cout == 8 ? 24 : 16, sx = p.Cin == 8 ? 24 : 16;           // PixStride<8>, PixStride<16>
+    size_t smem = ((size_t)BPX * sz + (size_t)g.TN * HT * WT * sx) * sizeof(float);
+    const size_t red = (size_t)4 * 37 * 64 * sizeof(float);
+    if (red > smem) smem = red;
+    int chunks = 1024; if (chunks > g.ntiles) chunks = g.ntiles;
+    p.tiles_per_block = (g.ntiles + chunks - 1) / chunks;
+    chunks = (g.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
+    p.atomic = chunks > 1 ? 1 : 0;
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_wgrad_thin_kernel<%d, %d, %d>", p.Cout, p.Cin, BPX);
+#define THIN(CO_, CI_) { auto kern = conv_wgrad_thin_kernel<CO_, CI_, BPX>; if (int rc = set_smem(kern, smem)) return rc; \
+                         hipLaunchKernelGGL(kern, dim3(chunks), dim3(256), smem, s, p); }
+    if (p.Cout == 8 && p.Cin == 8) THIN(8, 8)
+    else if (p.Cout == 16 && p.Cin == 8) THIN(16, 8)
+    else if (p.Cout == 8 && p.Cin == 16) THIN(8, 16)
+    else return PG_E_UNSUP;
+#undef THIN
+    return (int)hipGetLastError();
+}
+
 template <int KS>
 int dispatch_wgrad(WgP& p, hipStream_t s)
 {
@@ -989,7 +1193,14 @@ int dispatch_wgrad(WgP& p, hipStream_t s)
     } else {
         const long long M = (long long)p.N * p.Hout * p.Wout;
         if (M <= 32) return launch_wgrad<KS, 1, 1, 2, 2, 16>(p, s);
-        if (p.Cout <= 16 && p.Cin <= 16) return launch_wgrad<KS, 1, 1, 1, 1, 128>(p, s);     // 16x16 block
+        if (p.Cout <= 16 && p.Cin <= 16) {
+            if constexpr (KS == 3) {
+                // 8-channel sides: the 16x16x4 tile would be 50-75 % padding -> 4x4x1 block MFMA kernel
+                if (g_tune[1] != 8 && (p.Cout == 8 || p.Cin == 8) && (p.Cout == 8 || p.Cout == 16) && (p.Cin == 8 || p.Cin == 16))
+                    return launch_wgrad_thin<64>(p, s);
+            }
+            return launch_wgrad<KS, 1, 1, 1, 1, 128>(p, s);     // 16x16 block
+        }
         if constexpr (KS == 3) {
             switch (g_tune[1]) {                                                               // tuning sweep only
                 case 1: return launch_wgrad<KS, 2, 1, 1, 1, 128>(p, s);
