@@ -81,7 +81,11 @@ class KernelTimer(object):
             ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
             return (conv_flops(n, ho, wo, ks, pad, dw.shape[2], dw.shape[3]),
                     'wgrad %d->%d k%d @%d n%d' % (dw.shape[3], dw.shape[2], ks, ho, n))
+        def pool_desc(a, k):          # conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, ...): the conv of conv_desc + pooled output
+            fl, tag = conv_desc(a, k)
+            return fl, tag + ' +pool'
         self._wrap('conv2d', conv_desc)
+        self._wrap('conv2d_pool', pool_desc)
         self._wrap('conv2d_wgrad', wgrad_desc)
         return self
 

@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
-thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 3: unfused pooling
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8-cout layers, 3: unfused pooling
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -736,6 +736,98 @@ __global__ __launch_bounds__(256) void conv_k4_wgrad_kernel(WgP p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 3x3 layers with EIGHT output channels (8->8, 16->8: the 1024^2 stage and its backward-data convs).  A 16x16x4
+// tile wastes half of its rows on them; v_mfma_f32_4x4x1_16B_f32 does not: block = (cout quad, pixel quad), so one
+// instruction covers 8 couts x 32 consecutive pixels of a row for one (tap, cin) with every lane useful.
+// Workgroup: TH rows x 32 pixels of one image, halo tile in LDS (row stride CIN+4 floats: conflict-free b128),
+// wave w owns TH/4 rows; weights live in registers (CIN 8) or are re-read from LDS per (tap, cin quad) (CIN 16).
+template <int CIN, int TH>
+__global__ __launch_bounds__(256) void conv_thin8_kernel(ConvP p)
+{
+    constexpr int S = CIN + 4, WT = 34, HT = TH + 2, G = TH / 4, C4 = CIN / 4;
+    extern __shared__ __align__(16) float lds[];
+    float* xt = lds;                             // [HT][WT][S]
+    float* wl = lds + HT * WT * S;               // [9][8][CIN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = lane >> 2, j = lane & 3, qo = blk & 1, qp = blk >> 1;
+    int b = blockIdx.x;
+    const int tw_i = b % (p.Wout >> 5); b /= (p.Wout >> 5);
+    const int th_i = b % (p.Hout / TH); const int n = b / (p.Hout / TH);
+    const int oh0 = th_i * TH, ow0 = tw_i << 5;
+    const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
+
+    for (int e = tid; e < HT * WT * C4; e += 256) {
+        const int c4 = e % C4; const int q = e / C4;
+        const int tw = q % WT, th = q / WT;
+        int ih = oh0 + th - 1, iw = ow0 + tw - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
+            if (p.ups) { ih >>= 1; iw >>= 1; }
+            v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * xH + ih) * xW + iw) * CIN + 4 * c4);
+        }
+        *reinterpret_cast<float4*>(xt + q * S + 4 * c4) = v;
+    }
+    for (int e = tid; e < 9 * 8 * C4; e += 256)
+        *reinterpret_cast<float4*>(wl + 4 * e) = *reinterpret_cast<const float4*>(p.w + 4 * e);
+    __syncthreads();
+
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int px = 4 * qp + j;                   // pixel (column) of this lane inside the 32-pixel group
+    const float* wrow = wl + (4 * qo + j) * CIN; // A operand: couts 4*qo + (lane&3)
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3, dx = tp % 3;
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) {
+            const float4 a = *reinterpret_cast<const float4*>(wrow + tp * 8 * CIN + 4 * c4);
+            float4 bq[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                bq[g] = *reinterpret_cast<const float4*>(xt + ((wave * G + g + dy) * WT + px + dx) * S + 4 * c4);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, bq[g].x, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, bq[g].y, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, bq[g].z, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, bq[g].w, acc[g], 0, 0, 0);
+            }
+        }
+    }
+    // D register r of this lane = out[pixel px][cout 4*qo + r]
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + 4 * qo);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const size_t off = (((size_t)n * p.Hout + oh0 + wave * G + g) * p.Wout + ow0 + px) * 8 + 4 * qo;
+        float4 o = make_float4(acc[g][0] * p.scale, acc[g][1] * p.scale, acc[g][2] * p.scale, acc[g][3] * p.scale);
+        if (p.mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
+            o.x *= mk.x > 0.f ? 1.f : p.mask_slope; o.y *= mk.y > 0.f ? 1.f : p.mask_slope;
+            o.z *= mk.z > 0.f ? 1.f : p.mask_slope; o.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+        } else {
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+            o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
+            o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+        }
+        *reinterpret_cast<float4*>(p.y + off) = o;
+    }
+}
+
+template <int CIN, int TH>
+int launch_thin8(ConvP& p, hipStream_t s)
+{
+    const size_t smem = ((size_t)(TH + 2) * 34 * (CIN + 4) + 9 * 8 * CIN) * sizeof(float);
+    auto kern = conv_thin8_kernel<CIN, TH>;
+    if (int rc = set_smem(kern, smem)) return rc;
+    dim3 grid((unsigned)(p.N * (p.Hout / TH) * (p.Wout >> 5)));
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_thin8_kernel<%d, %d>", CIN, TH);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+    return (int)hipGetLastError();
+}
+
 inline bool k4_dense_ok(int Cin, int Cout) { return (Cin & 15) == 0 && (Cout & 15) == 0; }
 
 int launch_k4_conv(ConvP& p, hipStream_t s)
@@ -1250,6 +1342,11 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     p.pool_only = pool_only;
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    if (KS == 3 && pad == 1 && Cout == 8 && (Cin == 8 || Cin == 16) && !ypool && (p.Wout & 31) == 0 && (p.Hout & 7) == 0 &&
+        g_tune[3] != 2) {
+        if (Cin == 8) return launch_thin8<8, 8>(p, s);        // 8-row tiles measured best (16: fewer, fatter workgroups)
+        return launch_thin8<16, 8>(p, s);
+    }
     if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
         ((pad == 3 && Hin == 1 && Win == 1) || (pad == 0 && Hin == 4 && Win == 4)))
         rc = launch_k4_conv(p, s);
