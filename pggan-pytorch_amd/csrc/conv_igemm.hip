@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
-thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8-cout layers, 3: unfused pooling
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -737,20 +737,24 @@ __global__ __launch_bounds__(256) void conv_k4_wgrad_kernel(WgP p)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// 3x3 layers with EIGHT output channels (8->8, 16->8: the 1024^2 stage and its backward-data convs).  A 16x16x4
-// tile wastes half of its rows on them; v_mfma_f32_4x4x1_16B_f32 does not: block = (cout quad, pixel quad), so one
-// instruction covers 8 couts x 32 consecutive pixels of a row for one (tap, cin) with every lane useful.
-// Workgroup: TH rows x 32 pixels of one image, halo tile in LDS (row stride CIN+4 floats: conflict-free b128),
-// wave w owns TH/4 rows; weights live in registers (CIN 8) or are re-read from LDS per (tap, cin quad) (CIN 16).
-template <int CIN, int TH>
-__global__ __launch_bounds__(256) void conv_thin8_kernel(ConvP p)
+// 3x3 layers with 8 or 16 output channels and <= 32 input channels (the 512^2 / 1024^2 stages and their
+// backward-data convs).  A 16x16x4 tile wastes half of its rows on 8 couts and, more importantly, these layers have
+// no K loop to pipeline; v_mfma_f32_4x4x1_16B_f32 with block = (cout quad, pixel quad) covers COUT couts x
+// 64*4/COUT consecutive pixels of a row per instruction for one (tap, cin), every lane useful.
+// Workgroup: TH rows x 32 pixels of one image, whole-K halo tile in LDS (row stride CIN+4 floats: conflict-free
+// b128), one barrier, wave w owns TH/4 rows; weights are re-read from LDS per (tap, cin quad) as one b128.
+// Optional fused 2x2 average pool of the activated output (see pg_conv2d_pool_nhwc).
+template <int COUT, int CIN, int TH>
+__global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
 {
-    constexpr int S = CIN + 4, WT = 34, HT = TH + 2, G = TH / 4, C4 = CIN / 4;
+    constexpr int S = CIN + 4, WT = 34, HT = TH + 2, C4 = CIN / 4;
+    constexpr int QO = COUT / 4, QP = 16 / QO, PXG = 4 * QP;            // pixels per MFMA group: 32 (8 couts) / 16
+    constexpr int GPR = 32 / PXG, G = (TH / 4) * GPR;                   // groups per row, groups per wave
     extern __shared__ __align__(16) float lds[];
     float* xt = lds;                             // [HT][WT][S]
-    float* wl = lds + HT * WT * S;               // [9][8][CIN]
+    float* wl = lds + HT * WT * S;               // [9][COUT][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int blk = lane >> 2, j = lane & 3, qo = blk & 1, qp = blk >> 1;
+    const int blk = lane >> 2, j = lane & 3, qo = blk % QO, qp = blk / QO;
     int b = blockIdx.x;
     const int tw_i = b % (p.Wout >> 5); b /= (p.Wout >> 5);
     const int th_i = b % (p.Hout / TH); const int n = b / (p.Hout / TH);
@@ -768,25 +772,28 @@ __global__ __launch_bounds__(256) void conv_thin8_kernel(ConvP p)
         }
         *reinterpret_cast<float4*>(xt + q * S + 4 * c4) = v;
     }
-    for (int e = tid; e < 9 * 8 * C4; e += 256)
+    for (int e = tid; e < 9 * COUT * C4; e += 256)
         *reinterpret_cast<float4*>(wl + 4 * e) = *reinterpret_cast<const float4*>(p.w + 4 * e);
     __syncthreads();
 
     f32x4 acc[G];
+    int xoff[G];                                 // LDS offset of this lane's pixel in group g (tap 0,0)
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int px = 4 * qp + j;                   // pixel (column) of this lane inside the 32-pixel group
+    for (int g = 0; g < G; ++g) {
+        acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int gg = wave * G + g;
+        xoff[g] = ((gg / GPR) * WT + (gg % GPR) * PXG + 4 * qp + j) * S;
+    }
     const float* wrow = wl + (4 * qo + j) * CIN; // A operand: couts 4*qo + (lane&3)
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
-        const int dy = tp / 3, dx = tp % 3;
+        const int toff = ((tp / 3) * WT + (tp % 3)) * S;
 #pragma unroll
         for (int c4 = 0; c4 < C4; ++c4) {
-            const float4 a = *reinterpret_cast<const float4*>(wrow + tp * 8 * CIN + 4 * c4);
+            const float4 a = *reinterpret_cast<const float4*>(wrow + tp * COUT * CIN + 4 * c4);
             float4 bq[G];
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-                bq[g] = *reinterpret_cast<const float4*>(xt + ((wave * G + g + dy) * WT + px + dx) * S + 4 * c4);
+            for (int g = 0; g < G; ++g) bq[g] = *reinterpret_cast<const float4*>(xt + xoff[g] + toff + 4 * c4);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, bq[g].x, acc[g], 0, 0, 0);
@@ -796,12 +803,15 @@ __global__ __launch_bounds__(256) void conv_thin8_kernel(ConvP p)
             }
         }
     }
-    // D register r of this lane = out[pixel px][cout 4*qo + r]
+    // D register r of this lane = out[pixel][cout 4*qo + r]
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + 4 * qo);
+    float4 ov[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const size_t off = (((size_t)n * p.Hout + oh0 + wave * G + g) * p.Wout + ow0 + px) * 8 + 4 * qo;
+        const int gg = wave * G + g;
+        const int oy = oh0 + gg / GPR, ox = ow0 + (gg % GPR) * PXG + 4 * qp + j;
+        const size_t off = (((size_t)n * p.Hout + oy) * p.Wout + ox) * COUT + 4 * qo;
         float4 o = make_float4(acc[g][0] * p.scale, acc[g][1] * p.scale, acc[g][2] * p.scale, acc[g][3] * p.scale);
         if (p.mask) {
             const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
@@ -812,20 +822,53 @@ __global__ __launch_bounds__(256) void conv_thin8_kernel(ConvP p)
             o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
             o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
         }
-        *reinterpret_cast<float4*>(p.y + off) = o;
+        if (!(p.ypool && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
+        ov[g] = o;
+    }
+    if (p.ypool) {                               // 2x2 mean: column partner = lane^1, row partner = group g + GPR (same wave)
+        static_assert(TH % 8 == 0, "a wave must own complete row pairs");
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            ov[g].x += __shfl_xor(ov[g].x, 1, 64); ov[g].y += __shfl_xor(ov[g].y, 1, 64);
+            ov[g].z += __shfl_xor(ov[g].z, 1, 64); ov[g].w += __shfl_xor(ov[g].w, 1, 64);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (((g / GPR) & 1) != 0) continue;                  // compile-time: even rows lead
+            const int gg = wave * G + g;
+            const int oy = oh0 + gg / GPR, ox = ow0 + (gg % GPR) * PXG + 4 * qp + j;
+            float4 v = make_float4(((ov[g].x + ov[g + GPR].x)) * 0.25f, ((ov[g].y + ov[g + GPR].y)) * 0.25f,
+                                   ((ov[g].z + ov[g + GPR].z)) * 0.25f, ((ov[g].w + ov[g + GPR].w)) * 0.25f);
+            if (j & 1) continue;
+            const size_t poff = (((size_t)n * (p.Hout >> 1) + (oy >> 1)) * (p.Wout >> 1) + (ox >> 1)) * COUT + 4 * qo;
+            if (p.pool_other) {
+                const float4 q = *reinterpret_cast<const float4*>(p.pool_other + poff);
+                v.x = fmaf(v.x, p.pool_a, p.pool_b * q.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * q.y);
+                v.z = fmaf(v.z, p.pool_a, p.pool_b * q.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * q.w);
+            } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
+            *reinterpret_cast<float4*>(p.ypool + poff) = v;
+        }
     }
 }
 
-template <int CIN, int TH>
-int launch_thin8(ConvP& p, hipStream_t s)
+template <int COUT, int CIN, int TH>
+int launch_thin(ConvP& p, hipStream_t s)
 {
-    const size_t smem = ((size_t)(TH + 2) * 34 * (CIN + 4) + 9 * 8 * CIN) * sizeof(float);
-    auto kern = conv_thin8_kernel<CIN, TH>;
+    const size_t smem = ((size_t)(TH + 2) * 34 * (CIN + 4) + 9 * COUT * CIN) * sizeof(float);
+    auto kern = conv_thin_kernel<COUT, CIN, TH>;
     if (int rc = set_smem(kern, smem)) return rc;
     dim3 grid((unsigned)(p.N * (p.Hout / TH) * (p.Wout >> 5)));
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_thin8_kernel<%d, %d>", CIN, TH);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_thin_kernel<%d, %d, %d>", COUT, CIN, TH);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
     return (int)hipGetLastError();
+}
+
+int dispatch_thin(ConvP& p, hipStream_t s)
+{
+#define THIN(CO_, CI_) if (p.Cout == CO_ && p.Cin == CI_) return launch_thin<CO_, CI_, 8>(p, s);
+    THIN(8, 8) THIN(8, 16) THIN(16, 8)
+#undef THIN
+    return PG_E_UNSUP;
 }
 
 inline bool k4_dense_ok(int Cin, int Cout) { return (Cin & 15) == 0 && (Cout & 15) == 0; }
@@ -1342,10 +1385,16 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     p.pool_only = pool_only;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (KS == 3 && pad == 1 && Cout == 8 && (Cin == 8 || Cin == 16) && !ypool && (p.Wout & 31) == 0 && (p.Hout & 7) == 0 &&
-        g_tune[3] != 2) {
-        if (Cin == 8) return launch_thin8<8, 8>(p, s);        // 8-row tiles measured best (16: fewer, fatter workgroups)
-        return launch_thin8<16, 8>(p, s);
+    // measured (tools/sweep_thin8.py): 1.5-1.7x on 8 couts; on 16 couts only the masked 8->16 launch gains (the
+    // 16x16x4 tile has no padding there), 32 input channels lose -> those stay on the generic kernel
+    const bool thin_ok = KS == 3 && pad == 1 && ((Cout == 8 && (Cin == 8 || Cin == 16)) || (Cout == 16 && Cin == 8 && mask && !ypool)) &&
+                         (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
+    if (thin_ok) {
+        rc = dispatch_thin(p, s);                       // pools in its own epilogue when p.ypool is set
+        if (rc) return rc;
+        if (ypool && !p.ypool)
+            return pg_avgpool2_fwd(y, pool_other, ypool, N, p.Hout >> 1, p.Wout >> 1, Cout, pool_a, pool_b, stream);
+        return 0;
     }
     if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
         ((pad == 3 && Hin == 1 && Win == 1) || (pad == 0 && Hin == 4 && Win == 4)))

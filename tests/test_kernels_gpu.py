@@ -39,7 +39,8 @@ CONV_CASES = [
     (3, 8, 64, 32, 3, 1, 1), (3, 8, 528, 512, 3, 1, 0), (1, 256, 8, 8, 3, 1, 0), (2, 128, 16, 32, 3, 1, 1),
     (70, 1, 32, 32, 4, 3, 0), (130, 4, 16, 16, 4, 0, 0), (16, 1, 512, 512, 4, 3, 0), (48, 4, 512, 512, 4, 0, 0),
     (33, 1, 128, 48, 4, 3, 0), (9, 4, 80, 32, 4, 0, 0), (2, 32, 16, 8, 3, 1, 0), (3, 128, 8, 8, 3, 1, 0), (5, 8, 8, 16, 3, 1, 0),
-    (2, 4, 8, 8, 3, 1, 0), (2, 64, 16, 8, 3, 1, 1), (1, 32, 8, 8, 3, 1, 1),
+    (2, 4, 8, 8, 3, 1, 0), (2, 64, 16, 8, 3, 1, 1), (1, 32, 8, 8, 3, 1, 1), (2, 32, 32, 16, 3, 1, 0), (1, 64, 32, 8, 3, 1, 0),
+    (2, 64, 16, 16, 3, 1, 1),
 ]
 
 
@@ -60,7 +61,7 @@ def test_conv2d_fwd_and_masked(case):
 
 POOL_CASES = [(2, 32, 64, 64), (3, 16, 128, 96), (2, 64, 16, 16), (1, 64, 8, 8), (2, 32, 8, 16), (2, 16, 12, 20), (5, 4, 32, 16),
               (3, 8, 528, 512), (1, 256, 8, 16), (3, 128, 16, 32), (2, 64, 32, 64), (9, 16, 256, 256), (3, 32, 256, 512), (1, 8, 64, 32),
-              (2, 2, 16, 16)]
+              (2, 2, 16, 16), (2, 32, 16, 16), (1, 64, 32, 16), (3, 32, 8, 16)]
 
 
 @pytest.mark.parametrize('case', POOL_CASES)
