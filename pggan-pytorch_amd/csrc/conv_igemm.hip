@@ -1104,11 +1104,12 @@ int launch_wgrad(WgP& p, hipStream_t s)
     if (red > smem) smem = red;
     const int gy = (p.Cout + BCO - 1) / BCO, gz_ = (p.Cin + BCI - 1) / BCI;
     int chunks = (512 + gy * gz_ - 1) / (gy * gz_);        // ~512 workgroups: fills 256 CUs twice over while
+    if (g_tune[2] > 0) chunks = g_tune[2];                 // (tuning sweep)
     if (chunks > g.ntiles) chunks = g.ntiles;              // keeping the commit traffic (chunks x |dW|) small
     if (chunks < 1) chunks = 1;
     p.tiles_per_block = (g.ntiles + chunks - 1) / chunks;
     chunks = (g.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
-    p.atomic = chunks > 1 ? 1 : 0;
+    p.atomic = 1;        // fire-and-forget L2 atomics even for a sole writer: a load-add-store commit serialises on the load latency (+5 us per launch)
     auto kern = conv_wgrad_kernel<KS, WM, WN, WAVES_CO, WAVES_CI, BPX>;
     if (int rc = set_smem(kern, smem)) return rc;
     snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_wgrad_kernel<%d, %d, %d, %d, %d, %d>", KS, WM, WN, WAVES_CO, WAVES_CI, BPX);
