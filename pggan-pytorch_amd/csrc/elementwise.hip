@@ -244,6 +244,41 @@ __global__ __launch_bounds__(256) void pixelnorm_tangent_kernel(const float* __r
     }
 }
 
+// Narrow layers (C = 8 / 16: the 512^2 and 1024^2 stages, where this kernel moves the most bytes): one thread per
+// pixel keeps the whole channel vector of gy and y in registers -- one pass, no shuffles, no re-read.
+template <int C4>
+__global__ __launch_bounds__(256) void pixelnorm_lrelu_bwd_narrow_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                                         const float* __restrict__ r, const float* __restrict__ inj,
+                                                                         float* __restrict__ gz, size_t P, float slope)
+{
+    constexpr int C = 4 * C4;
+    for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < P; pix += (size_t)gridDim.x * 256) {
+        float4 g[C4], v[C4];
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            g[c] = reinterpret_cast<const float4*>(gy + pix * C)[c];
+            v[c] = reinterpret_cast<const float4*>(y + pix * C)[c];
+        }
+        float rr = 1.f, mean = 0.f;
+        if (r) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < C4; ++c) s += g[c].x * v[c].x + g[c].y * v[c].y + g[c].z * v[c].z + g[c].w * v[c].w;
+            rr = r[pix]; mean = s / (float)C;
+        }
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            float4 o;
+            o.x = rr * (g[c].x - v[c].x * mean); o.y = rr * (g[c].y - v[c].y * mean);
+            o.z = rr * (g[c].z - v[c].z * mean); o.w = rr * (g[c].w - v[c].w * mean);
+            if (inj) { const float4 q = reinterpret_cast<const float4*>(inj + pix * C)[c]; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+            o.x *= v[c].x > 0.f ? 1.f : slope; o.y *= v[c].y > 0.f ? 1.f : slope;
+            o.z *= v[c].z > 0.f ? 1.f : slope; o.w *= v[c].w > 0.f ? 1.f : slope;
+            reinterpret_cast<float4*>(gz + pix * C)[c] = o;
+        }
+    }
+}
+
 inline int pick_lpp(int C) { int c4 = C >> 2; int l = 1; while (l < c4 && l < 64) l <<= 1; return l; }
 
 // ------------------------------------------------------------------------------ minibatch stddev
@@ -618,9 +653,15 @@ extern "C" int pg_pixelnorm_lrelu_bwd(const float* gy, const float* y, const flo
 {
     if (!gy || !y || !gz || P <= 0 || C <= 0) return PG_E_ARG;
     if (C & 3) return PG_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 8 || C == 16) {
+        const int g = grid_for((size_t)P, 256, 1 << 20);
+        if (C == 8) hipLaunchKernelGGL(pixelnorm_lrelu_bwd_narrow_kernel<2>, dim3(g), dim3(256), 0, s, gy, y, r, (const float*)nullptr, gz, (size_t)P, slope);
+        else hipLaunchKernelGGL(pixelnorm_lrelu_bwd_narrow_kernel<4>, dim3(g), dim3(256), 0, s, gy, y, r, (const float*)nullptr, gz, (size_t)P, slope);
+        return (int)hipGetLastError();
+    }
     const int lpp = pick_lpp(C);
     const int grid = grid_for((size_t)P * lpp);
-    hipStream_t s = (hipStream_t)stream;
     switch (lpp) {
 #define CASE(L) case L: hipLaunchKernelGGL(pixelnorm_lrelu_bwd_kernel<L>, dim3(grid), dim3(256), 0, s, gy, y, r, (const float*)nullptr, gz, (size_t)P, C, slope); break;
         CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
@@ -634,9 +675,15 @@ extern "C" int pg_pixelnorm_lrelu_bwd_inj(const float* gy, const float* y, const
 {
     if (!gy || !y || !r || !inj || !gz || P <= 0 || C <= 0) return PG_E_ARG;
     if (C & 3) return PG_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 8 || C == 16) {
+        const int g = grid_for((size_t)P, 256, 1 << 20);
+        if (C == 8) hipLaunchKernelGGL(pixelnorm_lrelu_bwd_narrow_kernel<2>, dim3(g), dim3(256), 0, s, gy, y, r, inj, gz, (size_t)P, slope);
+        else hipLaunchKernelGGL(pixelnorm_lrelu_bwd_narrow_kernel<4>, dim3(g), dim3(256), 0, s, gy, y, r, inj, gz, (size_t)P, slope);
+        return (int)hipGetLastError();
+    }
     const int lpp = pick_lpp(C);
     const int grid = grid_for((size_t)P * lpp);
-    hipStream_t s = (hipStream_t)stream;
     switch (lpp) {
 #define CASE(L) case L: hipLaunchKernelGGL(pixelnorm_lrelu_bwd_kernel<L>, dim3(grid), dim3(256), 0, s, gy, y, r, inj, gz, (size_t)P, C, slope); break;
         CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)

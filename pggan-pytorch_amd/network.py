@@ -171,10 +171,18 @@ class _FlatParamsMixin(object):
         if not params:
             return
         dev = params[0].device
-        offs, total = [], 0
-        for p in params:
-            offs.append(total)
-            total += (p.numel() + 3) // 4 * 4               # keep every view 16-byte aligned
+        # Layout: 3x3/4x4 conv layers (+ linear) in module order first, the to/fromRGB layers last.  At any depth the
+        # active conv layers are then ONE contiguous run of the buffer (blocks are ordered by resolution), so
+        # FusedAdam updates them with a single launch instead of one per gap left by an inactive RGB layer.
+        rgb = set()
+        for m in self.modules():
+            if isinstance(m, PGConv2d) and m.kind != 'conv':
+                rgb.update((id(m.conv.weight), id(m.conv.bias)))
+        order = [i for i, p in enumerate(params) if id(p) not in rgb] + [i for i, p in enumerate(params) if id(p) in rgb]
+        offs, total = [0] * len(params), 0
+        for i in order:
+            offs[i] = total
+            total += (params[i].numel() + 3) // 4 * 4       # keep every view 16-byte aligned
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         with torch.no_grad():
             for p, o in zip(params, offs):
