@@ -209,7 +209,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-per-depth', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--graphs', action='store_true', help='replay the step from captured hipGraphs (graphs.py); default is\n                    eager two-stream launching, which measured faster at every growth stage')
+    ap.add_argument('--graphs', action='store_true', help='replay every stage from captured hipGraphs (graphs.py); default: only the launch-bound 4x4 stage, eager two-stream launching elsewhere (measured faster)')
     ap.add_argument('--serial-kernel-timing', action='store_true', help='instrumented passes with the weight-gradient stream off '
                     '(isolated per-kernel durations instead of the durations inside the two-stream step)')
     ap.add_argument('--kernel-table', action='store_true', help='per-layer conv timing table on stderr')
@@ -219,7 +219,7 @@ def main():
     if os.environ.get('PGGAN_TUNE'):                       # kernel A/B aid: "key=value,..." -> pg_debug_set_tuning
         for kv in os.environ['PGGAN_TUNE'].split(','):
             pg._lib.load().pg_debug_set_tuning(*[int(v) for v in kv.split('=')])
-    pg.wgan_gp_loss.enable_graphs(args.graphs)              # replayed whenever alpha == 1 (graphs.py)
+    pg.wgan_gp_loss.enable_graphs(True if args.graphs else 'auto')   # 'auto': hipGraph replay only at the launch-bound 4x4 stage
     world = int(os.environ.get('WORLD_SIZE', '1'))
     force_dp = os.environ.get('PGGAN_FORCE_DP', '') == '1'      # one-rank RCCL group: smoke test of the DP code path
     dp = pg.parallel.DataParallel.from_env(force=force_dp) if (world > 1 or force_dp) else None
@@ -254,7 +254,7 @@ def main():
         out['step_algorithmic_gflop_per_image'] = W / 1e9
         out['step_mfma_frac'] = W * (value / n_gpus) / MFMA_F32_PEAK
 
-    out['config']['hip_graphs'] = bool(args.graphs and args.alpha >= 1.0)
+    out['config']['hip_graphs'] = bool((args.graphs or depth == 0) and args.alpha >= 1.0)
     if rank == 0 and not args.no_kernel_timing:
         psteps = 3
         pg.wgan_gp_loss.enable_graphs(False)               # per-launch HIP events need eager launches
@@ -292,7 +292,7 @@ def main():
         pg.wgan_gp_loss.enable_graphs(False)
         for _ in range(3):                                  # keep collectives matched with rank 0
             tr.train()
-    pg.wgan_gp_loss.enable_graphs(args.graphs)
+    pg.wgan_gp_loss.enable_graphs(True if args.graphs else 'auto')
 
     if not args.no_per_depth and dp is None:
         per = []

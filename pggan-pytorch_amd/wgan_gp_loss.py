@@ -12,16 +12,25 @@ from . import engine
 # wgan_gp_loss.py:4-5 keeps module-global scratch; the only state kept here is the injectable RNG.
 mixing_factors = None
 _generator = None
-_use_graphs = False
+_use_graphs = 'auto'        # 'auto': replay only where the step is launch-bound (the 4x4 stage); True / False force it
 
 
 def enable_graphs(flag=True):
-    """Replay the D-step / G-step schedules from captured hipGraphs whenever alpha == 1 (see graphs.py)."""
+    """Replay the D-step / G-step schedules from captured hipGraphs whenever alpha == 1 (see graphs.py).
+    ``'auto'`` (default) does so only at depth 0: measured on MI355X the 4x4 stage (~100 launches of ~10 us) is
+    launch-bound and replays 1.44x faster, while from 8x8 on eager two-stream launching is faster (the replay
+    serialises the weight-gradient stream)."""
     global _use_graphs
-    _use_graphs = bool(flag)
+    _use_graphs = 'auto' if flag == 'auto' else bool(flag)
     if not flag:
         from . import graphs
         graphs.clear()
+
+
+def _graphs_on(net):
+    if _use_graphs == 'auto':
+        return int(net.depth) == 0
+    return bool(_use_graphs)
 
 
 def set_mixing_factors(m):
@@ -84,7 +93,7 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
         mixing_factors = None
     else:                                                                # :15-17 (device RNG)
         mix = torch.rand((n, 1), device=real_images_in.device, dtype=torch.float32, generator=_generator)
-    if _use_graphs and float(D.alpha) >= 1.0 and real_images_in.is_cuda:
+    if _graphs_on(D) and float(D.alpha) >= 1.0 and real_images_in.is_cuda:
         from . import graphs
         real_c = engine._check_dev(real_images_in, 'real images')
         z_c = engine._check_dev(fake_latents_in, 'latents')
@@ -105,7 +114,7 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
 def wgan_gp_G_loss(G, D, fake_latents_in):
     """reference wgan_gp_loss.py:68-74."""
     G.zero_grad()                                                        # :69
-    if _use_graphs and float(G.alpha) >= 1.0 and fake_latents_in.is_cuda:
+    if _graphs_on(G) and float(G.alpha) >= 1.0 and fake_latents_in.is_cuda:
         from . import graphs
         g_cost = graphs.g_step(G, D, engine._check_dev(fake_latents_in, 'latents'))
         return LossTensor.wrap(g_cost, _graphed_backward)
