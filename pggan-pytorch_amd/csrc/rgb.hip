@@ -469,7 +469,9 @@ extern "C" int pg_fromrgb_wgrad(const float* gz, const float* img, float* dw, fl
         else hipLaunchKernelGGL(fromrgb_wgrad_small_kernel<32>, dim3(g), dim3(256), 0, s, gz, img, dw, db, N, C, H, W, pool, scale);
         return (int)hipGetLastError();
     }
-    int blocks = grid_for(total, 4, 1024);        // >= 4 pixels per workgroup: the 4x4 / 8x8 stages still fill the chip
+    // every workgroup ends with Cout*(C+1) atomics: >= 4 pixels per workgroup so the 4x4 stage still fills the chip,
+    // ~128 workgroups beyond that so the atomics do not dominate (8x8 .. 32x32 stages)
+    int blocks = grid_for(total, 4, total < 4096 ? 128 : (total < 12288 ? 256 : 512));      // measured (tools/bench_rgb_wgrad.py)
     const int ppb = (int)((total + blocks - 1) / blocks);
     blocks = (int)((total + ppb - 1) / ppb);
     hipLaunchKernelGGL(fromrgb_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -515,7 +517,7 @@ extern "C" int pg_torgb_wgrad(const float* g, const float* x, float* dw, float* 
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cin & 3) return PG_E_ALIGN;
     const size_t total = (size_t)N * H * W;
-    int blocks = grid_for(total, 4, 1024);
+    int blocks = grid_for(total, 4, total < 8192 ? 256 : (total < 32768 ? 512 : 1024));     // Cin*C atomics per workgroup
     const int ppb = (int)((total + blocks - 1) / blocks);
     blocks = (int)((total + ppb - 1) / ppb);
     hipLaunchKernelGGL(torgb_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
