@@ -1,7 +1,7 @@
-"""Offline: replay the conv tile cost model against gpurun_out/sweep_all.txt and report regret."""
+"""Offline: replay the conv tile cost model against profiles/r01_conv_tile_sweep.txt and report regret."""
 import re, sys, math, itertools
 rows = []
-for l in open('gpurun_out/sweep_all.txt'):
+for l in open('profiles/r01_conv_tile_sweep.txt'):
     m = re.match(r'n(\d+)\s+@(\d+)\s+(\d+)->(\d+)\s+auto\s+([\d.]+)us', l)
     if not m: continue
     N, H, ci, co = [int(m.group(i)) for i in range(1, 5)]
