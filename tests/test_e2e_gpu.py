@@ -174,20 +174,22 @@ def test_trainer_trace_golden():
                 assert rel_err(v.cpu(), data['%s/%s' % (pre, k)]) < 5e-3, k
 
 
-@pytest.mark.parametrize('res,depth,alpha,n,fmap_base', [(128, 5, 1.0, 2, 4096), (128, 4, 0.5, 3, 4096),
-                                                         (1024, 8, 1.0, 1, 4096), (256, 6, 0.25, 2, 8192)])
-def test_against_oracle_at_baseline_widths(oracle, res, depth, alpha, n, fmap_base):
-    """HIP vs CPU oracle on seeded inputs at BASELINE.json widths (default 4096 and the paper's 8192)."""
+@pytest.mark.parametrize('res,depth,alpha,n,fmap_base,C', [(128, 5, 1.0, 2, 4096, 3), (128, 4, 0.5, 3, 4096, 3),
+                                                           (1024, 8, 1.0, 1, 4096, 3), (256, 6, 0.25, 2, 8192, 3),
+                                                           (256, 6, 1.0, 2, 4096, 1), (1024, 7, 0.5, 1, 4096, 3)])
+def test_against_oracle_at_baseline_widths(oracle, res, depth, alpha, n, fmap_base, C):
+    """HIP vs CPU oracle on seeded inputs at BASELINE.json widths (default 4096 and the paper's 8192), incl. the
+    one-channel 256^2 spectrogram shape of config 4 and a fade-in stage of the 1024^2 net."""
     torch.manual_seed(1337)
-    shape = (1, 3, res, res)
+    shape = (1, C, res, res)
     G = pg.Generator(shape, fmap_base=fmap_base)
     D = pg.Discriminator(shape, fmap_base=fmap_base)
     gp, dp = G.reference_state_dict(), D.reference_state_dict()
     G.to(DEV); D.to(DEV)
-    cfg = oracle.NetCfg(res, 3, fmap_base=fmap_base)
+    cfg = oracle.NetCfg(res, C, fmap_base=fmap_base)
     G.depth = D.depth = depth
     G.alpha = D.alpha = alpha
-    real, z_d, z_g, mix = oracle.synthetic_batch(42 + depth, n, 3, 4 * 2 ** depth, 512)
+    real, z_d, z_g, mix = oracle.synthetic_batch(42 + depth, n, C, 4 * 2 ** depth, 512)
     pg.wgan_gp_loss.set_mixing_factors(mix)
     d_cost, d_real_loss, d_fake_loss = pg.wgan_gp_D_loss(D, G, real.to(DEV), z_d.to(DEV))
     d_cost.backward()
