@@ -1128,7 +1128,10 @@ template <int CO, int CI, int BPX>
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
 {
     constexpr int KS = 3, TAPS = 9;
-    constexpr int QO = CO / 4, QI = CI / 4, NB = QO * QI, PPM = 16 / NB;     // pixels per MFMA
+    constexpr int QO = CO / 4, QI = CI / 4, NB = QO * QI;
+    constexpr int PPM = NB <= 16 ? 16 / NB : 1;                  // pixels per MFMA
+    constexpr int GQ = NB <= 16 ? 1 : NB / 16;                   // MFMAs (groups of 16 blocks) per pixel and tap
+    static_assert(NB <= 16 || (16 % QI) == 0, "the B operand must be shared by the block groups");
     constexpr int SZ = PixStride<CO>::value, SX = PixStride<CI>::value;
     constexpr int ZV = CO / 4, XV = CI / 4;
     constexpr int ZPT = (BPX * ZV + 255) / 256;
@@ -1143,13 +1146,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = lane >> 2, i4 = lane & 3;
-    const int hi = blk % QI, ho = (blk / QI) % QO, slot = blk / NB;
+    const int hi = blk % QI, slot = NB <= 16 ? blk / NB : 0;     // group q of this lane: cout quad (16q + blk) / QI
+    int ho[GQ];
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) ho[q] = ((16 * q + blk) / QI) % QO;
     const bool do_bias = p.db != nullptr;
 
-    f32x4 acc[TAPS];
+    f32x4 acc[GQ][TAPS];
+    float bsum[GQ];
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
+    for (int q = 0; q < GQ; ++q) {
+        bsum[q] = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) acc[q][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const int npix = p.TN * HT * WT;
     const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
@@ -1226,20 +1236,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
         __syncthreads();
         if (tile + 1 < t_end) fetch(tile + 1);
 
-        auto load_frags = [&](int step, float& af, float (&bf)[TAPS]) {
+        auto load_frags = [&](int step, float (&af)[GQ], float (&bf)[TAPS]) {
             const int q = PPM * step + slot;
             const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
-            af = gzt[q * SZ + 4 * ho + i4];
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) af[g] = gzt[q * SZ + 4 * ho[g] + i4];
             const int bo = ((tn * HT + th) * WT + tw) * SX + 4 * hi + i4;
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp) bf[tp] = xt[bo + tapoff[tp]];
         };
-        auto mfmas = [&](float af, const float (&bf)[TAPS]) {
-            bsum += af;
+        auto mfmas = [&](const float (&af)[GQ], const float (&bf)[TAPS]) {
 #pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) acc[tp] = __builtin_amdgcn_mfma_f32_4x4x1f32(af, bf[tp], acc[tp], 0, 0, 0);
+            for (int g = 0; g < GQ; ++g) {
+                bsum[g] += af[g];
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) acc[g][tp] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[g], bf[tp], acc[g][tp], 0, 0, 0);
+            }
         };
-        float a[2], b[2][TAPS];
+        float a[2][GQ], b[2][TAPS];
         static_assert(T % 2 == 0, "k-steps per wave must be even");
         load_frags(wave, a[0], b[0]);
         for (int s2 = 0; s2 < T; s2 += 2) {
@@ -1257,32 +1271,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
 
     // ---- sum the pixel slots (lanes 4*NB apart), then the 4 waves through LDS, then ONE commit per workgroup
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[tp][r];
-            if (PPM >= 2) v += __shfl_xor(v, 32, 64);
-            if (PPM >= 4) v += __shfl_xor(v, 16, 64);
-            acc[tp][r] = v;
-        }
-    if (PPM >= 2) bsum += __shfl_xor(bsum, 32, 64);
-    if (PPM >= 4) bsum += __shfl_xor(bsum, 16, 64);
-    constexpr int NL = 4 * NB;                                   // lanes holding distinct results
-    float* red = lds;                                            // [wave][TAPS*4 + 1][NL]
-    if (lane < NL) {
+    for (int g = 0; g < GQ; ++g) {
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(wave * (TAPS * 4 + 1) + tp * 4 + r) * NL + lane] = acc[tp][r];
-        red[(wave * (TAPS * 4 + 1) + TAPS * 4) * NL + lane] = bsum;
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[g][tp][r];
+                if (PPM >= 2) v += __shfl_xor(v, 32, 64);
+                if (PPM >= 4) v += __shfl_xor(v, 16, 64);
+                acc[g][tp][r] = v;
+            }
+        if (PPM >= 2) bsum[g] += __shfl_xor(bsum[g], 32, 64);
+        if (PPM >= 4) bsum[g] += __shfl_xor(bsum[g], 16, 64);
+    }
+    constexpr int NL = NB <= 16 ? 4 * NB : 64;                   // lanes holding distinct results
+    constexpr int NE = GQ * (TAPS * 4 + 1);                      // values per lane: [group][tap*4 + r | bias]
+    float* red = lds;                                            // [wave][NE][NL]
+    if (lane < NL) {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wave * NE + g * (TAPS * 4 + 1) + tp * 4 + r) * NL + lane] = acc[g][tp][r];
+            red[(wave * NE + g * (TAPS * 4 + 1) + TAPS * 4) * NL + lane] = bsum[g];
+        }
     }
     __syncthreads();
-    // thread t < (TAPS*4+1)*NL sums the four waves and commits one element
-    for (int e = tid; e < (TAPS * 4 + 1) * NL; e += 256) {
-        const int l = e % NL, slot_e = e / NL;                   // slot_e = tp*4 + r, or TAPS*4 for the bias
-        const float v = (red[e] + red[e + (TAPS * 4 + 1) * NL]) + (red[e + 2 * (TAPS * 4 + 1) * NL] + red[e + 3 * (TAPS * 4 + 1) * NL]);
+    // one thread per element sums the four waves and commits
+    for (int e = tid; e < NE * NL; e += 256) {
+        const int l = e % NL, ve = e / NL;
+        const int g = ve / (TAPS * 4 + 1), slot_e = ve % (TAPS * 4 + 1);   // slot_e = tp*4 + r, or TAPS*4 for the bias
+        const float v = (red[e] + red[e + NE * NL]) + (red[e + 2 * NE * NL] + red[e + 3 * NE * NL]);
         const int b_ = l >> 2, j = l & 3;
-        const int hi_ = b_ % QI, ho_ = (b_ / QI) % QO;
+        const int hi_ = b_ % QI, ho_ = ((16 * g + b_) / QI) % QO;
         if (slot_e < TAPS * 4) {
             const int tp = slot_e >> 2, r = slot_e & 3;
             float* dst = p.dw + ((size_t)(tp * CO + 4 * ho_ + r) * CI + 4 * hi_ + j);
@@ -1302,9 +1324,10 @@ int launch_wgrad_thin(WgP& p, hipStream_t s)
     const int HT = (1 << g.lgTH) + 2, WT = (1 << g.lgTW) + 2;
     if (g.TN * HT * WT > (BPX * 9) / 4) return PG_E_UNSUP;
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
-    const int sz = p.Cout == 8 ? 24 : 16, sx = p.Cin == 8 ? 24 : 16;           // PixStride<8>, PixStride<16>
+    const int sz = p.Cout == 16 ? 16 : p.Cout + 16, sx = p.Cin == 16 ? 16 : p.Cin + 16;      // PixStride<C>
     size_t smem = ((size_t)BPX * sz + (size_t)g.TN * HT * WT * sx) * sizeof(float);
-    const size_t red = (size_t)4 * 37 * 64 * sizeof(float);
+    const int nb = (p.Cout / 4) * (p.Cin / 4);
+    const size_t red = (size_t)4 * (nb <= 16 ? 1 : nb / 16) * 37 * (nb <= 16 ? 4 * nb : 64) * sizeof(float);   // [wave][NE][NL]
     if (red > smem) smem = red;
     int chunks = 1024; if (chunks > g.ntiles) chunks = g.ntiles;
     p.tiles_per_block = (g.ntiles + chunks - 1) / chunks;
@@ -1316,6 +1339,8 @@ int launch_wgrad_thin(WgP& p, hipStream_t s)
     if (p.Cout == 8 && p.Cin == 8) THIN(8, 8)
     else if (p.Cout == 16 && p.Cin == 8) THIN(16, 8)
     else if (p.Cout == 8 && p.Cin == 16) THIN(8, 16)
+    else if (p.Cout == 32 && p.Cin == 16) THIN(32, 16)
+    else if (p.Cout == 16 && p.Cin == 32) THIN(16, 32)
     else return PG_E_UNSUP;
 #undef THIN
     return (int)hipGetLastError();
@@ -1329,6 +1354,11 @@ int dispatch_wgrad(WgP& p, hipStream_t s)
     } else {
         const long long M = (long long)p.N * p.Hout * p.Wout;
         if (M <= 32) return launch_wgrad<KS, 1, 1, 2, 2, 16>(p, s);
+        if constexpr (KS == 3) {
+            // measured (tools/sweep_wgrad_thin.py): block-MFMA wins on 32 -> 16 always, on 16 -> 32 below ~1.5 M pixels
+            if (g_tune[1] != 8 && ((p.Cout == 16 && p.Cin == 32) || (p.Cout == 32 && p.Cin == 16 && M < 1500000)))
+                return launch_wgrad_thin<64>(p, s);
+        }
         if (p.Cout <= 16 && p.Cin <= 16) {
             if constexpr (KS == 3) {
                 // 8-channel sides: the 16x16x4 tile would be 50-75 % padding -> 4x4x1 block MFMA kernel

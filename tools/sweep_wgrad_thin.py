@@ -4,8 +4,8 @@ sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg
 ops, lib = pg.ops, pg._lib.load()
-cfgs = [int(v) for v in sys.argv[1:]] or [-1, 8, 9]
-SHAPES = [(9, 1024, 8, 8), (3, 1024, 8, 8), (9, 1024, 8, 16), (3, 1024, 16, 8), (9, 512, 16, 16), (3, 512, 16, 16), (6, 512, 16, 16)]
+cfgs = [int(v) for v in sys.argv[1:]] or [-1, 9]
+SHAPES = [(9, 1024, 8, 8), (9, 1024, 8, 16), (9, 512, 16, 16), (3, 512, 16, 16), (6, 512, 16, 16), (9, 512, 16, 32), (3, 512, 16, 32), (3, 512, 32, 16), (6, 512, 32, 16), (14, 256, 16, 16), (2, 64, 16, 32)]
 def run(f, reps=10):
     for _ in range(2): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
