@@ -86,6 +86,11 @@ int pg_debug_set_tuning(int key, int value);
  * [KS][KS][Cin][Cout] (spatially flipped, channels transposed).                               */
 int pg_pack_dgrad_weights(const float* w, float* wt, int KS, int Cout, int Cin, pg_stream_t stream);
 
+/* The same for `nlayers` layers of one network in a single launch: layer l lives at element offset off[l] of the flat
+ * weight buffer `wbase` and of its mirror `wtbase` (host arrays off/ks/cout/cin are read before the call returns). */
+int pg_pack_dgrad_weights_batched(const float* wbase, float* wtbase, int nlayers, const int64_t* off,
+                                  const int* ks, const int* cout, const int* cin, pg_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * fromRGB: 1x1 conv from an NCHW image (C_img in {1,3,4}) to NHWC features, fused LeakyReLU.
  * Replaces DBlock/DLastBlock.fromRGB  network.py:145,160 (+ F.avg_pool2d(x,2) network.py:231 when

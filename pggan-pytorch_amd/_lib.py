@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class PgganLibraryError(RuntimeError):
@@ -30,6 +30,7 @@ SIGNATURES = {
     'pg_debug_last_conv_kernel': [],
     'pg_debug_set_tuning': [I, I],
     'pg_pack_dgrad_weights': [P, P, I, I, I, P],
+    'pg_pack_dgrad_weights_batched': [P, P, I, P, P, P, P, P],
     'pg_fromrgb_fwd': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
     'pg_fromrgb_bwd_data': [P, P, P, I, I, I, I, I, I, I, F, P],
     'pg_fromrgb_wgrad': [P, P, P, P, I, I, I, I, I, I, F, P],

@@ -927,6 +927,42 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+// All layers of a network in ONE launch (the weights live in one flat buffer, the packed copies in its mirror).
+constexpr int PACK_MAX_LAYERS = 32;
+struct PackDesc {
+    int n;
+    int first_block[PACK_MAX_LAYERS + 1];          // prefix sum of the per-layer block counts
+    long long off[PACK_MAX_LAYERS];                // element offset of the layer in both flat buffers
+    int ks[PACK_MAX_LAYERS], cout[PACK_MAX_LAYERS], cin[PACK_MAX_LAYERS];
+};
+
+__global__ void pack_dgrad_batched_kernel(const float* __restrict__ wbase, float* __restrict__ wtbase, PackDesc d)
+{
+    __shared__ float tile[32][33];
+    int l = 0;
+    while (l + 1 < d.n && (int)blockIdx.x >= d.first_block[l + 1]) ++l;
+    const int KS = d.ks[l], Cout = d.cout[l], Cin = d.cin[l];
+    const float* w = wbase + d.off[l];
+    float* wt = wtbase + d.off[l];
+    int b = blockIdx.x - d.first_block[l];
+    const int nbx = (Cin + 31) / 32, nby = (Cout + 31) / 32;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby; const int tap = b / nby;
+    const int kh = tap / KS, kw = tap % KS;
+    const int otap = (KS - 1 - kh) * KS + (KS - 1 - kw);
+    const int ci_b = bx * 32, co_b = by * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co_b + r, ci = ci_b + tx;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)tap * Cout + co) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci_b + r, co = co_b + tx;
+        if (ci < Cin && co < Cout) wt[((size_t)otap * Cin + ci) * Cout + co] = tile[tx][r];
+    }
+}
+
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -1492,6 +1528,27 @@ extern "C" int pg_debug_set_tuning(int key, int value)
     if (key < 0 || key >= 4) return PG_E_ARG;
     g_tune[key] = value;
     return 0;
+}
+
+extern "C" int pg_pack_dgrad_weights_batched(const float* wbase, float* wtbase, int nlayers, const int64_t* off,
+                                             const int* ks, const int* cout, const int* cin, pg_stream_t stream)
+{
+    if (!wbase || !wtbase || nlayers <= 0 || !off || !ks || !cout || !cin) return PG_E_ARG;
+    for (int l0 = 0; l0 < nlayers; l0 += PACK_MAX_LAYERS) {
+        PackDesc d;
+        d.n = nlayers - l0 < PACK_MAX_LAYERS ? nlayers - l0 : PACK_MAX_LAYERS;
+        int total = 0;
+        for (int l = 0; l < d.n; ++l) {
+            const int i = l0 + l;
+            if (ks[i] <= 0 || cout[i] <= 0 || cin[i] <= 0 || off[i] < 0) return PG_E_ARG;
+            d.first_block[l] = total;
+            d.off[l] = off[i]; d.ks[l] = ks[i]; d.cout[l] = cout[i]; d.cin[l] = cin[i];
+            total += ((cin[i] + 31) / 32) * ((cout[i] + 31) / 32) * ks[i] * ks[i];
+        }
+        d.first_block[d.n] = total;
+        hipLaunchKernelGGL(pack_dgrad_batched_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, wbase, wtbase, d);
+    }
+    return (int)hipGetLastError();
 }
 
 extern "C" int pg_pack_dgrad_weights(const float* w, float* wt, int KS, int Cout, int Cin, pg_stream_t stream)

@@ -40,8 +40,14 @@ def _wt(net, layer):
     net._ensure_buffers()
     ver = net._param_version
     if getattr(layer, '_wt_ver', None) != ver or layer._wt is None:
-        ops.pack_dgrad_weights(layer.conv.weight.data, layer._wt)
-        layer._wt_ver = ver
+        # one launch re-packs every conv layer of the network (they share the flat buffer and its mirror)
+        todo = [m for m in net._layers() if m.kind == 'conv' and m._wt is not None]
+        base = net._flat_param.data_ptr()
+        ops.pack_dgrad_weights_batched(net._flat_param, net._flat_wt,
+                                       [((m.conv.weight.data_ptr() - base) // 4, m.ksize, m.conv.weight.shape[2],
+                                         m.conv.weight.shape[3]) for m in todo])
+        for m in todo:
+            m._wt_ver = ver
     return layer._wt
 
 

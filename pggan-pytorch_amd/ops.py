@@ -67,6 +67,18 @@ def pack_dgrad_weights(w, wt):
     return wt
 
 
+def pack_dgrad_weights_batched(flat_w, flat_wt, layers):
+    """layers: [(element offset, ks, cout, cin), ...] inside the flat weight buffer / its mirror; one launch."""
+    import ctypes
+    n = len(layers)
+    off = (ctypes.c_int64 * n)(*[l[0] for l in layers])
+    ks = (ctypes.c_int * n)(*[l[1] for l in layers])
+    co = (ctypes.c_int * n)(*[l[2] for l in layers])
+    ci = (ctypes.c_int * n)(*[l[3] for l in layers])
+    _lib.call('pg_pack_dgrad_weights_batched', _p(flat_w), _p(flat_wt), n, ctypes.cast(off, ctypes.c_void_p),
+              ctypes.cast(ks, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), ctypes.cast(ci, ctypes.c_void_p), _stream())
+
+
 # --------------------------------------------------------------------------------- from/toRGB
 def fromrgb_fwd(img, w, bias, N, C, H, W, scale, slope, pool=False, mask=None, mask_slope=0.2):
     cout = w.shape[0]

@@ -57,6 +57,12 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
     return _ret(y, out)
 
 
+def pack_dgrad_weights_batched(flat_w, flat_wt, layers):
+    for off, ks, co, ci in layers:
+        w = flat_w[off:off + ks * ks * co * ci].view(ks, ks, co, ci)
+        pack_dgrad_weights(w, flat_wt[off:off + ks * ks * co * ci].view(ks, ks, ci, co))
+
+
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
                 pool_only=False):
     y = conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=slope, mask=mask, mask_slope=mask_slope)
