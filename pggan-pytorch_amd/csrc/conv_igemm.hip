@@ -1043,6 +1043,180 @@ int launch_conv(ConvP& p, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Small-M layers (4x4 .. 16x16 at minibatch 3: a few hundred output pixels against K = 9*512).  The generic kernel
+// has to slice K across workgroups there (memset + fp32 atomics + a deferred epilogue launch).  Here the FOUR WAVES of a
+// workgroup split K instead: all waves own the same 16-cout x (16*WN)-pixel tile, wave w takes channels
+// [64c + 16w, 64c + 16w + 16) of every 64-channel super-chunk (its own slice of the LDS rows), the four partial
+// accumulators are summed through LDS and wave 0 runs the fused epilogue -- one launch, no atomics.
+template <int WN>
+__global__ __launch_bounds__(256) void conv_ksplit_kernel(ConvP p)
+{
+    constexpr int KS = 3, TAPS = 9, BCO = 16, BPX = 16 * WN, KCP = 24, RS = 4 * KCP;   // LDS row = 4 wave slices
+    constexpr int WEL = TAPS * BCO * 16;                        // float4 per weight super-chunk
+    constexpr int WPT = (WEL + 255) / 256;
+    constexpr int XMAX = BPX <= 16 ? 36 : (BPX * 9) / 4;
+    constexpr int XPT = (XMAX * 16 + 255) / 256;
+    extern __shared__ __align__(16) float lds[];
+    const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
+    const int HT = TH + KS - 1, WT = TW + KS - 1;
+    float* wt = lds;                          // [TAPS][BCO][4][KCP]
+    float* xt = lds + TAPS * BCO * RS;        // [TN*HT*WT][4][KCP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    int t = blockIdx.x;
+    const int tw_i = t % p.tilesW; t /= p.tilesW;
+    const int th_i = t % p.tilesH; t /= p.tilesH;
+    const int n0 = t * p.TN;
+    const int oh0 = th_i << p.lgTH, ow0 = tw_i << p.lgTW;
+    const int co0 = blockIdx.y * BCO;
+
+    int pixbase[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int j = n * 16 + li;
+        const int tw = j & (TW - 1), th = (j >> p.lgTW) & (TH - 1), tn = j >> (p.lgTW + p.lgTH);
+        pixbase[n] = ((tn * HT + th) * WT + tw) * RS + wave * KCP + 4 * kk;
+    }
+    const int wbase = li * RS + wave * KCP + 4 * kk;
+
+    const int npix = p.TN * HT * WT;
+    int wsrc[WPT], wdst[WPT], xsrc[XPT], xdst[XPT], wch[WPT], xch[XPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 4, v = idx & 15;                   // row (tap, cout), float4 index inside the 64 channels
+        const int tap = r / BCO, col = r - tap * BCO, co = co0 + col;
+        wdst[i] = idx < WEL ? r * RS + (v >> 2) * KCP + 4 * (v & 3) : -1;
+        wsrc[i] = (idx < WEL && co < p.Cout) ? (tap * p.Cout + co) * p.Cin : -1;
+        wch[i] = 4 * v;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx >> 4, v = idx & 15;
+        const int r2 = (int)__umulhi((unsigned)q, p.mWT), tw = q - r2 * WT;
+        const int tn = (int)__umulhi((unsigned)r2, p.mHT), th = r2 - tn * HT;
+        const int n = n0 + tn;
+        const int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
+        const bool in_tile = q < npix;
+        const bool ok = in_tile && n < p.N && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        xdst[i] = in_tile ? q * RS + (v >> 2) * KCP + 4 * (v & 3) : -1;
+        xsrc[i] = ok ? ((n * p.Hin + ih) * p.Win + iw) * p.Cin : -1;
+        xch[i] = 4 * v;
+    }
+    int tapoff[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) tapoff[tp] = ((tp / KS) * WT + (tp % KS)) * RS;
+
+    f32x4 acc[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsuper = (p.Cin + 63) >> 6;
+    float4 wreg[WPT], xreg[XPT];
+    auto fetch = [&](int sc) {
+        const int k0 = sc << 6;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            wreg[i] = (wsrc[i] >= 0 && k0 + wch[i] < p.Cin) ? *reinterpret_cast<const float4*>(p.w + (size_t)(unsigned)(wsrc[i] + k0 + wch[i]))
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+            xreg[i] = (xsrc[i] >= 0 && k0 + xch[i] < p.Cin) ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)(xsrc[i] + k0 + xch[i]))
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+    for (int sc = 0; sc < nsuper; ++sc) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) if (wdst[i] >= 0) *reinterpret_cast<float4*>(wt + wdst[i]) = wreg[i];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) if (xdst[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
+        __syncthreads();
+        if (sc + 1 < nsuper) fetch(sc + 1);
+        float a[2][4], b[2][WN][4];
+        lds_load<4>(wt + wbase, a[0]);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) lds_load<4>(xt + pixbase[n] + tapoff[0], b[0][n]);
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+            const int cur = tp & 1, nxt = cur ^ 1;
+            if (tp + 1 < TAPS) {
+                lds_load<4>(wt + (tp + 1) * BCO * RS + wbase, a[nxt]);
+#pragma unroll
+                for (int n = 0; n < WN; ++n) lds_load<4>(xt + pixbase[n] + tapoff[tp + 1], b[nxt][n]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) acc[n] = MFMA16(a[cur][s4], b[cur][n][s4], acc[n]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // ---- sum the four K slices through LDS; wave 0 finishes
+    float* red = lds;                                           // [3][WN][64][4]
+    if (wave > 0) {
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+            *reinterpret_cast<float4*>(red + (((wave - 1) * WN + n) * 64 + lane) * 4) = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int cb = co0 + 4 * kk;
+    if (cb >= p.Cout) return;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + cb);
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        float4 sacc = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(red + ((w * WN + n) * 64 + lane) * 4);
+            sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+        }
+        const int j = n * 16 + li;
+        const int tw = j & (TW - 1), th = (j >> p.lgTW) & (TH - 1), tn = j >> (p.lgTW + p.lgTH);
+        const int ni = n0 + tn;
+        if (ni >= p.N) continue;
+        const size_t off = (((size_t)ni * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * p.Cout + cb;
+        float4 o = make_float4(sacc.x * p.scale, sacc.y * p.scale, sacc.z * p.scale, sacc.w * p.scale);
+        if (p.mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
+            o.x *= mk.x > 0.f ? 1.f : p.mask_slope; o.y *= mk.y > 0.f ? 1.f : p.mask_slope;
+            o.z *= mk.z > 0.f ? 1.f : p.mask_slope; o.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+        } else {
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+            o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
+            o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+        }
+        *reinterpret_cast<float4*>(p.y + off) = o;
+    }
+}
+
+template <int WN>
+int launch_ksplit(ConvP& p, hipStream_t s)
+{
+    constexpr int BPX = 16 * WN;
+    TileGeom g = make_geom(p.N, p.Hout, p.Wout, BPX);
+    p.lgTW = g.lgTW; p.lgTH = g.lgTH; p.TN = g.TN; p.tilesW = g.tilesW; p.tilesH = g.tilesH;
+    const int HT = (1 << g.lgTH) + 2, WT = (1 << g.lgTW) + 2;
+    constexpr int XMAX = BPX <= 16 ? 36 : (BPX * 9) / 4;
+    if (g.TN * HT * WT > XMAX) return PG_E_UNSUP;
+    p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
+    size_t smem = (size_t)(9 * 16 + g.TN * HT * WT) * 96 * sizeof(float);
+    const size_t red = (size_t)3 * WN * 256 * sizeof(float);
+    if (red > smem) smem = red;
+    auto kern = conv_ksplit_kernel<WN>;
+    if (int rc = set_smem(kern, smem)) return rc;
+    p.ksplit = 1;
+    dim3 grid(g.ntiles, (p.Cout + 15) / 16);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_ksplit_kernel<%d>", WN);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+    return (int)hipGetLastError();
+}
+
 // Tile-shape selection.  A workgroup (4 waves, one per SIMD) runs for  L = chunks x (MFMA cycles per chunk + per-chunk
 // overhead) + fixed cycles  when it has the CU to itself; r workgroups are resident per CU (LDS / VGPR limited) and
 // share the matrix pipes, so a batch of r workgroups takes max(L, r x MFMA cycles) and the launch takes
@@ -1058,6 +1232,14 @@ int dispatch_conv(ConvP& p, hipStream_t s)
     if constexpr (KS == 4) {
         return launch_conv<KS, VEC, 4, 1, 1>(p, s);               // 16-tap halo: keep the pixel tile small
     } else {
+        if constexpr (VEC == 4) {
+            const long long Mpx = (long long)p.N * p.Hout * p.Wout;
+            if (!p.ups && !p.ypool && p.Cin >= 128 && g_tune[0] < 0 && g_tune[3] != 8 &&
+                ((g_tune[3] == 9 && Mpx <= 2304) || (g_tune[3] != 9 && Mpx <= 576))) {
+                const int rc = Mpx <= 256 ? launch_ksplit<1>(p, s) : launch_ksplit<2>(p, s);
+                if (rc != PG_E_UNSUP) return rc;
+            }
+        }
         static const TileCand cands[] = {{256, 16}, {128, 64}, {128, 32}, {128, 16}, {64, 64}, {64, 32}, {64, 16}, {16, 64}};
         // registers per lane of each instantiation (hipcc 7.2, KS = 3): residency = min(LDS, 512 / vgpr)
         static const int vgpr4[] = {160, 200, 128, 100, 164, 100, 68, 92};

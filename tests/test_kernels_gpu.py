@@ -40,7 +40,8 @@ CONV_CASES = [
     (70, 1, 32, 32, 4, 3, 0), (130, 4, 16, 16, 4, 0, 0), (16, 1, 512, 512, 4, 3, 0), (48, 4, 512, 512, 4, 0, 0),
     (33, 1, 128, 48, 4, 3, 0), (9, 4, 80, 32, 4, 0, 0), (2, 32, 16, 8, 3, 1, 0), (3, 128, 8, 8, 3, 1, 0), (5, 8, 8, 16, 3, 1, 0),
     (2, 4, 8, 8, 3, 1, 0), (2, 64, 16, 8, 3, 1, 1), (1, 32, 8, 8, 3, 1, 1), (2, 32, 32, 16, 3, 1, 0), (1, 64, 32, 8, 3, 1, 0),
-    (2, 64, 16, 16, 3, 1, 1), (2, 64, 32, 16, 3, 1, 1), (3, 32, 16, 32, 3, 1, 0),
+    (2, 64, 16, 16, 3, 1, 1), (2, 64, 32, 16, 3, 1, 1), (3, 32, 16, 32, 3, 1, 0), (3, 4, 256, 64, 3, 1, 0), (9, 8, 128, 48, 3, 1, 0),
+    (5, 4, 528, 512, 3, 1, 0), (1, 16, 144, 32, 3, 1, 0),
 ]
 
 
