@@ -71,6 +71,15 @@ int pg_conv2d_pool_nhwc(const float* x, const float* w, const float* bias, const
                         int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
                         float scale, float slope, float mask_slope, pg_stream_t stream);
 
+/* Backward-data convolution with the ADJOINT of that pool fused into its epilogue (the avg_pool2d backward +
+ * LeakyReLU' mask between two DBlocks in the backward sweep):
+ *   yup[n][2h+dy][2w+dx][c] = 0.25 * up_mul * scale*conv(x,w)[n][h][w][c] * (upmask[n][2h+dy][2w+dx][c] > 0 ? 1 : mask_slope)
+ * `y` ([N][Hout][Wout][Cout]) is scratch: written only when the launch cannot fuse (split-K / small-M / thin
+ * kernels), in which case pg_avgpool2_bwd runs as a second pass.  Bit-identical to that pair.  upmask may be NULL. */
+int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, float* y, float* yup,
+                          int N, int Hin, int Win, int Cin, int Cout, int KS, int pad,
+                          float scale, float up_mul, float mask_slope, pg_stream_t stream);
+
 /* Profiling aid: symbol (as rocprofv3 prints it, e.g. "conv_igemm_kernel<3, 4, 2, 2, 4>") of the conv
  * kernel instantiation most recently launched by the calling thread through the two entry points
  * above ("" before the first launch).  Thread-local; lets bench.py attribute its HIP-event timings

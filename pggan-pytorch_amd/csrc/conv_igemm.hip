@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
-thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling, 10: unfused unpooling
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -53,6 +53,8 @@ struct ConvP {
                                 // committed with fp32 atomics into a pre-zeroed y (epilogue deferred)
     // fused 2x2 average pool of the activated output (pg_conv2d_pool_nhwc): ypool = pool_a * avgpool2(y) + pool_b * pool_other
     float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
+    // fused adjoint of that pool (pg_conv2d_unpool_nhwc): yup[n][2h+dy][2w+dx][c] = 0.25*up_mul * y[n][h][w][c] * lrelu'(upmask[...])
+    float* yup; const float* upmask; float up_mul;
 };
 
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
@@ -250,6 +252,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
                 o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
                 o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
                 o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+            }
+            if (p.yup) {                                         // unpool: four masked copies, y itself is not needed
+                const float k = p.up_mul * 0.25f;
+                const size_t W2 = (size_t)2 * p.Wout;
+                const size_t ubase = (((size_t)ni * 2 * p.Hout + 2 * (oh0 + th)) * W2 + 2 * (ow0 + tw)) * p.Cout + cb;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const size_t uo = ubase + ((size_t)(d >> 1) * W2 + (d & 1)) * p.Cout;
+                    float4 v = make_float4(o.x * k, o.y * k, o.z * k, o.w * k);
+                    if (p.upmask) {
+                        const float4 mk = *reinterpret_cast<const float4*>(p.upmask + uo);
+                        v.x *= mk.x > 0.f ? 1.f : p.mask_slope; v.y *= mk.y > 0.f ? 1.f : p.mask_slope;
+                        v.z *= mk.z > 0.f ? 1.f : p.mask_slope; v.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+                    }
+                    *reinterpret_cast<float4*>(p.yup + uo) = v;
+                }
+                continue;
             }
             if (!(pooling && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
             ov[n] = o;
@@ -1023,6 +1042,7 @@ int launch_conv(ConvP& p, hipStream_t s)
         const int cper = (nchunks + ksplit - 1) / ksplit;
         ksplit = (nchunks + cper - 1) / cper;
     }
+    if (ksplit > 1 && p.yup) return PG_E_UNSUP;          // the unpool epilogue needs complete sums
     p.ksplit = ksplit;
     const size_t npix = (size_t)p.N * p.Hout * p.Wout;
     if (ksplit > 1) {
@@ -1234,7 +1254,7 @@ int dispatch_conv(ConvP& p, hipStream_t s)
     } else {
         if constexpr (VEC == 4) {
             const long long Mpx = (long long)p.N * p.Hout * p.Wout;
-            if (!p.ups && !p.ypool && p.Cin >= 128 && g_tune[0] < 0 && g_tune[3] != 8 &&
+            if (!p.ups && !p.ypool && !p.yup && p.Cin >= 128 && g_tune[0] < 0 && g_tune[3] != 8 &&
                 ((g_tune[3] == 9 && Mpx <= 2304) || (g_tune[3] != 9 && Mpx <= 576))) {
                 const int rc = Mpx <= 256 ? launch_ksplit<1>(p, s) : launch_ksplit<2>(p, s);
                 if (rc != PG_E_UNSUP) return rc;
@@ -1297,6 +1317,9 @@ int dispatch_conv(ConvP& p, hipStream_t s)
     }
 }
 
+// Generic tile kernel only, and only when it runs without split-K (used by the fused unpool epilogue).
+int dispatch_conv_generic_nosplit(ConvP& p, hipStream_t s);
+
 template <int KS>
 int dispatch_conv_vec(ConvP& p, hipStream_t s)
 {
@@ -1304,6 +1327,8 @@ int dispatch_conv_vec(ConvP& p, hipStream_t s)
     if ((p.Cin & 7) == 0) return dispatch_conv<KS, 2>(p, s);
     return dispatch_conv<KS, 1>(p, s);
 }
+
+int dispatch_conv_generic_nosplit(ConvP& p, hipStream_t s) { return dispatch_conv_vec<3>(p, s); }
 
 template <int KS, int WM, int WN, int WAVES_CO, int WAVES_CI, int BPX>
 int launch_wgrad(WgP& p, hipStream_t s)
@@ -1610,10 +1635,14 @@ int dispatch_wgrad(WgP& p, hipStream_t s)
 extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
                                float a, float b, pg_stream_t stream);
 
+extern "C" int pg_avgpool2_bwd(const float* gy, const float* mask, float* gx, int N, int H, int W, int C,
+                               float mul, float mask_slope, pg_stream_t stream);
+
 static int conv2d_impl(const float* x, const float* w, const float* bias, const float* mask, float* y,
                        float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
                        int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
-                       float scale, float slope, float mask_slope, pg_stream_t stream)
+                       float scale, float slope, float mask_slope, pg_stream_t stream,
+                       float* yup = nullptr, const float* upmask = nullptr, float up_mul = 1.f)
 {
     if (!x || !w || !y || N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
     if ((Cin & 3) || (Cout & 3)) return PG_E_ALIGN;
@@ -1632,8 +1661,18 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     const bool fuse_pool = ypool != nullptr && KS == 3 && g_tune[3] != 3;
     p.ypool = fuse_pool ? ypool : nullptr; p.pool_other = pool_other; p.pool_a = pool_a; p.pool_b = pool_b;
     p.pool_only = pool_only;
+    // the unpool epilogue exists in the generic tile kernel only (no split-K): everything else unpools in a second pass
+    const bool fuse_up = yup != nullptr && KS == 3 && g_tune[3] != 10;
+    p.yup = nullptr; p.upmask = upmask; p.up_mul = up_mul;
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    if (fuse_up) {
+        p.yup = yup;
+        rc = dispatch_conv_generic_nosplit(p, s);
+        if (rc == 0) return 0;
+        if (rc != PG_E_UNSUP) return rc;
+        p.yup = nullptr;
+    }
     // measured (tools/sweep_thin8.py): 1.5-1.7x on 8 couts; on 16 couts only the masked 8->16 launch gains (the
     // 16x16x4 tile has no padding there), 32 input channels lose -> those stay on the generic kernel
     const bool thin_ok = KS == 3 && pad == 1 && ((Cout == 8 && (Cin == 8 || Cin == 16)) || (Cout == 16 && Cin == 8 && mask && !ypool)) &&
@@ -1643,6 +1682,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
         if (rc) return rc;
         if (ypool && !p.ypool)
             return pg_avgpool2_fwd(y, pool_other, ypool, N, p.Hout >> 1, p.Wout >> 1, Cout, pool_a, pool_b, stream);
+        if (yup) return pg_avgpool2_bwd(y, upmask, yup, N, p.Hout, p.Wout, Cout, up_mul, mask_slope, stream);
         return 0;
     }
     if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
@@ -1657,6 +1697,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     if (rc) return rc;
     if (ypool && !(fuse_pool && p.ksplit == 1))          // split-K / non-3x3 launches pool in a second pass over y
         return pg_avgpool2_fwd(y, pool_other, ypool, N, p.Hout >> 1, p.Wout >> 1, Cout, pool_a, pool_b, stream);
+    if (yup) return pg_avgpool2_bwd(y, upmask, yup, N, p.Hout, p.Wout, Cout, up_mul, mask_slope, stream);
     return 0;
 }
 
@@ -1666,6 +1707,15 @@ extern "C" int pg_conv2d_nhwc(const float* x, const float* w, const float* bias,
 {
     return conv2d_impl(x, w, bias, mask, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, ups,
                        scale, slope, mask_slope, stream);
+}
+
+extern "C" int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, float* y, float* yup,
+                                     int N, int Hin, int Win, int Cin, int Cout, int KS, int pad,
+                                     float scale, float up_mul, float mask_slope, pg_stream_t stream)
+{
+    if (!yup) return PG_E_ARG;
+    return conv2d_impl(x, w, nullptr, nullptr, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, 0,
+                       scale, 1.0f, mask_slope, stream, yup, upmask, up_mul);
 }
 
 extern "C" int pg_conv2d_pool_nhwc(const float* x, const float* w, const float* bias, const float* mask, float* y,

@@ -363,7 +363,15 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             gz1 = _dgrad(D, gz2, c2, NB, H, mask=rec['a1'], mask_slope=c1.slope)
             if full:
                 _wgrad(rec['inp'], gz1, c1, NB, H)
-            gin = _dgrad(D, gz1, c1, NB, H, mask=rec['inp'] if rec['first'] else None, mask_slope=fr_slope)
+            g_fused = None
+            if not rec['first'] and not (recs[idx - 1]['first'] and alpha < 1.0):
+                # backward-data conv + pool adjoint + LeakyReLU' of the finer block's output in one kernel
+                pv = recs[idx - 1]
+                g_fused = ops.conv2d_unpool(gz1, _wt(D, c1), NB, H, H, c1.ksize, c1.ksize - 1 - c1.pad, c1.c,
+                                            upmask=pv['a2'], mul=1.0, mask_slope=pv['blk'].c2.slope)
+                gin = None
+            else:
+                gin = _dgrad(D, gz1, c1, NB, H, mask=rec['inp'] if rec['first'] else None, mask_slope=fr_slope)
             if save_adjoints:
                 adj[idx].update(gz2=gz2, gz1=gz1)
         if rec['first']:
@@ -394,6 +402,8 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                     with _on_side(gpf, x):
                         ops.fromrgb_wgrad(gpf, x, pfr._gw, pfr._gb, NB, C, H, H, pfr.c, pool=True)
                 pending_prev = (gpf, pfr)
+            elif not rec['last'] and g_fused is not None:
+                g = g_fused
             else:
                 g = ops.avgpool2_bwd(gin, prev['a2'], 1.0, pc2.slope)
     return gimg, adj

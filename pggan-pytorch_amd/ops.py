@@ -54,6 +54,18 @@ def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, m
     return y, yp
 
 
+def conv2d_unpool(x, w, N, Hin, Win, ks, pad, scale, upmask=None, mul=1.0, mask_slope=0.2):
+    """Backward-data conv followed by the adjoint of the 2x2 average pool (x0.25*mul, nearest x2) and the
+    LeakyReLU' mask of the finer activation, fused.  Returns the fine-resolution gradient [N,2Ho,2Wo,Cout]."""
+    cout, cin = w.shape[2], w.shape[3]
+    ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
+    y = torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)          # scratch (unfused fallback)
+    yup = torch.empty((N, 2 * ho, 2 * wo, cout), device=x.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_unpool_nhwc', _p(x), _p(w), _p(upmask), _p(y), _p(yup), N, Hin, Win, cin, cout, ks, pad,
+              scale, mul, mask_slope, _stream())
+    return yup
+
+
 def conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=False):
     """Accumulates into dw [ks,ks,Cout,Cin] (and db [Cout] if given)."""
     cout, cin = dw.shape[2], dw.shape[3]

@@ -92,6 +92,30 @@ def test_conv2d_pool_fused(case, cand):
         lib.pg_debug_set_tuning(0, -1)
 
 
+@pytest.mark.parametrize('case', POOL_CASES)
+@pytest.mark.parametrize('cand', [-1, 0, 1, 2, 3, 4, 5, 6, 7])
+def test_conv2d_unpool_fused(case, cand):
+    """Backward-data conv + pool adjoint + LeakyReLU' mask in one kernel == conv followed by avgpool2_bwd."""
+    N, H, ci, co = case
+    lib = pg._lib.load()
+    x, w = rnd(N, H, H, ci), rnd(3, 3, co, ci, seed=1) * 0.2
+    m = rnd(N, 2 * H, 2 * H, co, seed=3)
+    lib.pg_debug_set_tuning(0, cand)
+    try:
+        try:
+            up = ops.conv2d_unpool(dev(x), dev(w), N, H, H, 3, 1, 0.37, upmask=dev(m), mul=0.7, mask_slope=0.2)
+            y = ops.conv2d(dev(x), dev(w), None, N, H, H, 3, 1, 0.37)
+        except RuntimeError:
+            pytest.skip('tile candidate not available for this shape')
+        # (not torch.equal: when the shape needs split-K both calls fall back to atomics, whose order differs run to run)
+        check('conv+unpool vs unfused pair %s' % (case,), up, ops.avgpool2_bwd(y, dev(m), 0.7, 0.2).cpu(), 2e-6)
+        check('conv+unpool vs emulation %s' % (case,), up, E.conv2d_unpool(x, w, N, H, H, 3, 1, 0.37, upmask=m, mul=0.7, mask_slope=0.2))
+        up2 = ops.conv2d_unpool(dev(x), dev(w), N, H, H, 3, 1, 0.37)
+        check('conv+unpool (no mask) %s' % (case,), up2, ops.avgpool2_bwd(y).cpu(), 2e-6)
+    finally:
+        lib.pg_debug_set_tuning(0, -1)
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv2d_wgrad(case):
     N, H, ci, co, ks, pad, ups = case
