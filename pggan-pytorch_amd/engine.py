@@ -216,11 +216,11 @@ def generator_backward(G, ctx, g_out):
         g1 = _dgrad(G, gz2, c2, N, H)
         gz1 = ops.pixelnorm_lrelu_bwd(g1, rec['a1'], rec['r1'], c1.slope, inplace=True)
         _wgrad(rec['inp'], gz1, c1, N, H, ups=True)
-        gup = _dgrad(G, gz1, c1, N, H)
-        g = ops.upsample2_bwd(gup)
-        if g_extra is not None:
-            g = ops.axpby_mask(g, other=g_extra, a=1.0, b=1.0, out=g)
-            g_extra = None
+        # backward-data conv of c1 + adjoint of the nearest x2 upsample (sum over 2x2 = 4 * average pool, exact in fp32)
+        # + the fade-in branch's gradient, all in the conv epilogue
+        _, g = ops.conv2d_pool(gz1, _wt(G, c1), None, N, H, H, c1.ksize, c1.ksize - 1 - c1.pad, c1.c, 1.0,
+                               other=g_extra, a=4.0, b=1.0, pool_only=True)
+        g_extra = None
         active += [c1, c2]
     gz2 = ops.pixelnorm_lrelu_bwd(g, ctx['y2'], ctx['r2'], b0.c2.slope, inplace=True)
     _wgrad(ctx['y1'], gz2, b0.c2, N, 4)
