@@ -71,6 +71,13 @@ int pg_conv2d_pool_nhwc(const float* x, const float* w, const float* bias, const
                         int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
                         float scale, float slope, float mask_slope, pg_stream_t stream);
 
+/* Generator layer in one launch: conv -> bias -> LeakyReLU -> PixelNorm (network.py:32-41):
+ *   y = act(conv) * r,  r[pixel] = rsqrt(mean_c act(conv)^2 + eps)          r: [N*Hout*Wout]
+ * Fused when one wave holds every cout of a pixel (Cout <= 32); otherwise conv followed by pg_pixelnorm_fwd in place. */
+int pg_conv2d_pixelnorm_nhwc(const float* x, const float* w, const float* bias, float* y, float* r,
+                             int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
+                             float scale, float slope, float eps, pg_stream_t stream);
+
 /* Backward-data convolution with the ADJOINT of that pool fused into its epilogue (the avg_pool2d backward +
  * LeakyReLU' mask between two DBlocks in the backward sweep):
  *   yup[n][2h+dy][2w+dx][c] = 0.25 * up_mul * scale*conv(x,w)[n][h][w][c] * (upmask[n][2h+dy][2w+dx][c] > 0 ? 1 : mask_slope)

@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
-thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling, 10: unfused unpooling
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling, 10: unfused unpooling, 11: unfused PixelNorm
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -55,6 +55,8 @@ struct ConvP {
     float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
     // fused adjoint of that pool (pg_conv2d_unpool_nhwc): yup[n][2h+dy][2w+dx][c] = 0.25*up_mul * y[n][h][w][c] * lrelu'(upmask[...])
     float* yup; const float* upmask; float up_mul;
+    // fused PixelNorm of the activated output (pg_conv2d_pixelnorm_nhwc): y *= rsqrt(mean_c y^2 + pn_eps), pn_r[pixel] = that factor
+    float* pn_r; float pn_eps;
 };
 
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
@@ -220,6 +222,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     }
 
     // epilogue: lane holds couts cb..cb+3 of pixel j
+    if (p.pn_r != nullptr) {                     // conv -> bias -> LeakyReLU -> PixelNorm; the workgroup holds every cout of its pixels
+        float4 o[WM][WN];
+        float ss[WN];
+#pragma unroll
+        for (int n = 0; n < WN; ++n) ss[n] = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const int cb = co0 + (wave_co * WM + m) * 16 + 4 * kk;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && cb < p.Cout) bv = *reinterpret_cast<const float4*>(p.bias + cb);
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                float4 v = make_float4(acc[m][n][0] * p.scale + bv.x, acc[m][n][1] * p.scale + bv.y,
+                                       acc[m][n][2] * p.scale + bv.z, acc[m][n][3] * p.scale + bv.w);
+                v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+                v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+                if (cb >= p.Cout) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                o[m][n] = v;
+                ss[n] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            ss[n] += __shfl_xor(ss[n], 16, 64);
+            ss[n] += __shfl_xor(ss[n], 32, 64);
+            const float rr = rsqrtf(ss[n] / (float)p.Cout + p.pn_eps);
+            const int j = (wave_px * WN + n) * 16 + li;
+            const int tw = j & (TW - 1), th = (j >> p.lgTW) & (TH - 1), tn = j >> (p.lgTW + p.lgTH);
+            const int ni = n0 + tn;
+            if (ni >= p.N) continue;
+            const size_t pix = ((size_t)ni * p.Hout + oh0 + th) * p.Wout + ow0 + tw;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                const int cb = co0 + (wave_co * WM + m) * 16 + 4 * kk;
+                if (cb >= p.Cout) continue;
+                *reinterpret_cast<float4*>(p.y + pix * p.Cout + cb) =
+                    make_float4(o[m][n].x * rr, o[m][n].y * rr, o[m][n].z * rr, o[m][n].w * rr);
+            }
+            if (kk == 0) p.pn_r[pix] = rr;
+        }
+        return;
+    }
     const bool pooling = p.ypool != nullptr && p.ksplit == 1;
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
@@ -841,6 +885,14 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
             o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
             o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
         }
+        if (p.pn_r) {                                // PixelNorm over the COUT channels of the pixel: QO lanes (4 apart) share it
+            float ssq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+            ssq += __shfl_xor(ssq, 4, 64);
+            if (QO >= 4) ssq += __shfl_xor(ssq, 8, 64);
+            const float rr = rsqrtf(ssq / (float)COUT + p.pn_eps);
+            o.x *= rr; o.y *= rr; o.z *= rr; o.w *= rr;
+            if (qo == 0) p.pn_r[((size_t)n * p.Hout + oy) * p.Wout + ox] = rr;
+        }
         if (!(p.ypool && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
         ov[g] = o;
     }
@@ -1042,7 +1094,8 @@ int launch_conv(ConvP& p, hipStream_t s)
         const int cper = (nchunks + ksplit - 1) / ksplit;
         ksplit = (nchunks + cper - 1) / cper;
     }
-    if (ksplit > 1 && p.yup) return PG_E_UNSUP;          // the unpool epilogue needs complete sums
+    if (ksplit > 1 && (p.yup || p.pn_r)) return PG_E_UNSUP;      // the unpool / PixelNorm epilogues need complete sums
+    if (p.pn_r && (WAVES_CO != 1 || ncob != 1)) return PG_E_UNSUP;  // ... and every cout of a pixel inside one wave
     p.ksplit = ksplit;
     const size_t npix = (size_t)p.N * p.Hout * p.Wout;
     if (ksplit > 1) {
@@ -1254,7 +1307,7 @@ int dispatch_conv(ConvP& p, hipStream_t s)
     } else {
         if constexpr (VEC == 4) {
             const long long Mpx = (long long)p.N * p.Hout * p.Wout;
-            if (!p.ups && !p.ypool && !p.yup && p.Cin >= 128 && g_tune[0] < 0 && g_tune[3] != 8 &&
+            if (!p.ups && !p.ypool && !p.yup && !p.pn_r && p.Cin >= 128 && g_tune[0] < 0 && g_tune[3] != 8 &&
                 ((g_tune[3] == 9 && Mpx <= 2304) || (g_tune[3] != 9 && Mpx <= 576))) {
                 const int rc = Mpx <= 256 ? launch_ksplit<1>(p, s) : launch_ksplit<2>(p, s);
                 if (rc != PG_E_UNSUP) return rc;
@@ -1274,6 +1327,7 @@ int dispatch_conv(ConvP& p, hipStream_t s)
             if (c.bpx == 256 && p.Cout > 16) continue;            // 256-pixel tiles only exist for <= 16 couts
             if (c.bco > 16 && p.Cout <= 16) continue;
             if (c.bco > 32 && p.Cout <= 32) continue;
+            if (p.pn_r && (c.bco < p.Cout || i == 1 || i == 4 || i == 5 || i == 7)) continue;   // fused PixelNorm: one wave row of couts
             const TileGeom g = make_geom(p.N, p.Hout, p.Wout, c.bpx);
             const int halo = g.TN * ((1 << g.lgTH) + KS - 1) * ((1 << g.lgTW) + KS - 1);
             const long long lds = (long long)(KS * KS * c.bco + halo) * KCP * 4;
@@ -1637,12 +1691,14 @@ extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int
 
 extern "C" int pg_avgpool2_bwd(const float* gy, const float* mask, float* gx, int N, int H, int W, int C,
                                float mul, float mask_slope, pg_stream_t stream);
+extern "C" int pg_pixelnorm_fwd(const float* x, float* y, float* r, int64_t P, int C, float eps, pg_stream_t stream);
 
 static int conv2d_impl(const float* x, const float* w, const float* bias, const float* mask, float* y,
                        float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
                        int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
                        float scale, float slope, float mask_slope, pg_stream_t stream,
-                       float* yup = nullptr, const float* upmask = nullptr, float up_mul = 1.f)
+                       float* yup = nullptr, const float* upmask = nullptr, float up_mul = 1.f,
+                       float* pn_r = nullptr, float pn_eps = 0.f)
 {
     if (!x || !w || !y || N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
     if ((Cin & 3) || (Cout & 3)) return PG_E_ALIGN;
@@ -1664,8 +1720,17 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     // the unpool epilogue exists in the generic tile kernel only (no split-K): everything else unpools in a second pass
     const bool fuse_up = yup != nullptr && KS == 3 && g_tune[3] != 10;
     p.yup = nullptr; p.upmask = upmask; p.up_mul = up_mul;
+    p.pn_r = nullptr; p.pn_eps = pn_eps;
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    if (pn_r && KS == 3 && Cout <= 32 && !mask && g_tune[3] != 11) {   // fused PixelNorm: thin kernel (8 couts) or one-row generic tiles
+        p.pn_r = pn_r;
+        const bool thin_pn = pad == 1 && Cout == 8 && (Cin == 8 || Cin == 16) && (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
+        rc = thin_pn ? dispatch_thin(p, s) : dispatch_conv_generic_nosplit(p, s);
+        if (rc == 0) return 0;
+        if (rc != PG_E_UNSUP) return rc;
+        p.pn_r = nullptr;
+    }
     if (fuse_up) {
         p.yup = yup;
         rc = dispatch_conv_generic_nosplit(p, s);
@@ -1683,6 +1748,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
         if (ypool && !p.ypool)
             return pg_avgpool2_fwd(y, pool_other, ypool, N, p.Hout >> 1, p.Wout >> 1, Cout, pool_a, pool_b, stream);
         if (yup) return pg_avgpool2_bwd(y, upmask, yup, N, p.Hout, p.Wout, Cout, up_mul, mask_slope, stream);
+        if (pn_r) return pg_pixelnorm_fwd(y, y, pn_r, (int64_t)N * p.Hout * p.Wout, Cout, pn_eps, stream);
         return 0;
     }
     if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
@@ -1698,6 +1764,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     if (ypool && !(fuse_pool && p.ksplit == 1))          // split-K / non-3x3 launches pool in a second pass over y
         return pg_avgpool2_fwd(y, pool_other, ypool, N, p.Hout >> 1, p.Wout >> 1, Cout, pool_a, pool_b, stream);
     if (yup) return pg_avgpool2_bwd(y, upmask, yup, N, p.Hout, p.Wout, Cout, up_mul, mask_slope, stream);
+    if (pn_r) return pg_pixelnorm_fwd(y, y, pn_r, (int64_t)N * p.Hout * p.Wout, Cout, pn_eps, stream);
     return 0;
 }
 
@@ -1707,6 +1774,15 @@ extern "C" int pg_conv2d_nhwc(const float* x, const float* w, const float* bias,
 {
     return conv2d_impl(x, w, bias, mask, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, ups,
                        scale, slope, mask_slope, stream);
+}
+
+extern "C" int pg_conv2d_pixelnorm_nhwc(const float* x, const float* w, const float* bias, float* y, float* r,
+                                        int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
+                                        float scale, float slope, float eps, pg_stream_t stream)
+{
+    if (!r) return PG_E_ARG;
+    return conv2d_impl(x, w, bias, nullptr, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, ups,
+                       scale, slope, 0.2f, stream, nullptr, nullptr, 1.f, r, eps);
 }
 
 extern "C" int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, float* y, float* yup,

@@ -148,11 +148,10 @@ def generator_forward(G, z, save=False, out=None):
     ctx['zn'] = zn
 
     def layer(x, lay, H, ups=False):
-        y = _conv(x, lay, N, H, ups=ups)
-        r = None
-        if lay.pixelnorm:
-            y, r = ops.pixelnorm_fwd(y, lay.eps, inplace=True)
-        return y, r
+        if lay.pixelnorm:                         # conv + bias + act + PixelNorm in one launch where the tile allows it
+            return ops.conv2d_pixelnorm(x, lay.conv.weight.data, lay.conv.bias.data, N, H, H, lay.ksize, lay.pad, lay.c,
+                                        lay.slope, lay.eps, ups=ups)
+        return _conv(x, lay, N, H, ups=ups), None
 
     y1, r1 = layer(zn.view(N, 1, 1, L), b0.c1, 1)                            # 4x4 conv pad 3 on 1x1
     y2, r2 = layer(y1, b0.c2, 4)

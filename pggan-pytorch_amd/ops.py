@@ -54,6 +54,17 @@ def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, m
     return y, yp
 
 
+def conv2d_pixelnorm(x, w, bias, N, Hin, Win, ks, pad, scale, slope, eps=1e-8, ups=False):
+    """conv -> bias -> LeakyReLU -> PixelNorm in one launch where the tile shape allows it.  Returns (y, r)."""
+    cout, cin = w.shape[2], w.shape[3]
+    ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
+    y = torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
+    r = torch.empty((N * ho * wo,), device=x.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_pixelnorm_nhwc', _p(x), _p(w), _p(bias), _p(y), _p(r), N, Hin, Win, cin, cout, ks, pad,
+              1 if ups else 0, scale, slope, eps, _stream())
+    return y, r
+
+
 def conv2d_unpool(x, w, N, Hin, Win, ks, pad, scale, upmask=None, mul=1.0, mask_slope=0.2):
     """Backward-data conv followed by the adjoint of the 2x2 average pool (x0.25*mul, nearest x2) and the
     LeakyReLU' mask of the finer activation, fused.  Returns the fine-resolution gradient [N,2Ho,2Wo,Cout]."""

@@ -92,6 +92,26 @@ def test_conv2d_pool_fused(case, cand):
         lib.pg_debug_set_tuning(0, -1)
 
 
+@pytest.mark.parametrize('case', [(1, 64, 8, 8, 0), (2, 64, 16, 8, 1), (2, 32, 16, 8, 0), (2, 64, 16, 16, 0), (3, 32, 32, 16, 1), (2, 32, 32, 32, 0),
+                                  (1, 128, 64, 32, 1), (2, 16, 64, 64, 0), (3, 8, 512, 512, 0), (5, 4, 32, 16, 0), (2, 16, 12, 20, 0)])
+def test_conv2d_pixelnorm_fused(case):
+    """Generator layer (conv -> bias -> LeakyReLU -> PixelNorm) in one launch vs the separate kernels and the emulation."""
+    N, H, ci, co, ups = case
+    hin = H // 2 if ups else H
+    x, w, b = rnd(N, hin, hin, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    y, r = ops.conv2d_pixelnorm(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.37, 0.2, 1e-8, ups=bool(ups))
+    print(pg._lib.load().pg_debug_last_conv_kernel().decode())
+    ry, rr = E.conv2d_pixelnorm(x, w, b, N, H, H, 3, 1, 0.37, 0.2, 1e-8, ups=bool(ups))
+    check('conv+pixelnorm y %s' % (case,), y, ry)
+    check('conv+pixelnorm r %s' % (case,), r, rr)
+    pg._lib.load().pg_debug_set_tuning(3, 11)
+    try:
+        y2, r2 = ops.conv2d_pixelnorm(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.37, 0.2, 1e-8, ups=bool(ups))
+    finally:
+        pg._lib.load().pg_debug_set_tuning(3, -1)
+    check('fused vs separate kernels', y, y2.cpu(), 2e-6)
+
+
 @pytest.mark.parametrize('case', POOL_CASES)
 @pytest.mark.parametrize('cand', [-1, 0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv2d_unpool_fused(case, cand):
