@@ -78,6 +78,14 @@ int pg_conv2d_pixelnorm_nhwc(const float* x, const float* w, const float* bias, 
                              int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
                              float scale, float slope, float eps, pg_stream_t stream);
 
+/* ... and its backward counterpart: backward-data conv of a layer followed by the adjoint of the PREVIOUS layer's
+ * (LeakyReLU -> PixelNorm), given that layer's saved output `ysaved` and factors `r` (r may be NULL: mask only):
+ *   g = scale*conv(x,w);   y = r * (g - ysaved * mean_c(g*ysaved)) * (ysaved > 0 ? 1 : slope)
+ * == pg_conv2d_nhwc + pg_pixelnorm_lrelu_bwd (which is also the fallback when the tile cannot hold a pixel's couts). */
+int pg_conv2d_pnbwd_nhwc(const float* x, const float* w, const float* ysaved, const float* r, float* y,
+                         int N, int Hin, int Win, int Cin, int Cout, int KS, int pad,
+                         float scale, float slope, pg_stream_t stream);
+
 /* Backward-data convolution with the ADJOINT of that pool fused into its epilogue (the avg_pool2d backward +
  * LeakyReLU' mask between two DBlocks in the backward sweep):
  *   yup[n][2h+dy][2w+dx][c] = 0.25 * up_mul * scale*conv(x,w)[n][h][w][c] * (upmask[n][2h+dy][2w+dx][c] > 0 ? 1 : mask_slope)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class PgganLibraryError(RuntimeError):
@@ -27,6 +27,7 @@ SIGNATURES = {
     'pg_conv2d_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_pool_nhwc': [P, P, P, P, P, P, P, F, F, I, I, I, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_pixelnorm_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
+    'pg_conv2d_pnbwd_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, F, F, P],
     'pg_conv2d_unpool_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
     'pg_debug_last_conv_kernel': [],

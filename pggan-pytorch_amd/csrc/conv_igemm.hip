@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
-thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling, 10: unfused unpooling, 11: unfused PixelNorm
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling, 10: unfused unpooling, 11 / 12: unfused PixelNorm forward / adjoint
 
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
@@ -57,6 +57,9 @@ struct ConvP {
     float* yup; const float* upmask; float up_mul;
     // fused PixelNorm of the activated output (pg_conv2d_pixelnorm_nhwc): y *= rsqrt(mean_c y^2 + pn_eps), pn_r[pixel] = that factor
     float* pn_r; float pn_eps;
+    // fused adjoint of (LeakyReLU -> PixelNorm) applied to the conv result g (pg_conv2d_pnbwd_nhwc):
+    //   y = r[pix] * (g - pnb_y * mean_c(g * pnb_y)) * lrelu'(pnb_y)
+    const float* pnb_y; const float* pnb_r;
 };
 
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
@@ -261,6 +264,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
                     make_float4(o[m][n].x * rr, o[m][n].y * rr, o[m][n].z * rr, o[m][n].w * rr);
             }
             if (kk == 0) p.pn_r[pix] = rr;
+        }
+        return;
+    }
+    if (p.pnb_y != nullptr) {                    // backward-data conv + adjoint of the previous layer's LeakyReLU -> PixelNorm
+        float4 gq[WM][WN], yq[WM][WN];
+        float dot[WN];
+#pragma unroll
+        for (int n = 0; n < WN; ++n) dot[n] = 0.f;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int j = (wave_px * WN + n) * 16 + li;
+            const int tw = j & (TW - 1), th = (j >> p.lgTW) & (TH - 1), tn = j >> (p.lgTW + p.lgTH);
+            const int ni = n0 + tn;
+            const size_t pix = ((size_t)(ni < p.N ? ni : 0) * p.Hout + oh0 + th) * p.Wout + ow0 + tw;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                const int cb = co0 + (wave_co * WM + m) * 16 + 4 * kk;
+                float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), yv = gv;
+                if (cb < p.Cout && ni < p.N) {
+                    gv = make_float4(acc[m][n][0] * p.scale, acc[m][n][1] * p.scale, acc[m][n][2] * p.scale, acc[m][n][3] * p.scale);
+                    yv = *reinterpret_cast<const float4*>(p.pnb_y + pix * p.Cout + cb);
+                }
+                gq[m][n] = gv; yq[m][n] = yv;
+                dot[n] += (gv.x * yv.x + gv.y * yv.y) + (gv.z * yv.z + gv.w * yv.w);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            dot[n] += __shfl_xor(dot[n], 16, 64);
+            dot[n] += __shfl_xor(dot[n], 32, 64);
+            const int j = (wave_px * WN + n) * 16 + li;
+            const int tw = j & (TW - 1), th = (j >> p.lgTW) & (TH - 1), tn = j >> (p.lgTW + p.lgTH);
+            const int ni = n0 + tn;
+            if (ni >= p.N) continue;
+            const size_t pix = ((size_t)ni * p.Hout + oh0 + th) * p.Wout + ow0 + tw;
+            const float rr = p.pnb_r[pix], mean = dot[n] / (float)p.Cout;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                const int cb = co0 + (wave_co * WM + m) * 16 + 4 * kk;
+                if (cb >= p.Cout) continue;
+                const float4 gv = gq[m][n], yv = yq[m][n];
+                float4 o;
+                o.x = rr * (gv.x - yv.x * mean) * (yv.x > 0.f ? 1.f : p.mask_slope);
+                o.y = rr * (gv.y - yv.y * mean) * (yv.y > 0.f ? 1.f : p.mask_slope);
+                o.z = rr * (gv.z - yv.z * mean) * (yv.z > 0.f ? 1.f : p.mask_slope);
+                o.w = rr * (gv.w - yv.w * mean) * (yv.w > 0.f ? 1.f : p.mask_slope);
+                *reinterpret_cast<float4*>(p.y + pix * p.Cout + cb) = o;
+            }
         }
         return;
     }
@@ -885,6 +936,18 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
             o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
             o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
         }
+        if (p.pnb_y) {                               // adjoint of the previous layer's (LeakyReLU -> PixelNorm), see ConvP
+            const float4 yv = *reinterpret_cast<const float4*>(p.pnb_y + off);
+            const float4 gv = make_float4(acc[g][0] * p.scale, acc[g][1] * p.scale, acc[g][2] * p.scale, acc[g][3] * p.scale);
+            float dt = (gv.x * yv.x + gv.y * yv.y) + (gv.z * yv.z + gv.w * yv.w);
+            dt += __shfl_xor(dt, 4, 64);
+            if (QO >= 4) dt += __shfl_xor(dt, 8, 64);
+            const float rr = p.pnb_r[((size_t)n * p.Hout + oy) * p.Wout + ox], mean = dt / (float)COUT;
+            o.x = rr * (gv.x - yv.x * mean) * (yv.x > 0.f ? 1.f : p.mask_slope);
+            o.y = rr * (gv.y - yv.y * mean) * (yv.y > 0.f ? 1.f : p.mask_slope);
+            o.z = rr * (gv.z - yv.z * mean) * (yv.z > 0.f ? 1.f : p.mask_slope);
+            o.w = rr * (gv.w - yv.w * mean) * (yv.w > 0.f ? 1.f : p.mask_slope);
+        }
         if (p.pn_r) {                                // PixelNorm over the COUT channels of the pixel: QO lanes (4 apart) share it
             float ssq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
             ssq += __shfl_xor(ssq, 4, 64);
@@ -1094,8 +1157,8 @@ int launch_conv(ConvP& p, hipStream_t s)
         const int cper = (nchunks + ksplit - 1) / ksplit;
         ksplit = (nchunks + cper - 1) / cper;
     }
-    if (ksplit > 1 && (p.yup || p.pn_r)) return PG_E_UNSUP;      // the unpool / PixelNorm epilogues need complete sums
-    if (p.pn_r && (WAVES_CO != 1 || ncob != 1)) return PG_E_UNSUP;  // ... and every cout of a pixel inside one wave
+    if (ksplit > 1 && (p.yup || p.pn_r || p.pnb_y)) return PG_E_UNSUP;      // the unpool / PixelNorm epilogues need complete sums
+    if ((p.pn_r || p.pnb_y) && (WAVES_CO != 1 || ncob != 1)) return PG_E_UNSUP;  // ... and every cout of a pixel inside one wave
     p.ksplit = ksplit;
     const size_t npix = (size_t)p.N * p.Hout * p.Wout;
     if (ksplit > 1) {
@@ -1307,7 +1370,7 @@ int dispatch_conv(ConvP& p, hipStream_t s)
     } else {
         if constexpr (VEC == 4) {
             const long long Mpx = (long long)p.N * p.Hout * p.Wout;
-            if (!p.ups && !p.ypool && !p.yup && !p.pn_r && p.Cin >= 128 && g_tune[0] < 0 && g_tune[3] != 8 &&
+            if (!p.ups && !p.ypool && !p.yup && !p.pn_r && !p.pnb_y && p.Cin >= 128 && g_tune[0] < 0 && g_tune[3] != 8 &&
                 ((g_tune[3] == 9 && Mpx <= 2304) || (g_tune[3] != 9 && Mpx <= 576))) {
                 const int rc = Mpx <= 256 ? launch_ksplit<1>(p, s) : launch_ksplit<2>(p, s);
                 if (rc != PG_E_UNSUP) return rc;
@@ -1327,7 +1390,7 @@ int dispatch_conv(ConvP& p, hipStream_t s)
             if (c.bpx == 256 && p.Cout > 16) continue;            // 256-pixel tiles only exist for <= 16 couts
             if (c.bco > 16 && p.Cout <= 16) continue;
             if (c.bco > 32 && p.Cout <= 32) continue;
-            if (p.pn_r && (c.bco < p.Cout || i == 1 || i == 4 || i == 5 || i == 7)) continue;   // fused PixelNorm: one wave row of couts
+            if ((p.pn_r || p.pnb_y) && (c.bco < p.Cout || i == 1 || i == 4 || i == 5 || i == 7)) continue;   // fused PixelNorm: one wave row of couts
             const TileGeom g = make_geom(p.N, p.Hout, p.Wout, c.bpx);
             const int halo = g.TN * ((1 << g.lgTH) + KS - 1) * ((1 << g.lgTW) + KS - 1);
             const long long lds = (long long)(KS * KS * c.bco + halo) * KCP * 4;
@@ -1692,13 +1755,15 @@ extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int
 extern "C" int pg_avgpool2_bwd(const float* gy, const float* mask, float* gx, int N, int H, int W, int C,
                                float mul, float mask_slope, pg_stream_t stream);
 extern "C" int pg_pixelnorm_fwd(const float* x, float* y, float* r, int64_t P, int C, float eps, pg_stream_t stream);
+extern "C" int pg_pixelnorm_lrelu_bwd(const float* gy, const float* y, const float* r, float* gz,
+                                      int64_t P, int C, float slope, pg_stream_t stream);
 
 static int conv2d_impl(const float* x, const float* w, const float* bias, const float* mask, float* y,
                        float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
                        int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int ups,
                        float scale, float slope, float mask_slope, pg_stream_t stream,
                        float* yup = nullptr, const float* upmask = nullptr, float up_mul = 1.f,
-                       float* pn_r = nullptr, float pn_eps = 0.f)
+                       float* pn_r = nullptr, float pn_eps = 0.f, const float* pnb_y = nullptr, const float* pnb_r = nullptr)
 {
     if (!x || !w || !y || N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
     if ((Cin & 3) || (Cout & 3)) return PG_E_ALIGN;
@@ -1720,9 +1785,17 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     // the unpool epilogue exists in the generic tile kernel only (no split-K): everything else unpools in a second pass
     const bool fuse_up = yup != nullptr && KS == 3 && g_tune[3] != 10;
     p.yup = nullptr; p.upmask = upmask; p.up_mul = up_mul;
-    p.pn_r = nullptr; p.pn_eps = pn_eps;
+    p.pn_r = nullptr; p.pn_eps = pn_eps; p.pnb_y = nullptr; p.pnb_r = pnb_r;
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    if (pnb_y && pnb_r && KS == 3 && Cout <= 32 && g_tune[3] != 12) {
+        p.pnb_y = pnb_y;
+        const bool thin_pn = pad == 1 && Cout == 8 && (Cin == 8 || Cin == 16) && (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
+        rc = thin_pn ? dispatch_thin(p, s) : dispatch_conv_generic_nosplit(p, s);
+        if (rc == 0) return 0;
+        if (rc != PG_E_UNSUP) return rc;
+        p.pnb_y = nullptr;
+    }
     if (pn_r && KS == 3 && Cout <= 32 && !mask && g_tune[3] != 11) {   // fused PixelNorm: thin kernel (8 couts) or one-row generic tiles
         p.pn_r = pn_r;
         const bool thin_pn = pad == 1 && Cout == 8 && (Cin == 8 || Cin == 16) && (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
@@ -1749,6 +1822,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
             return pg_avgpool2_fwd(y, pool_other, ypool, N, p.Hout >> 1, p.Wout >> 1, Cout, pool_a, pool_b, stream);
         if (yup) return pg_avgpool2_bwd(y, upmask, yup, N, p.Hout, p.Wout, Cout, up_mul, mask_slope, stream);
         if (pn_r) return pg_pixelnorm_fwd(y, y, pn_r, (int64_t)N * p.Hout * p.Wout, Cout, pn_eps, stream);
+        if (pnb_y) return pg_pixelnorm_lrelu_bwd(y, pnb_y, pnb_r, y, (int64_t)N * p.Hout * p.Wout, Cout, mask_slope, stream);
         return 0;
     }
     if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
@@ -1765,6 +1839,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
         return pg_avgpool2_fwd(y, pool_other, ypool, N, p.Hout >> 1, p.Wout >> 1, Cout, pool_a, pool_b, stream);
     if (yup) return pg_avgpool2_bwd(y, upmask, yup, N, p.Hout, p.Wout, Cout, up_mul, mask_slope, stream);
     if (pn_r) return pg_pixelnorm_fwd(y, y, pn_r, (int64_t)N * p.Hout * p.Wout, Cout, pn_eps, stream);
+    if (pnb_y) return pg_pixelnorm_lrelu_bwd(y, pnb_y, pnb_r, y, (int64_t)N * p.Hout * p.Wout, Cout, mask_slope, stream);
     return 0;
 }
 
@@ -1783,6 +1858,15 @@ extern "C" int pg_conv2d_pixelnorm_nhwc(const float* x, const float* w, const fl
     if (!r) return PG_E_ARG;
     return conv2d_impl(x, w, bias, nullptr, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, ups,
                        scale, slope, 0.2f, stream, nullptr, nullptr, 1.f, r, eps);
+}
+
+extern "C" int pg_conv2d_pnbwd_nhwc(const float* x, const float* w, const float* ysaved, const float* r, float* y,
+                                    int N, int Hin, int Win, int Cin, int Cout, int KS, int pad,
+                                    float scale, float slope, pg_stream_t stream)
+{
+    if (!ysaved) return PG_E_ARG;
+    return conv2d_impl(x, w, nullptr, nullptr, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, 0,
+                       scale, 1.0f, slope, stream, nullptr, nullptr, 1.f, nullptr, 0.f, ysaved, r);
 }
 
 extern "C" int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, float* y, float* yup,

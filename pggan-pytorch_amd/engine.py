@@ -212,8 +212,8 @@ def generator_backward(G, ctx, g_out):
         c1, c2 = blk.c1, blk.c2
         gz2 = ops.pixelnorm_lrelu_bwd(g, rec['a2'], rec['r2'], c2.slope, inplace=True)
         _wgrad(rec['a1'], gz2, c2, N, H)
-        g1 = _dgrad(G, gz2, c2, N, H)
-        gz1 = ops.pixelnorm_lrelu_bwd(g1, rec['a1'], rec['r1'], c1.slope, inplace=True)
+        # backward-data conv of c2 + adjoint of c1's (LeakyReLU -> PixelNorm) in one launch
+        gz1 = ops.conv2d_pnbwd(gz2, _wt(G, c2), rec['a1'], rec['r1'], N, H, H, c2.ksize, c2.ksize - 1 - c2.pad, c2.c, c1.slope)
         _wgrad(rec['inp'], gz1, c1, N, H, ups=True)
         # backward-data conv of c1 + adjoint of the nearest x2 upsample (sum over 2x2 = 4 * average pool, exact in fp32)
         # + the fade-in branch's gradient, all in the conv epilogue

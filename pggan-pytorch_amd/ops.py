@@ -65,6 +65,15 @@ def conv2d_pixelnorm(x, w, bias, N, Hin, Win, ks, pad, scale, slope, eps=1e-8, u
     return y, r
 
 
+def conv2d_pnbwd(x, w, ysaved, r, N, Hin, Win, ks, pad, scale, slope):
+    """Backward-data conv + adjoint of the previous layer's (LeakyReLU -> PixelNorm) in one launch where possible."""
+    cout, cin = w.shape[2], w.shape[3]
+    ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
+    y = torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_pnbwd_nhwc', _p(x), _p(w), _p(ysaved), _p(r), _p(y), N, Hin, Win, cin, cout, ks, pad, scale, slope, _stream())
+    return y
+
+
 def conv2d_unpool(x, w, N, Hin, Win, ks, pad, scale, upmask=None, mul=1.0, mask_slope=0.2):
     """Backward-data conv followed by the adjoint of the 2x2 average pool (x0.25*mul, nearest x2) and the
     LeakyReLU' mask of the finer activation, fused.  Returns the fine-resolution gradient [N,2Ho,2Wo,Cout]."""

@@ -73,6 +73,10 @@ def conv2d_pixelnorm(x, w, bias, N, Hin, Win, ks, pad, scale, slope, eps=1e-8, u
     return pixelnorm_fwd(conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=slope, ups=ups), eps)
 
 
+def conv2d_pnbwd(x, w, ysaved, r, N, Hin, Win, ks, pad, scale, slope):
+    return pixelnorm_lrelu_bwd(conv2d(x, w, None, N, Hin, Win, ks, pad, scale), ysaved, r, slope)
+
+
 def conv2d_unpool(x, w, N, Hin, Win, ks, pad, scale, upmask=None, mul=1.0, mask_slope=0.2):
     return avgpool2_bwd(conv2d(x, w, None, N, Hin, Win, ks, pad, scale), upmask, mul, mask_slope)
 

@@ -112,6 +112,22 @@ def test_conv2d_pixelnorm_fused(case):
     check('fused vs separate kernels', y, y2.cpu(), 2e-6)
 
 
+@pytest.mark.parametrize('case', [(1, 64, 8, 8), (2, 64, 16, 8), (2, 64, 16, 16), (3, 32, 32, 16), (2, 32, 32, 32), (1, 128, 64, 32),
+                                  (2, 16, 64, 64), (3, 8, 512, 512), (5, 4, 32, 16), (2, 16, 12, 20)])
+@pytest.mark.parametrize('with_r', [True, False])
+def test_conv2d_pnbwd_fused(case, with_r):
+    """Backward-data conv + adjoint of the previous layer's (LeakyReLU -> PixelNorm) in one launch vs the emulation."""
+    N, H, ci, co = case
+    x, w = rnd(N, H, H, ci), rnd(3, 3, co, ci, seed=1) * 0.2
+    h = rnd(N, H, H, co, seed=4)
+    ys, r = E.pixelnorm_fwd(h)
+    if not with_r:
+        ys, r = h, None
+    out = ops.conv2d_pnbwd(dev(x), dev(w), dev(ys), None if r is None else dev(r), N, H, H, 3, 1, 0.37, 0.2)
+    print(pg._lib.load().pg_debug_last_conv_kernel().decode())
+    check('conv+pnbwd %s r=%s' % (case, with_r), out, E.conv2d_pnbwd(x, w, ys, r, N, H, H, 3, 1, 0.37, 0.2), 5e-5)
+
+
 @pytest.mark.parametrize('case', POOL_CASES)
 @pytest.mark.parametrize('cand', [-1, 0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv2d_unpool_fused(case, cand):
