@@ -84,8 +84,18 @@ class KernelTimer(object):
         def pool_desc(a, k):          # conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, ...): the conv of conv_desc + pooled output
             fl, tag = conv_desc(a, k)
             return fl, tag + ' +pool'
+        def generic(w_i, n_i, suffix):  # ops whose signature is (x, w, ..., N, Hin, Win, ks, pad, ...) with N at position n_i
+            def desc(a, k):
+                w, n, hin, win, ks, pad = a[w_i], a[n_i], a[n_i + 1], a[n_i + 2], a[n_i + 3], a[n_i + 4]
+                ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
+                return (conv_flops(n, ho, wo, ks, pad, w.shape[2], w.shape[3]),
+                        'conv %d->%d k%d @%d n%d %s' % (w.shape[3], w.shape[2], ks, ho, n, suffix))
+            return desc
         self._wrap('conv2d', conv_desc)
         self._wrap('conv2d_pool', pool_desc)
+        self._wrap('conv2d_pixelnorm', generic(1, 3, '+pixelnorm'))
+        self._wrap('conv2d_unpool', generic(1, 2, '+unpool'))
+        self._wrap('conv2d_pnbwd', generic(1, 4, '+pn adjoint'))
         self._wrap('conv2d_wgrad', wgrad_desc)
         return self
 
