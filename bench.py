@@ -63,7 +63,7 @@ class KernelTimer(object):
             e0.record()
             out = orig(*a, **k)
             e1.record()
-            sym = lib.pg_debug_last_conv_kernel().decode()
+            sym = (lib.pg_debug_last_wino_kernel() if name == 'conv2d_wino' else lib.pg_debug_last_conv_kernel()).decode()
             fl, tag = describe(a, k)
             self.rec.append((sym, fl, e0, e1, '%s %s' % (tag, sym.replace('conv_', '').replace('_kernel', ''))))
             return out
@@ -91,7 +91,12 @@ class KernelTimer(object):
                 return (conv_flops(n, ho, wo, ks, pad, w.shape[2], w.shape[3]),
                         'conv %d->%d k%d @%d n%d %s' % (w.shape[3], w.shape[2], ks, ho, n, suffix))
             return desc
+        def wino_desc(a, k):          # conv2d_wino(x, u, bias, N, H, W, scale, ...): 3x3 pad 1 on Winograd-domain weights
+            u, n, h = a[1], a[3], a[4]
+            return (conv_flops(n, h, h, 3, 1, u.shape[1], u.shape[2]),
+                    'conv %d->%d k3 @%d n%d winograd%s' % (u.shape[2], u.shape[1], h, n, ' masked' if k.get('mask') is not None else ''))
         self._wrap('conv2d', conv_desc)
+        self._wrap('conv2d_wino', wino_desc)
         self._wrap('conv2d_pool', pool_desc)
         self._wrap('conv2d_pixelnorm', generic(1, 3, '+pixelnorm'))
         self._wrap('conv2d_unpool', generic(1, 2, '+unpool'))

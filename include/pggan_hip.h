@@ -95,6 +95,22 @@ int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, f
                           int N, int Hin, int Win, int Cin, int Cout, int KS, int pad,
                           float scale, float up_mul, float mask_slope, pg_stream_t stream);
 
+/* Winograd F(2x2,3x3) path for the wide 3x3 layers (pad 1; Cin % 16 == 0; H, W powers of two >= 8): 2.25x fewer MFMAs
+ * than the direct implicit GEMM, same fp32 sums re-associated (transform coefficients +-1, 1/2; ~1e-6 relative).
+ *   pg_wino_transform_weights: u[16][Cout][Cin] = G g G^T of w[3][3][Cout][Cin]   (once per weight version)
+ *   pg_conv2d_wino_nhwc: the conv of pg_conv2d_nhwc (KS 3, pad 1) on the transformed weights, with the optional fused
+ *   epilogues of pg_conv2d_pool_nhwc (ypool/pool_other/pool_a/pool_b/pool_only) and pg_conv2d_unpool_nhwc
+ *   (yup/upmask/up_mul); pass NULL for the ones not wanted.  Returns PG_E_UNSUP for shapes it does not take.      */
+int pg_wino_transform_weights(const float* w, float* u, int Cout, int Cin, pg_stream_t stream);
+int pg_wino_transform_weights_batched(const float* wbase, float* ubase, int nlayers, const int64_t* woff,
+                                      const int64_t* uoff, const int* cout, const int* cin, pg_stream_t stream);
+int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const float* mask, float* y,
+                        float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
+                        float* yup, const float* upmask, float up_mul,
+                        int N, int H, int W, int Cin, int Cout, int ups,
+                        float scale, float slope, float mask_slope, pg_stream_t stream);
+const char* pg_debug_last_wino_kernel(void);
+
 /* Profiling aid: symbol (as rocprofv3 prints it, e.g. "conv_igemm_kernel<3, 4, 2, 2, 4>") of the conv
  * kernel instantiation most recently launched by the calling thread through the two entry points
  * above ("" before the first launch).  Thread-local; lets bench.py attribute its HIP-event timings

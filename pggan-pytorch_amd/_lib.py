@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class PgganLibraryError(RuntimeError):
@@ -29,6 +29,10 @@ SIGNATURES = {
     'pg_conv2d_pixelnorm_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_pnbwd_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, F, F, P],
     'pg_conv2d_unpool_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, P],
+    'pg_wino_transform_weights': [P, P, I, I, P],
+    'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P],
+    'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
+    'pg_debug_last_wino_kernel': [],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
     'pg_debug_last_conv_kernel': [],
     'pg_debug_set_tuning': [I, I],
@@ -88,7 +92,7 @@ def load():
         except AttributeError:
             raise PgganLibraryError('symbol %s missing from %s' % (name, LIB_PATH))
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == 'pg_debug_last_conv_kernel' else ctypes.c_int
+        fn.restype = ctypes.c_char_p if name in ('pg_debug_last_conv_kernel', 'pg_debug_last_wino_kernel') else ctypes.c_int
     v = lib.pg_abi_version()
     if v != ABI_VERSION:
         raise PgganLibraryError('ABI version mismatch: library %d, binding %d' % (v, ABI_VERSION))

@@ -1,0 +1,346 @@
+// Winograd F(2x2, 3x3) convolution for the wide 3x3 layers (>= 32 input channels), fp32 on v_mfma_f32_16x16x4_f32.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// 16 multiplies per 2x2 outputs instead of 36: the sixteen element-wise products become sixteen independent
+// [Cout x Cin] x [Cin x tiles] GEMMs, i.e. 2.25x fewer MFMAs than the direct implicit GEMM.  Numerically this is a
+// re-association of the same fp32 sums (transform coefficients +-1 and 1/2), well inside the 1e-3 parity bar
+// (measured ~1e-6 relative); it replaces F.conv2d network.py:33-36 for those layers exactly like the direct kernel.
+//
+// Layout: U[16][Cout][Cin] transformed weights (pg_wino_transform_weights, once per weight version); workgroup =
+// 16 couts x 64 tiles (4 waves x 16 tiles), K in chunks of 16 channels: raw input halo region and the U chunk in
+// LDS, each lane loads ITS tile's 4x4 patch (16 b128 reads), transforms it in registers (32 float4 adds) and feeds
+// 64 MFMAs; the output transform is lane-local because a lane holds all 16 products of its (tile, 4 couts).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "pggan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+struct WinoP {
+    const float* x; const float* u; const float* bias; const float* mask; float* y;
+    int N, H, W, Cin, Cout, ups;
+    float scale, slope, mask_slope;
+    int lgTW, lgTH, TN, blocksW, blocksH;      // workgroup = TN images x 2^lgTH x 2^lgTW tiles (64 tiles)
+    unsigned mWT, mHT;                         // magic reciprocals of the halo region width / height in pixels
+    // fused epilogues (same semantics as the direct kernel, see pggan_hip.h)
+    float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
+    float* yup; const float* upmask; float up_mul;
+};
+
+constexpr int KCP = 24;                        // LDS row stride of a 16-channel row (conflict-free b128)
+constexpr int XMAX = 400;                      // halo pixels per workgroup: 18x18 (8x8 tiles) .. 4 x 10x10 (8x8 images)
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin)
+{
+    const size_t n = (size_t)Cout * Cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float g[3][3], t[4][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = w[(size_t)(a * 3 + b) * n + i];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {                     // t = G g
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
+            t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                     // U = t G^T
+            u[(size_t)(4 * a + 0) * n + i] = t[a][0];
+            u[(size_t)(4 * a + 1) * n + i] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
+            u[(size_t)(4 * a + 2) * n + i] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
+            u[(size_t)(4 * a + 3) * n + i] = t[a][2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
+{
+    constexpr int XPT = (XMAX * 4 + 255) / 256;             // float4 per thread for the halo region (16 channels)
+    constexpr int UPT = 4;                                   // 16 xi x 16 couts x 4 float4 / 256 threads
+    extern __shared__ __align__(16) float lds[];
+    float* ut = lds;                                         // [16 xi][16 co][KCP]
+    float* xt = lds + 16 * 16 * KCP;                         // [TN][HT][WT][KCP]
+    const int TTW = 1 << p.lgTW, TTH = 1 << p.lgTH;
+    const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    int b = blockIdx.x;
+    const int bw = b % p.blocksW; b /= p.blocksW;
+    const int bh = b % p.blocksH; b /= p.blocksH;
+    const int n0 = b * p.TN;
+    const int ty0 = bh << p.lgTH, tx0 = bw << p.lgTW;        // first tile of the block
+    const int co0 = blockIdx.y * 16;
+    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
+    const int npix = p.TN * HT * WT;
+
+    // this lane's tile inside the block
+    const int t = wave * 16 + li;
+    const int ttx = t & (TTW - 1), tty = (t >> p.lgTW) & (TTH - 1), ttn = t >> (p.lgTW + p.lgTH);
+    const int pbase = ((ttn * HT + 2 * tty) * WT + 2 * ttx) * KCP + 4 * kk;
+
+    int xsrc[XPT], xdst[XPT], usrc[UPT], udst[UPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx >> 2, v = idx & 3;
+        const int r2 = (int)__umulhi((unsigned)q, p.mWT), tw = q - r2 * WT;
+        const int tn = (int)__umulhi((unsigned)r2, p.mHT), th = r2 - tn * HT;
+        const int n = n0 + tn;
+        int ih = 2 * ty0 + th - 1, iw = 2 * tx0 + tw - 1;
+        const bool in_tile = q < npix;
+        const bool ok = in_tile && n < p.N && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        if (p.ups) { ih >>= 1; iw >>= 1; }
+        xdst[i] = in_tile ? q * KCP + 4 * v : -1;
+        xsrc[i] = ok ? (((n * xH + ih) * xW + iw) * p.Cin + 4 * v) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 2, v = idx & 3;                 // r = xi*16 + co
+        const int xi = r >> 4, co = co0 + (r & 15);
+        udst[i] = r * KCP + 4 * v;
+        usrc[i] = co < p.Cout ? ((xi * p.Cout + co) * p.Cin + 4 * v) : -1;
+    }
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 xreg[XPT], ureg[UPT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < UPT; ++i)
+            ureg[i] = usrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.u + (size_t)(unsigned)(usrc[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+            xreg[i] = xsrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)(xsrc[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < p.Cin; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) *reinterpret_cast<float4*>(ut + udst[i]) = ureg[i];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) if (xdst[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
+        __syncthreads();
+        if (k0 + 16 < p.Cin) fetch(k0 + 16);
+
+        float4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[a][c] = *reinterpret_cast<const float4*>(xt + pbase + (a * WT + c) * KCP);
+        // V = B^T d B, in place
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 t0 = f4sub(d[0][c], d[2][c]), t1 = f4add(d[1][c], d[2][c]);
+            const float4 t2 = f4sub(d[2][c], d[1][c]), t3 = f4sub(d[1][c], d[3][c]);
+            d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 t0 = f4sub(d[a][0], d[a][2]), t1 = f4add(d[a][1], d[a][2]);
+            const float4 t2 = f4sub(d[a][2], d[a][1]), t3 = f4sub(d[a][1], d[a][3]);
+            d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
+        }
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            const float4 a = *reinterpret_cast<const float4*>(ut + (xi * 16 + li) * KCP + 4 * kk);
+            const float4 v = d[xi >> 2][xi & 3];
+            acc[xi] = MFMA16(a.x, v.x, acc[xi]); acc[xi] = MFMA16(a.y, v.y, acc[xi]);
+            acc[xi] = MFMA16(a.z, v.z, acc[xi]); acc[xi] = MFMA16(a.w, v.w, acc[xi]);
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform Y = A^T M A (lane-local), then the fused epilogue on the 2x2 outputs
+    f32x4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = acc[0 + j] + acc[4 + j] + acc[8 + j];
+        s[1][j] = acc[4 + j] - acc[8 + j] - acc[12 + j];
+    }
+    f32x4 yq[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        yq[a][0] = s[a][0] + s[a][1] + s[a][2];
+        yq[a][1] = s[a][1] - s[a][2] - s[a][3];
+    }
+    const int cb = co0 + 4 * kk;
+    const int ni = n0 + ttn;
+    if (cb >= p.Cout || ni >= p.N) return;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + cb);
+    const int oy0 = 2 * (ty0 + tty), ox0 = 2 * (tx0 + ttx);
+    float4 ov[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = yq[q >> 1][q & 1];
+        const size_t off = (((size_t)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1)) * p.Cout + cb;
+        float4 o = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
+        if (p.mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
+            o.x *= mk.x > 0.f ? 1.f : p.mask_slope; o.y *= mk.y > 0.f ? 1.f : p.mask_slope;
+            o.z *= mk.z > 0.f ? 1.f : p.mask_slope; o.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+        } else {
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+            o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
+            o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+        }
+        ov[q] = o;
+        if (p.yup) {                                         // pool adjoint: four masked copies of every output
+            const float k = p.up_mul * 0.25f;
+            const size_t W2 = (size_t)2 * p.W;
+            const size_t ubase = (((size_t)ni * 2 * p.H + 2 * (oy0 + (q >> 1))) * W2 + 2 * (ox0 + (q & 1))) * p.Cout + cb;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const size_t uo = ubase + ((size_t)(dd >> 1) * W2 + (dd & 1)) * p.Cout;
+                float4 w4 = make_float4(o.x * k, o.y * k, o.z * k, o.w * k);
+                if (p.upmask) {
+                    const float4 mk = *reinterpret_cast<const float4*>(p.upmask + uo);
+                    w4.x *= mk.x > 0.f ? 1.f : p.mask_slope; w4.y *= mk.y > 0.f ? 1.f : p.mask_slope;
+                    w4.z *= mk.z > 0.f ? 1.f : p.mask_slope; w4.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+                }
+                *reinterpret_cast<float4*>(p.yup + uo) = w4;
+            }
+        } else if (!(p.ypool && p.pool_only)) {
+            *reinterpret_cast<float4*>(p.y + off) = o;
+        }
+    }
+    if (p.ypool) {                                           // the 2x2 outputs of a tile ARE one pooled pixel
+        float4 v;
+        v.x = ((ov[0].x + ov[1].x) + (ov[2].x + ov[3].x)) * 0.25f; v.y = ((ov[0].y + ov[1].y) + (ov[2].y + ov[3].y)) * 0.25f;
+        v.z = ((ov[0].z + ov[1].z) + (ov[2].z + ov[3].z)) * 0.25f; v.w = ((ov[0].w + ov[1].w) + (ov[2].w + ov[3].w)) * 0.25f;
+        const size_t poff = (((size_t)ni * (p.H >> 1) + (oy0 >> 1)) * (p.W >> 1) + (ox0 >> 1)) * p.Cout + cb;
+        if (p.pool_other) {
+            const float4 q = *reinterpret_cast<const float4*>(p.pool_other + poff);
+            v.x = fmaf(v.x, p.pool_a, p.pool_b * q.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * q.y);
+            v.z = fmaf(v.z, p.pool_a, p.pool_b * q.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * q.w);
+        } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
+        *reinterpret_cast<float4*>(p.ypool + poff) = v;
+    }
+}
+
+// all layers of a network in one launch (layer l: w at wbase + woff[l], u at ubase + uoff[l])
+constexpr int WB_MAX = 32;
+struct WinoBatch {
+    int n;
+    int first_block[WB_MAX + 1];
+    long long woff[WB_MAX], uoff[WB_MAX];
+    int cout[WB_MAX], cin[WB_MAX];
+};
+
+__global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* __restrict__ wbase, float* __restrict__ ubase, WinoBatch d)
+{
+    int l = 0;
+    while (l + 1 < d.n && (int)blockIdx.x >= d.first_block[l + 1]) ++l;
+    const float* w = wbase + d.woff[l];
+    float* u = ubase + d.uoff[l];
+    const size_t n = (size_t)d.cout[l] * d.cin[l];
+    const size_t i = (size_t)(blockIdx.x - d.first_block[l]) * 256 + threadIdx.x;
+    if (i >= n) return;
+    float g[3][3], t[4][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = w[(size_t)(a * 3 + b) * n + i];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
+        t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        u[(size_t)(4 * a + 0) * n + i] = t[a][0];
+        u[(size_t)(4 * a + 1) * n + i] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
+        u[(size_t)(4 * a + 2) * n + i] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
+        u[(size_t)(4 * a + 3) * n + i] = t[a][2];
+    }
+}
+
+inline int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+thread_local char g_wino_last[64] = "";
+
+}  // namespace
+
+extern "C" const char* pg_debug_last_wino_kernel(void) { return g_wino_last; }
+
+extern "C" int pg_wino_transform_weights(const float* w, float* u, int Cout, int Cin, pg_stream_t stream)
+{
+    if (!w || !u || Cout <= 0 || Cin <= 0) return PG_E_ARG;
+    size_t g = ((size_t)Cout * Cin + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, u, Cout, Cin);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_wino_transform_weights_batched(const float* wbase, float* ubase, int nlayers, const int64_t* woff,
+                                                 const int64_t* uoff, const int* cout, const int* cin, pg_stream_t stream)
+{
+    if (!wbase || !ubase || nlayers <= 0 || !woff || !uoff || !cout || !cin) return PG_E_ARG;
+    for (int l0 = 0; l0 < nlayers; l0 += WB_MAX) {
+        WinoBatch d;
+        d.n = nlayers - l0 < WB_MAX ? nlayers - l0 : WB_MAX;
+        int total = 0;
+        for (int l = 0; l < d.n; ++l) {
+            const int i = l0 + l;
+            if (cout[i] <= 0 || cin[i] <= 0 || woff[i] < 0 || uoff[i] < 0) return PG_E_ARG;
+            d.first_block[l] = total;
+            d.woff[l] = woff[i]; d.uoff[l] = uoff[i]; d.cout[l] = cout[i]; d.cin[l] = cin[i];
+            total += (int)(((size_t)cout[i] * cin[i] + 255) / 256);
+        }
+        d.first_block[d.n] = total;
+        hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, wbase, ubase, d);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const float* mask, float* y,
+                                   float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
+                                   float* yup, const float* upmask, float up_mul,
+                                   int N, int H, int W, int Cin, int Cout, int ups,
+                                   float scale, float slope, float mask_slope, pg_stream_t stream)
+{
+    if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
+    if ((Cin & 15) || (Cout & 3)) return PG_E_ALIGN;
+    if (!pow2(H) || !pow2(W) || H < 8 || W < 8) return PG_E_UNSUP;
+    if ((long long)N * H * W * Cin >= (1ll << 31) || (long long)N * H * W * Cout >= (1ll << 29) || (long long)16 * Cout * Cin >= (1ll << 31))
+        return PG_E_UNSUP;
+    WinoP p;
+    p.x = x; p.u = u; p.bias = bias; p.mask = mask; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups;
+    p.scale = scale; p.slope = slope; p.mask_slope = mask_slope;
+    p.ypool = ypool; p.pool_other = pool_other; p.pool_a = pool_a; p.pool_b = pool_b; p.pool_only = pool_only;
+    p.yup = yup; p.upmask = upmask; p.up_mul = up_mul;
+    const int tilesW = W >> 1, tilesH = H >> 1;
+    int TTW = tilesW < 8 ? tilesW : 8;
+    int TTH = 64 / TTW; if (TTH > tilesH) TTH = tilesH;
+    const int TN = 64 / (TTW * TTH);
+    p.lgTW = ilog2i(TTW); p.lgTH = ilog2i(TTH); p.TN = TN;
+    p.blocksW = tilesW / TTW; p.blocksH = tilesH / TTH;
+    const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
+    if (TN * HT * WT > XMAX) return PG_E_UNSUP;
+    p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
+    const size_t smem = (size_t)(16 * 16 + TN * HT * WT) * KCP * sizeof(float);
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid((unsigned)(((N + TN - 1) / TN) * p.blocksH * p.blocksW), (unsigned)((Cout + 15) / 16));
+    snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino_kernel");
+    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), smem, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

@@ -35,33 +35,107 @@ def _check_dev(t, what):
     return t.contiguous()
 
 
-def _wt(net, layer):
-    """Backward-data (flipped/transposed) copy of a conv layer's weights, refreshed lazily."""
+# Winograd F(2x2,3x3) (csrc/conv_wino.hip) replaces the direct implicit GEMM where it measured faster: wide 3x3
+# layers (>= 32 channels on both sides) with enough 64-tile workgroups to fill the chip (tools/sweep_wino.py).
+USE_WINOGRAD = True
+WINO_MIN_WORKGROUPS = 384
+
+
+def _derived(net):
+    """Derived weight copies of a network, refreshed with three launches per weight version: backward-data
+    (flipped / transposed) weights, and the Winograd-domain forward and backward-data weights."""
     net._ensure_buffers()
     ver = net._param_version
-    if getattr(layer, '_wt_ver', None) != ver or layer._wt is None:
-        # one launch re-packs every conv layer of the network (they share the flat buffer and its mirror)
-        todo = [m for m in net._layers() if m.kind == 'conv' and m._wt is not None]
-        base = net._flat_param.data_ptr()
-        ops.pack_dgrad_weights_batched(net._flat_param, net._flat_wt,
-                                       [((m.conv.weight.data_ptr() - base) // 4, m.ksize, m.conv.weight.shape[2],
-                                         m.conv.weight.shape[3]) for m in todo])
-        for m in todo:
-            m._wt_ver = ver
+    if net._derived_ver == ver:
+        return
+    base = net._flat_param.data_ptr()
+    todo = [m for m in net._layers() if m.kind == 'conv' and m._wt is not None]
+    ops.pack_dgrad_weights_batched(net._flat_param, net._flat_wt,
+                                   [((m.conv.weight.data_ptr() - base) // 4, m.ksize, m.conv.weight.shape[2],
+                                     m.conv.weight.shape[3]) for m in todo])
+    if USE_WINOGRAD and net._wino_layers:
+        ops.wino_transform_weights_batched(net._flat_param, net._flat_wu,
+                                           [(woff, uoff, m.conv.weight.shape[2], m.conv.weight.shape[3])
+                                            for m, woff, uoff in net._wino_layers])
+        ops.wino_transform_weights_batched(net._flat_wt, net._flat_wtu,
+                                           [(woff, uoff, m.conv.weight.shape[3], m.conv.weight.shape[2])
+                                            for m, woff, uoff in net._wino_layers])
+    net._derived_ver = ver
+
+
+def _wt(net, layer):
+    """Backward-data (flipped/transposed) copy of a conv layer's weights, refreshed lazily."""
+    _derived(net)
     return layer._wt
+
+
+def _wino(layer, N, H, cout, transposed=False):
+    """Winograd-domain weights of ``layer`` if that path should run for an N x H x H output with ``cout`` channels."""
+    if not USE_WINOGRAD or getattr(layer, '_wu', None) is None or H < 8:
+        return None
+    if -(-(N * (H // 2) * (H // 2)) // 64) * -(-cout // 16) < WINO_MIN_WORKGROUPS:
+        return None
+    _derived(layer._net())
+    return layer._wtu if transposed else layer._wu
 
 
 def _conv(x, layer, N, H, act=True, mask=None, bias=True, ups=False, out=None):
     """Forward conv (+bias+act) or, with ``mask``, the masked linear map of the tangent pass."""
+    u = _wino(layer, N, H, layer.conv.weight.shape[2])
+    if u is not None:
+        return ops.conv2d_wino(x, u, layer.conv.bias.data if bias else None, N, H, H, layer.c,
+                               layer.slope if act else 1.0, mask=mask, mask_slope=layer.slope, ups=ups, out=out)
     return ops.conv2d(x, layer.conv.weight.data, layer.conv.bias.data if bias else None, N, H, H,
                       layer.ksize, layer.pad, layer.c, layer.slope if act else 1.0,
                       mask=mask, mask_slope=layer.slope, ups=ups, out=out)
 
 
+def _conv_pool(x, layer, N, H, bias=True, mask=None, other=None, a=1.0, b=0.0, pool_only=False):
+    """conv (+bias+act | mask) followed by the 2x2 average pool / fade-in blend, one launch."""
+    u = _wino(layer, N, H, layer.conv.weight.shape[2])
+    if u is not None:
+        return ops.conv2d_wino(x, u, layer.conv.bias.data if bias else None, N, H, H, layer.c,
+                               layer.slope if mask is None else 1.0, mask=mask, mask_slope=layer.slope,
+                               pool=True, other=other, a=a, b=b, pool_only=pool_only)
+    return ops.conv2d_pool(x, layer.conv.weight.data, layer.conv.bias.data if bias else None, N, H, H, layer.ksize, layer.pad,
+                           layer.c, layer.slope if mask is None else 1.0, mask=mask, mask_slope=layer.slope,
+                           other=other, a=a, b=b, pool_only=pool_only)
+
+
 def _dgrad(net, gz, layer, N, Hout, mask=None, mask_slope=0.2):
     """Adjoint of the conv wrt its input: gz [N,Hout,Hout,Cout] -> [N,Hin,Hin,Cin_store] (* mask)."""
+    u = _wino(layer, N, Hout, layer.conv.weight.shape[3], transposed=True) if layer.ksize == 3 and layer.pad == 1 else None
+    if u is not None:
+        return ops.conv2d_wino(gz, u, None, N, Hout, Hout, layer.c, 1.0, mask=mask, mask_slope=mask_slope)
     return ops.conv2d(gz, _wt(net, layer), None, N, Hout, Hout, layer.ksize, layer.ksize - 1 - layer.pad,
                       layer.c, 1.0, mask=mask, mask_slope=mask_slope)
+
+
+def _dgrad_pool(net, gz, layer, N, H, other=None, a=1.0, b=0.0):
+    """Backward-data conv + 2x2 pooled epilogue (a * mean + b * other); only the pooled result is produced."""
+    u = _wino(layer, N, H, layer.conv.weight.shape[3], transposed=True)
+    if u is not None:
+        return ops.conv2d_wino(gz, u, None, N, H, H, layer.c, 1.0, pool=True, other=other, a=a, b=b, pool_only=True)[1]
+    return ops.conv2d_pool(gz, _wt(net, layer), None, N, H, H, layer.ksize, layer.ksize - 1 - layer.pad, layer.c, 1.0,
+                           other=other, a=a, b=b, pool_only=True)[1]
+
+
+def _dgrad_unpool(net, gz, layer, N, H, upmask, mul, mask_slope):
+    """Backward-data conv + pool adjoint + LeakyReLU' mask of the finer activation, one launch."""
+    u = _wino(layer, N, H, layer.conv.weight.shape[3], transposed=True)
+    if u is not None:
+        return ops.conv2d_wino(gz, u, None, N, H, H, layer.c, 1.0, mask_slope=mask_slope, unpool=True, upmask=upmask, up_mul=mul)
+    return ops.conv2d_unpool(gz, _wt(net, layer), N, H, H, layer.ksize, layer.ksize - 1 - layer.pad, layer.c,
+                             upmask=upmask, mul=mul, mask_slope=mask_slope)
+
+
+def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
+    """Backward-data conv + adjoint of the previous layer's (LeakyReLU -> PixelNorm)."""
+    u = _wino(layer, N, H, layer.conv.weight.shape[3], transposed=True)
+    if u is not None:                              # wide layers: Winograd conv, then the (HBM-bound) adjoint kernel in place
+        g = ops.conv2d_wino(gz, u, None, N, H, H, layer.c, 1.0)
+        return ops.pixelnorm_lrelu_bwd(g, ysaved, r, slope, inplace=True)
+    return ops.conv2d_pnbwd(gz, _wt(net, layer), ysaved, r, N, H, H, layer.ksize, layer.ksize - 1 - layer.pad, layer.c, slope)
 
 
 # Weight gradients are leaves of the backward sweeps (nothing downstream reads them before the optimizer), so
@@ -140,6 +214,7 @@ def generator_forward(G, z, save=False, out=None):
     depth, alpha = int(G.depth), float(G.alpha)
     C = G.num_channels
     b0 = G.block0
+    G._ensure_buffers()
     ctx = dict(N=N, depth=depth, alpha=alpha, recs=[])
     if G.normalize_latents:
         zn, _ = ops.pixelnorm_fwd(z, G.eps)                                   # :120-123
@@ -148,7 +223,12 @@ def generator_forward(G, z, save=False, out=None):
     ctx['zn'] = zn
 
     def layer(x, lay, H, ups=False):
-        if lay.pixelnorm:                         # conv + bias + act + PixelNorm in one launch where the tile allows it
+        if lay.pixelnorm:
+            u = _wino(lay, N, H, lay.conv.weight.shape[2]) if lay.ksize == 3 else None
+            if u is not None:                     # wide layers: Winograd conv, PixelNorm as its own (HBM-bound) pass
+                y = ops.conv2d_wino(x, u, lay.conv.bias.data, N, H, H, lay.c, lay.slope, ups=ups)
+                return ops.pixelnorm_fwd(y, lay.eps, inplace=True)
+            # conv + bias + act + PixelNorm in one launch where the tile allows it
             return ops.conv2d_pixelnorm(x, lay.conv.weight.data, lay.conv.bias.data, N, H, H, lay.ksize, lay.pad, lay.c,
                                         lay.slope, lay.eps, ups=ups)
         return _conv(x, lay, N, H, ups=ups), None
@@ -213,12 +293,11 @@ def generator_backward(G, ctx, g_out):
         gz2 = ops.pixelnorm_lrelu_bwd(g, rec['a2'], rec['r2'], c2.slope, inplace=True)
         _wgrad(rec['a1'], gz2, c2, N, H)
         # backward-data conv of c2 + adjoint of c1's (LeakyReLU -> PixelNorm) in one launch
-        gz1 = ops.conv2d_pnbwd(gz2, _wt(G, c2), rec['a1'], rec['r1'], N, H, H, c2.ksize, c2.ksize - 1 - c2.pad, c2.c, c1.slope)
+        gz1 = _dgrad_pnbwd(G, gz2, c2, N, H, rec['a1'], rec['r1'], c1.slope)
         _wgrad(rec['inp'], gz1, c1, N, H, ups=True)
         # backward-data conv of c1 + adjoint of the nearest x2 upsample (sum over 2x2 = 4 * average pool, exact in fp32)
         # + the fade-in branch's gradient, all in the conv epilogue
-        _, g = ops.conv2d_pool(gz1, _wt(G, c1), None, N, H, H, c1.ksize, c1.ksize - 1 - c1.pad, c1.c, 1.0,
-                               other=g_extra, a=4.0, b=1.0, pool_only=True)
+        g = _dgrad_pool(G, gz1, c1, N, H, other=g_extra, a=4.0, b=1.0)
         g_extra = None
         active += [c1, c2]
     gz2 = ops.pixelnorm_lrelu_bwd(g, ctx['y2'], ctx['r2'], b0.c2.slope, inplace=True)
@@ -241,6 +320,7 @@ def d_forward(D, x, groups=1):
         raise ValueError('input %s does not match depth %d / %d channels' % (tuple(x.shape), depth, D.num_channels))
     nb = len(D.blocks)
     e = nb - 1 - depth                                                        # blocks[-(depth+1)]  (:227)
+    D._ensure_buffers()
     ctx = dict(NB=NB, groups=groups, depth=depth, alpha=alpha, x=x, recs=[])
     pn = bool(getattr(D, 'pixelnorm', False))
     fr = D.blocks[e].fromRGB
@@ -276,9 +356,7 @@ def d_forward(D, x, groups=1):
                 a2, rec['r2'] = ops.pixelnorm_fwd(a2, inplace=True)
                 cur = ops.avgpool2_fwd(a2, pf, pa, pb)                        # :229,238
             else:                                                             # pool (+ fade-in blend) in the conv epilogue
-                c2 = blk.c2
-                a2, cur = ops.conv2d_pool(a1, c2.conv.weight.data, c2.conv.bias.data, NB, H, H, c2.ksize, c2.pad, c2.c,
-                                          c2.slope, other=pf, a=pa, b=pb)
+                a2, cur = _conv_pool(a1, blk.c2, NB, H, other=pf, a=pa, b=pb)
             rec.update(a1=a1, a2=a2)
             H //= 2
         ctx['recs'].append(rec)
@@ -366,8 +444,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             if not rec['first'] and not (recs[idx - 1]['first'] and alpha < 1.0):
                 # backward-data conv + pool adjoint + LeakyReLU' of the finer block's output in one kernel
                 pv = recs[idx - 1]
-                g_fused = ops.conv2d_unpool(gz1, _wt(D, c1), NB, H, H, c1.ksize, c1.ksize - 1 - c1.pad, c1.c,
-                                            upmask=pv['a2'], mul=1.0, mask_slope=pv['blk'].c2.slope)
+                g_fused = _dgrad_unpool(D, gz1, c1, NB, H, pv['a2'], 1.0, pv['blk'].c2.slope)
                 gin = None
             else:
                 gin = _dgrad(D, gz1, c1, NB, H, mask=rec['inp'] if rec['first'] else None, mask_slope=fr_slope)
@@ -567,8 +644,7 @@ def d_tangent_wgrad(D, sub, adj, u):
                 t2, injs[idx]['inj2'] = ops.pixelnorm_tangent(t2, rec['a2'], rec['r2'], adj[idx]['gy2'])
                 cur = ops.avgpool2_fwd(t2, tpf, pa, pb)
             else:                                                 # only the pooled tangent is needed downstream
-                t2, cur = ops.conv2d_pool(t1, c2.conv.weight.data, None, N, H, H, c2.ksize, c2.pad, c2.c, 1.0,
-                                          mask=rec['a2'], mask_slope=c2.slope, other=tpf, a=pa, b=pb, pool_only=True)
+                t2, cur = _conv_pool(t1, c2, N, H, bias=False, mask=rec['a2'], other=tpf, a=pa, b=pb, pool_only=True)
     # Linear: d/dw <ones, w . t2> = sum_n t2[n]
     ops.linear1_wgrad(_ones(N, u.device), t2, D._lin_gw, None)
     return hvp + (injs,) if pn else hvp

@@ -34,8 +34,7 @@ def clear():
 def _force_repack(net, layers):
     """The derived backward-data weights must be re-packed on EVERY replay: make them stale so that the
     pack kernels are part of the captured sequence."""
-    for m in layers:
-        m._wt_ver = None
+    net._derived_ver = None
 
 
 def _d_active_conv(D, depth):

@@ -107,6 +107,8 @@ class PGConv2d(nn.Module):
         d = self.__dict__.copy()
         d['_gw'] = d['_gb'] = d['_wt'] = None
         d['_wt_ver'] = None
+        d['_wu'] = d['_wtu'] = None
+        d['_net'] = None
         return d
 
 
@@ -196,6 +198,9 @@ class _FlatParamsMixin(object):
         self._flat_wt = None
         for m in self._layers():
             m._gw = m._gb = m._wt = None
+            m._wu = m._wtu = None
+        self._flat_wu = self._flat_wtu = None
+        self._derived_ver = None
         self._param_version = getattr(self, '_param_version', 0) + 1
         for m in self._layers():
             m._wt_ver = None
@@ -224,6 +229,26 @@ class _FlatParamsMixin(object):
             if m.kind == 'conv':
                 ks, _, co, ci = w.shape
                 m._wt = self._flat_wt[ow:ow + w.numel()].view(ks, ks, ci, co)
+        # Winograd-domain copies (forward and backward-data) of the wide 3x3 layers: 16/9 of their weights each
+        wl = [m for m in self._layers() if m.kind == 'conv' and m.ksize == 3 and m.pad == 1 and
+              m.conv.weight.shape[2] % 16 == 0 and m.conv.weight.shape[3] % 16 == 0 and
+              min(m.conv.weight.shape[2], m.conv.weight.shape[3]) >= 32]
+        total = sum(16 * m.conv.weight.shape[2] * m.conv.weight.shape[3] for m in wl)
+        self._flat_wu = torch.zeros(max(total, 4), dtype=torch.float32, device=flat.device)
+        self._flat_wtu = torch.zeros(max(total, 4), dtype=torch.float32, device=flat.device)
+        self._wino_layers = []
+        off = 0
+        for m in self._layers():
+            m._wu = m._wtu = None
+            m._net = weakref.ref(self)
+        for m in wl:
+            co, ci = m.conv.weight.shape[2], m.conv.weight.shape[3]
+            n = 16 * co * ci
+            m._wu = self._flat_wu[off:off + n].view(16, co, ci)
+            m._wtu = self._flat_wtu[off:off + n].view(16, ci, co)
+            self._wino_layers.append((m, byptr[id(m.conv.weight)], off))
+            off += n
+        self._derived_ver = None
         if hasattr(self, 'linear'):
             ow, ob = byptr[id(self.linear.weight)], byptr[id(self.linear.bias)]
             self._lin_gw = self._flat_grad[ow:ow + self.linear.weight.numel()].view(self.linear.weight.shape)
@@ -250,6 +275,9 @@ class _FlatParamsMixin(object):
         d = self.__dict__.copy()
         d['_flat_grad'] = None
         d['_flat_wt'] = None
+        d['_flat_wu'] = d['_flat_wtu'] = None
+        d['_wino_layers'] = None
+        d['_derived_ver'] = None
         d['_lin_gw'] = d['_lin_gb'] = None
         return d
 

@@ -41,6 +41,46 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
     return y
 
 
+def wino_transform_weights(w, u=None):
+    """w packed [3,3,Cout,Cin] -> Winograd-domain weights u [16,Cout,Cin]."""
+    ks, _, cout, cin = w.shape
+    assert ks == 3
+    if u is None:
+        u = torch.empty((16, cout, cin), device=w.device, dtype=torch.float32)
+    _lib.call('pg_wino_transform_weights', _p(w), _p(u), cout, cin, _stream())
+    return u
+
+
+def wino_transform_weights_batched(flat_w, flat_u, layers):
+    """layers: [(w element offset in flat_w, u element offset in flat_u, cout, cin), ...]; one launch."""
+    import ctypes
+    n = len(layers)
+    if n == 0:
+        return
+    woff = (ctypes.c_int64 * n)(*[l[0] for l in layers])
+    uoff = (ctypes.c_int64 * n)(*[l[1] for l in layers])
+    co = (ctypes.c_int * n)(*[l[2] for l in layers])
+    ci = (ctypes.c_int * n)(*[l[3] for l in layers])
+    _lib.call('pg_wino_transform_weights_batched', _p(flat_w), _p(flat_u), n, ctypes.cast(woff, ctypes.c_void_p),
+              ctypes.cast(uoff, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), ctypes.cast(ci, ctypes.c_void_p), _stream())
+
+
+def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None,
+                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0):
+    """3x3 pad-1 conv on Winograd-domain weights (+ the fused pool / unpool epilogues).  Returns y, (y, ypool) or yup."""
+    cout, cin = u.shape[1], u.shape[2]
+    y = out if out is not None else torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    yp = torch.empty((N, H // 2, W // 2, cout), device=x.device, dtype=torch.float32) if pool else None
+    yu = torch.empty((N, 2 * H, 2 * W, cout), device=x.device, dtype=torch.float32) if unpool else None
+    _lib.call('pg_conv2d_wino_nhwc', _p(x), _p(u), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
+              _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, 1 if ups else 0, scale, slope, mask_slope, _stream())
+    if pool:
+        return y, yp
+    if unpool:
+        return yu
+    return y
+
+
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
                 pool_only=False):
     """conv2d with the following 2x2 average pool (+ fade-in blend a*pool + b*other) fused into the epilogue.

@@ -63,6 +63,51 @@ def pack_dgrad_weights_batched(flat_w, flat_wt, layers):
         pack_dgrad_weights(w, flat_wt[off:off + ks * ks * co * ci].view(ks, ks, ci, co))
 
 
+class _WinoWeights(torch.Tensor):
+    """Emulated Winograd-domain weights: a [16,Cout,Cin] tensor that remembers the packed weights it came from."""
+
+
+def _wino_of(w):
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=w.dtype)
+    u = torch.einsum('ia,abok,jb->ijok', G, w, G).reshape(16, w.shape[2], w.shape[3])
+    return u
+
+
+def wino_transform_weights(w, u=None):
+    out = _wino_of(w)
+    if u is not None:
+        u.copy_(out)
+        out = u
+    return out
+
+
+def wino_transform_weights_batched(flat_w, flat_u, layers):
+    for woff, uoff, co, ci in layers:
+        w = flat_w[woff:woff + 9 * co * ci].view(3, 3, co, ci)
+        flat_u[uoff:uoff + 16 * co * ci].view(16, co, ci).copy_(_wino_of(w))
+
+
+def _unwino(u):
+    """Inverse of the weight transform on the 3x3 support (least squares; exact because G has full column rank)."""
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=u.dtype)
+    Gp = torch.linalg.pinv(G)
+    return torch.einsum('ai,ijok,bj->abok', Gp, u.view(4, 4, u.shape[1], u.shape[2]), Gp).contiguous()
+
+
+def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None,
+                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0):
+    w = _unwino(u)
+    y = conv2d(x, w, bias, N, H, W, 3, 1, scale, slope=slope, mask=mask, mask_slope=mask_slope, ups=ups)
+    if out is not None:
+        out.copy_(y)
+        y = out
+    if pool:
+        return y, avgpool2_fwd(y, other, a, b)
+    if unpool:
+        return avgpool2_bwd(y, upmask, up_mul, mask_slope)
+    return y
+
+
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
                 pool_only=False):
     y = conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=slope, mask=mask, mask_slope=mask_slope)

@@ -1,0 +1,106 @@
+"""Winograd F(2x2,3x3) path (csrc/conv_wino.hip): kernel vs the direct-conv emulation, and the engine with the path forced
+on for every eligible layer vs the CPU oracle (host emulation on CPU, HIP on the GPU)."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import rel_err
+from helpers import reference_grads
+import emu_ops as E
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+pg = importlib.import_module('pggan-pytorch_amd')
+oracle = importlib.import_module('oracle.pggan_cpu')
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g)
+
+
+def test_emulated_weight_transform_roundtrip():
+    w = rnd(3, 3, 32, 48)
+    assert rel_err(E._unwino(E.wino_transform_weights(w)), w) < 1e-5
+
+
+@pytest.fixture()
+def emu(monkeypatch):
+    for modname in ('engine', 'optim'):
+        mod = importlib.import_module('pggan-pytorch_amd.' + modname)
+        monkeypatch.setattr(mod, 'ops', E)
+    monkeypatch.setattr(pg.engine, '_check_dev', lambda t, what: t.contiguous())
+    yield
+
+
+def _engine_vs_oracle(dev, monkeypatch, res, depth, alpha, n):
+    monkeypatch.setattr(pg.engine, 'WINO_MIN_WORKGROUPS', 0)          # every eligible layer takes the Winograd path
+    torch.manual_seed(21)
+    shape = (1, 3, res, res)
+    kw = dict(fmap_base=256, fmap_max=64)
+    G = pg.Generator(shape, latent_size=64, **kw)
+    D = pg.Discriminator(shape, **kw)
+    gp, dp = G.reference_state_dict(), D.reference_state_dict()
+    G.to(dev); D.to(dev)
+    cfg = oracle.NetCfg(res, 3, latent_size=64, **kw)
+    G.depth = D.depth = depth
+    G.alpha = D.alpha = alpha
+    real, z_d, z_g, mix = oracle.synthetic_batch(300 + depth, n, 3, 4 * 2 ** depth, 64)
+    pg.wgan_gp_loss.set_mixing_factors(mix)
+    d_cost, rl, fl = pg.wgan_gp_D_loss(D, G, real.to(dev), z_d.to(dev))
+    d_cost.backward()
+    ref = oracle.d_loss_and_grads(dp, gp, cfg, real, z_d, mix, depth, alpha)
+    assert rel_err(d_cost, ref['D_cost']) < 2e-4
+    mine = reference_grads(D)
+    for k, v in ref['grads'].items():
+        assert rel_err(mine[k], v) < 2e-2, (k, rel_err(mine[k], v))
+    g_cost = pg.wgan_gp_G_loss(G, D, z_g.to(dev))
+    g_cost.backward()
+    refg = oracle.g_loss_and_grads(gp, dp, cfg, z_g, depth, alpha)
+    assert rel_err(g_cost, refg['G_cost']) < 2e-4
+    assert rel_err(G(z_g.to(dev)).cpu(), refg['fake']) < 2e-4
+    gm = reference_grads(G)
+    for k, v in refg['grads'].items():
+        assert rel_err(gm[k], v) < 2e-2, (k, rel_err(gm[k], v))
+    used = [m for m in D._layers() if getattr(m, '_wu', None) is not None]
+    assert used, 'no layer was eligible for the Winograd path: the test does not exercise it'
+
+
+@pytest.mark.parametrize('depth,alpha,n', [(2, 1.0, 2), (3, 0.6, 2)])
+def test_engine_with_winograd_host(emu, monkeypatch, depth, alpha, n):
+    _engine_vs_oracle('cpu', monkeypatch, 32, depth, alpha, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('depth,alpha,n', [(2, 1.0, 3), (3, 0.6, 2), (4, 1.0, 2)])
+def test_engine_with_winograd_gpu(monkeypatch, depth, alpha, n):
+    _engine_vs_oracle('cuda', monkeypatch, 64, depth, alpha, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2, 32, 64, 64, 0), (3, 16, 128, 96, 0), (1, 8, 32, 48, 0), (9, 8, 512, 512, 0), (2, 64, 32, 64, 1),
+                                  (3, 16, 528, 512, 0), (5, 8, 64, 36, 0), (1, 128, 32, 32, 1), (2, 8, 16, 32, 0)])
+def test_conv2d_wino_kernel(case):
+    N, H, ci, co, ups = case
+    ops = pg.ops
+    hin = H // 2 if ups else H
+    x, w, b = rnd(N, hin, hin, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    m, other, um = rnd(N, H, H, co, seed=3), rnd(N, H // 2, H // 2, co, seed=4), rnd(N, 2 * H, 2 * H, co, seed=5)
+    dev = lambda t: t.cuda()
+    u = ops.wino_transform_weights(dev(w))
+    assert rel_err(u, E.wino_transform_weights(w)) < 1e-6
+    tol = 2e-5
+    y = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.37, 0.2, ups=bool(ups))
+    assert rel_err(y, E.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2, ups=bool(ups))) < tol
+    y = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.37, mask=dev(m), mask_slope=0.2, ups=bool(ups))
+    assert rel_err(y, E.conv2d(x, w, None, N, H, H, 3, 1, 0.37, mask=m, mask_slope=0.2, ups=bool(ups))) < tol
+    if not ups:
+        y, yp = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.37, 0.2, pool=True, other=dev(other), a=0.6, b=0.4)
+        ry, ryp = E.conv2d_pool(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2, other=other, a=0.6, b=0.4)
+        assert rel_err(y, ry) < tol and rel_err(yp, ryp) < tol
+        _, yp = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.37, pool=True, a=4.0, pool_only=True)
+        assert rel_err(yp, E.conv2d_pool(x, w, None, N, H, H, 3, 1, 0.37, a=4.0)[1]) < tol
+        yu = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.37, mask_slope=0.2, unpool=True, upmask=dev(um), up_mul=0.7)
+        assert rel_err(yu, E.conv2d_unpool(x, w, N, H, H, 3, 1, 0.37, upmask=um, mul=0.7, mask_slope=0.2)) < tol
