@@ -110,6 +110,7 @@ int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const
                         int N, int H, int W, int Cin, int Cout, int ups,
                         float scale, float slope, float mask_slope, pg_stream_t stream);
 const char* pg_debug_last_wino_kernel(void);
+int pg_debug_set_wino(int vec);                 /* tuning aid: K-chunk of 4*vec channels (2 or 4) for the calling thread */
 
 /* Profiling aid: symbol (as rocprofv3 prints it, e.g. "conv_igemm_kernel<3, 4, 2, 2, 4>") of the conv
  * kernel instantiation most recently launched by the calling thread through the two entry points

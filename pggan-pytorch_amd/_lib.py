@@ -33,6 +33,7 @@ SIGNATURES = {
     'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P],
     'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
     'pg_debug_last_wino_kernel': [],
+    'pg_debug_set_wino': [I],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
     'pg_debug_last_conv_kernel': [],
     'pg_debug_set_tuning': [I, I],

@@ -17,6 +17,7 @@
 #include "pggan_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 namespace {
@@ -32,7 +33,7 @@ struct WinoP {
     float* yup; const float* upmask; float up_mul;
 };
 
-constexpr int KCP = 24;                        // LDS row stride of a 16-channel row (conflict-free b128)
+template <int VEC> struct WRow { static constexpr int value = VEC == 4 ? 24 : 12; };   // LDS row stride (floats), conflict-free b128 / b64
 constexpr int XMAX = 400;                      // halo pixels per workgroup: 18x18 (8x8 tiles) .. 4 x 10x10 (8x8 images)
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -64,10 +65,13 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
 {
-    constexpr int XPT = (XMAX * 4 + 255) / 256;             // float4 per thread for the halo region (16 channels)
-    constexpr int UPT = 4;                                   // 16 xi x 16 couts x 4 float4 / 256 threads
+    constexpr int KC = 4 * VEC, KCP = WRow<VEC>::value;
+    constexpr int XPT = (XMAX * VEC + 255) / 256;           // float4 per thread for the halo region (KC channels)
+    constexpr int UPT = VEC;                                 // 16 xi x 16 couts x VEC float4 / 256 threads
+    typedef float fragv __attribute__((ext_vector_type(VEC)));
     extern __shared__ __align__(16) float lds[];
     float* ut = lds;                                         // [16 xi][16 co][KCP]
     float* xt = lds + 16 * 16 * KCP;                         // [TN][HT][WT][KCP]
@@ -87,13 +91,13 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     // this lane's tile inside the block
     const int t = wave * 16 + li;
     const int ttx = t & (TTW - 1), tty = (t >> p.lgTW) & (TTH - 1), ttn = t >> (p.lgTW + p.lgTH);
-    const int pbase = ((ttn * HT + 2 * tty) * WT + 2 * ttx) * KCP + 4 * kk;
+    const int pbase = ((ttn * HT + 2 * tty) * WT + 2 * ttx) * KCP + VEC * kk;
 
     int xsrc[XPT], xdst[XPT], usrc[UPT], udst[UPT];
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
         const int idx = tid + 256 * i;
-        const int q = idx >> 2, v = idx & 3;
+        const int q = idx / VEC, v = idx - q * VEC;
         const int r2 = (int)__umulhi((unsigned)q, p.mWT), tw = q - r2 * WT;
         const int tn = (int)__umulhi((unsigned)r2, p.mHT), th = r2 - tn * HT;
         const int n = n0 + tn;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
         const int idx = tid + 256 * i;
-        const int r = idx >> 2, v = idx & 3;                 // r = xi*16 + co
+        const int r = idx / VEC, v = idx - r * VEC;          // r = xi*16 + co
         const int xi = r >> 4, co = co0 + (r & 15);
         udst[i] = r * KCP + 4 * v;
         usrc[i] = co < p.Cout ? ((xi * p.Cout + co) * p.Cin + 4 * v) : -1;
@@ -127,38 +131,45 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
             xreg[i] = xsrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)(xsrc[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     fetch(0);
-    for (int k0 = 0; k0 < p.Cin; k0 += 16) {
+    for (int k0 = 0; k0 < p.Cin; k0 += KC) {
 #pragma unroll
         for (int i = 0; i < UPT; ++i) *reinterpret_cast<float4*>(ut + udst[i]) = ureg[i];
 #pragma unroll
         for (int i = 0; i < XPT; ++i) if (xdst[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
         __syncthreads();
-        if (k0 + 16 < p.Cin) fetch(k0 + 16);
+        if (k0 + KC < p.Cin) fetch(k0 + KC);
 
-        float4 d[4][4];
+        // the patch as pairs of floats: the transform then compiles to packed adds (v_pk_add_f32, 2 lanes-of-channel / instr)
+        v2f d[4][4][VEC / 2];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d[a][c] = *reinterpret_cast<const float4*>(xt + pbase + (a * WT + c) * KCP);
+            for (int c = 0; c < 4; ++c) {
+                const fragv t = *reinterpret_cast<const fragv*>(xt + pbase + (a * WT + c) * KCP);
+#pragma unroll
+                for (int h = 0; h < VEC / 2; ++h) d[a][c][h] = v2f{t[2 * h], t[2 * h + 1]};
+            }
         // V = B^T d B, in place
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 t0 = f4sub(d[0][c], d[2][c]), t1 = f4add(d[1][c], d[2][c]);
-            const float4 t2 = f4sub(d[2][c], d[1][c]), t3 = f4sub(d[1][c], d[3][c]);
-            d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
-        }
+        for (int h = 0; h < VEC / 2; ++h) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 t0 = f4sub(d[a][0], d[a][2]), t1 = f4add(d[a][1], d[a][2]);
-            const float4 t2 = f4sub(d[a][2], d[a][1]), t3 = f4sub(d[a][1], d[a][3]);
-            d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
+            for (int c = 0; c < 4; ++c) {
+                const v2f t0 = d[0][c][h] - d[2][c][h], t1 = d[1][c][h] + d[2][c][h];
+                const v2f t2 = d[2][c][h] - d[1][c][h], t3 = d[1][c][h] - d[3][c][h];
+                d[0][c][h] = t0; d[1][c][h] = t1; d[2][c][h] = t2; d[3][c][h] = t3;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const v2f t0 = d[a][0][h] - d[a][2][h], t1 = d[a][1][h] + d[a][2][h];
+                const v2f t2 = d[a][2][h] - d[a][1][h], t3 = d[a][1][h] - d[a][3][h];
+                d[a][0][h] = t0; d[a][1][h] = t1; d[a][2][h] = t2; d[a][3][h] = t3;
+            }
         }
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
-            const float4 a = *reinterpret_cast<const float4*>(ut + (xi * 16 + li) * KCP + 4 * kk);
-            const float4 v = d[xi >> 2][xi & 3];
-            acc[xi] = MFMA16(a.x, v.x, acc[xi]); acc[xi] = MFMA16(a.y, v.y, acc[xi]);
-            acc[xi] = MFMA16(a.z, v.z, acc[xi]); acc[xi] = MFMA16(a.w, v.w, acc[xi]);
+            const fragv a = *reinterpret_cast<const fragv*>(ut + (xi * 16 + li) * KCP + VEC * kk);
+#pragma unroll
+            for (int s4 = 0; s4 < VEC; ++s4) acc[xi] = MFMA16(a[s4], d[xi >> 2][xi & 3][s4 >> 1][s4 & 1], acc[xi]);
         }
         __syncthreads();
     }
@@ -274,10 +285,12 @@ inline int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 thread_local char g_wino_last[64] = "";
+thread_local int g_wino_vec = 4;               // K-chunk = 4*vec channels (pg_debug_set_wino)
 
 }  // namespace
 
 extern "C" const char* pg_debug_last_wino_kernel(void) { return g_wino_last; }
+extern "C" int pg_debug_set_wino(int vec) { if (vec != 2 && vec != 4) return PG_E_ARG; g_wino_vec = vec; return 0; }
 
 extern "C" int pg_wino_transform_weights(const float* w, float* u, int Cout, int Cin, pg_stream_t stream)
 {
@@ -334,13 +347,18 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
     const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
     if (TN * HT * WT > XMAX) return PG_E_UNSUP;
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
-    const size_t smem = (size_t)(16 * 16 + TN * HT * WT) * KCP * sizeof(float);
-    if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
+    const int vec = g_wino_vec;
+    const size_t smem = (size_t)(16 * 16 + TN * HT * WT) * (vec == 4 ? 24 : 12) * sizeof(float);
     dim3 grid((unsigned)(((N + TN - 1) / TN) * p.blocksH * p.blocksW), (unsigned)((Cout + 15) / 16));
-    snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino_kernel");
-    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), smem, (hipStream_t)stream, p);
+    snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino_kernel<%d>", vec);
+    if (vec == 4) {
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(conv_wino_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL(conv_wino_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, p);
+    }
     return (int)hipGetLastError();
 }

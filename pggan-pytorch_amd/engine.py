@@ -37,8 +37,9 @@ def _check_dev(t, what):
 
 # Winograd F(2x2,3x3) (csrc/conv_wino.hip) replaces the direct implicit GEMM where it measured faster: wide 3x3
 # layers (>= 32 channels on both sides) with enough 64-tile workgroups to fill the chip (tools/sweep_wino.py).
-USE_WINOGRAD = True
-WINO_MIN_WORKGROUPS = 384
+import os as _os
+USE_WINOGRAD = _os.environ.get('PGGAN_WINOGRAD', '1') != '0'
+WINO_MIN_WORKGROUPS = int(_os.environ.get('PGGAN_WINO_MIN_WG', '384'))
 
 
 def _derived(net):

@@ -23,6 +23,10 @@ for (N, H, ci, co) in SHAPES:
     ym0 = ops.conv2d(x, w, None, N, H, H, 3, 1, 0.5, mask=m); ym1 = ops.conv2d_wino(x, u, None, N, H, H, 0.5, mask=m)
     errm = float((ym1 - ym0).abs().max() / ym0.abs().max())
     t0 = run(lambda: ops.conv2d(x, w, b, N, H, H, 3, 1, 0.5, 0.2, out=y0))
+    lib.pg_debug_set_wino(4)
     t1 = run(lambda: ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2, out=y1))
-    print('conv n%d @%d %d->%d: direct %.1fus %.0fTF   wino %.1fus %.0fTF (%.2fx)   rel err %.1e / masked %.1e' % (
-        N, H, ci, co, t0 * 1e6, fl / t0 / 1e12, t1 * 1e6, fl / t1 / 1e12, t0 / t1, err, errm), flush=True)
+    lib.pg_debug_set_wino(2)
+    t2 = run(lambda: ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2, out=y1))
+    lib.pg_debug_set_wino(4)
+    print('conv n%d @%d %d->%d: direct %.1fus %.0fTF   wino %.1fus %.0fTF (%.2fx)  wino-kc8 %.1fus (%.2fx)   rel err %.1e / masked %.1e' % (
+        N, H, ci, co, t0 * 1e6, fl / t0 / 1e12, t1 * 1e6, fl / t1 / 1e12, t0 / t1, t2 * 1e6, t0 / t2, err, errm), flush=True)
