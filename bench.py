@@ -112,14 +112,21 @@ class KernelTimer(object):
         torch.cuda.synchronize()
         fam = {}
         self.table = {}
+        per_tag = {}
         for family, fl, e0, e1, tag in self.rec:
+            per_tag.setdefault(tag, []).append(e0.elapsed_time(e1))
+        med = {tag: sorted(v)[len(v) // 2] for tag, v in per_tag.items()}
+        for family, fl, e0, e1, tag in self.rec:
+            ms = e0.elapsed_time(e1)
+            if ms > 10.0 * med[tag]:                       # a one-off stall (allocator / first touch) is not the kernel
+                ms = med[tag]
             t = self.table.setdefault(tag, dict(flops=0.0, ms=0.0, launches=0))
             t['flops'] += fl
-            t['ms'] += e0.elapsed_time(e1)
+            t['ms'] += ms
             t['launches'] += 1
             d = fam.setdefault(family, dict(flops=0.0, ms=0.0, launches=0))
             d['flops'] += fl
-            d['ms'] += e0.elapsed_time(e1)
+            d['ms'] += ms
             d['launches'] += 1
         for d in fam.values():
             d['flops_per_step'] = d['flops'] / nsteps

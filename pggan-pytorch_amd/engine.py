@@ -40,6 +40,7 @@ def _check_dev(t, what):
 import os as _os
 USE_WINOGRAD = _os.environ.get('PGGAN_WINOGRAD', '1') != '0'
 WINO_MIN_WORKGROUPS = int(_os.environ.get('PGGAN_WINO_MIN_WG', '384'))
+WINO_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_MIN_C', '32'))
 
 
 def _derived(net):
@@ -73,6 +74,8 @@ def _wt(net, layer):
 def _wino(layer, N, H, cout, transposed=False):
     """Winograd-domain weights of ``layer`` if that path should run for an N x H x H output with ``cout`` channels."""
     if not USE_WINOGRAD or getattr(layer, '_wu', None) is None or H < 8:
+        return None
+    if min(layer.conv.weight.shape[2], layer.conv.weight.shape[3]) < WINO_MIN_CHANNELS:
         return None
     if -(-(N * (H // 2) * (H // 2)) // 64) * -(-cout // 16) < WINO_MIN_WORKGROUPS:
         return None
