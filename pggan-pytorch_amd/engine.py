@@ -75,7 +75,8 @@ def _wino(layer, N, H, cout, transposed=False):
     """Winograd-domain weights of ``layer`` if that path should run for an N x H x H output with ``cout`` channels."""
     if not USE_WINOGRAD or getattr(layer, '_wu', None) is None or H < 8:
         return None
-    if min(layer.conv.weight.shape[2], layer.conv.weight.shape[3]) < WINO_MIN_CHANNELS:
+    cin = layer.conv.weight.shape[2] if transposed else layer.conv.weight.shape[3]     # input channels of THIS direction
+    if cin < WINO_MIN_CHANNELS:
         return None
     if -(-(N * (H // 2) * (H // 2)) // 64) * -(-cout // 16) < WINO_MIN_WORKGROUPS:
         return None

@@ -232,7 +232,7 @@ class _FlatParamsMixin(object):
         # Winograd-domain copies (forward and backward-data) of the wide 3x3 layers: 16/9 of their weights each
         wl = [m for m in self._layers() if m.kind == 'conv' and m.ksize == 3 and m.pad == 1 and
               m.conv.weight.shape[2] % 16 == 0 and m.conv.weight.shape[3] % 16 == 0 and
-              min(m.conv.weight.shape[2], m.conv.weight.shape[3]) >= 32]
+              max(m.conv.weight.shape[2], m.conv.weight.shape[3]) >= 32]     # each direction needs >= 32 INPUT channels
         total = sum(16 * m.conv.weight.shape[2] * m.conv.weight.shape[3] for m in wl)
         self._flat_wu = torch.zeros(max(total, 4), dtype=torch.float32, device=flat.device)
         self._flat_wtu = torch.zeros(max(total, 4), dtype=torch.float32, device=flat.device)
