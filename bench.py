@@ -63,7 +63,9 @@ class KernelTimer(object):
             e0.record()
             out = orig(*a, **k)
             e1.record()
-            sym = (lib.pg_debug_last_wino_kernel() if name == 'conv2d_wino' else lib.pg_debug_last_conv_kernel()).decode()
+            sym = (lib.pg_debug_last_wino_kernel() if name == 'conv2d_wino' else
+                   lib.pg_debug_last_wino_wgrad_kernel() if name == 'conv2d_wgrad_wino' else
+                   lib.pg_debug_last_conv_kernel()).decode()
             fl, tag = describe(a, k)
             self.rec.append((sym, fl, e0, e1, '%s %s' % (tag, sym.replace('conv_', '').replace('_kernel', ''))))
             return out
@@ -81,6 +83,10 @@ class KernelTimer(object):
             ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
             return (conv_flops(n, ho, wo, ks, pad, dw.shape[2], dw.shape[3]),
                     'wgrad %d->%d k%d @%d n%d' % (dw.shape[3], dw.shape[2], ks, ho, n))
+        def wino_wgrad_desc(a, k):    # conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=)
+            dw, n, h = a[2], a[4], a[5]
+            return (conv_flops(n, h, h, 3, 1, dw.shape[2], dw.shape[3]),
+                    'wgrad %d->%d k3 @%d n%d winograd' % (dw.shape[3], dw.shape[2], h, n))
         def pool_desc(a, k):          # conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, ...): the conv of conv_desc + pooled output
             fl, tag = conv_desc(a, k)
             return fl, tag + ' +pool'
@@ -102,6 +108,7 @@ class KernelTimer(object):
         self._wrap('conv2d_unpool', generic(1, 2, '+unpool'))
         self._wrap('conv2d_pnbwd', generic(1, 4, '+pn adjoint'))
         self._wrap('conv2d_wgrad', wgrad_desc)
+        self._wrap('conv2d_wgrad_wino', wino_wgrad_desc)
         return self
 
     def __exit__(self, *exc):

@@ -110,6 +110,13 @@ int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const
                         int N, int H, int W, int Cin, int Cout, int ups,
                         float scale, float slope, float mask_slope, pg_stream_t stream);
 const char* pg_debug_last_wino_kernel(void);
+
+/* Winograd weight gradient of the same layers: dW[kh][kw][co][ci] += scale * sum gz*x (3x3, pad 1), db[co] += sum gz, computed as
+ * G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G  -- 16 MFMAs per 4 output tiles instead of 36.  H, W powers of two with
+ * H >= 8, W >= 16; commits with fp32 atomics.  Same arguments as pg_conv2d_wgrad_nhwc (KS 3, pad 1 implied).          */
+int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float* dw, float* db,
+                              int N, int H, int W, int Cin, int Cout, int ups, float scale, pg_stream_t stream);
+const char* pg_debug_last_wino_wgrad_kernel(void);
 int pg_debug_set_wino(int vec);                 /* tuning aid: K-chunk of 4*vec channels (2 or 4) for the calling thread */
 
 /* Profiling aid: symbol (as rocprofv3 prints it, e.g. "conv_igemm_kernel<3, 4, 2, 2, 4>") of the conv

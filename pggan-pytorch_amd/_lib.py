@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class PgganLibraryError(RuntimeError):
@@ -33,6 +33,8 @@ SIGNATURES = {
     'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P],
     'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
     'pg_debug_last_wino_kernel': [],
+    'pg_conv2d_wgrad_wino_nhwc': [P, P, P, P, I, I, I, I, I, I, F, P],
+    'pg_debug_last_wino_wgrad_kernel': [],
     'pg_debug_set_wino': [I],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
     'pg_debug_last_conv_kernel': [],
@@ -93,7 +95,7 @@ def load():
         except AttributeError:
             raise PgganLibraryError('symbol %s missing from %s' % (name, LIB_PATH))
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name in ('pg_debug_last_conv_kernel', 'pg_debug_last_wino_kernel') else ctypes.c_int
+        fn.restype = ctypes.c_char_p if name in ('pg_debug_last_conv_kernel', 'pg_debug_last_wino_kernel', 'pg_debug_last_wino_wgrad_kernel') else ctypes.c_int
     v = lib.pg_abi_version()
     if v != ABI_VERSION:
         raise PgganLibraryError('ABI version mismatch: library %d, binding %d' % (v, ABI_VERSION))

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__); \
     return (int)hipGetLastError()
 
-extern "C" int pg_abi_version(void) { return 13; }
+extern "C" int pg_abi_version(void) { return 14; }
 
 extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
                                float a, float b, pg_stream_t stream)

@@ -133,6 +133,12 @@ def conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=False):
               1 if ups else 0, scale, _stream())
 
 
+def conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=False):
+    """Winograd form of conv2d_wgrad for 3x3 pad-1 layers: accumulates into dw [3,3,Cout,Cin] (and db)."""
+    cout, cin = dw.shape[2], dw.shape[3]
+    _lib.call('pg_conv2d_wgrad_wino_nhwc', _p(x), _p(gz), _p(dw), _p(db), N, H, W, cin, cout, 1 if ups else 0, scale, _stream())
+
+
 def pack_dgrad_weights(w, wt):
     ks, _, cout, cin = w.shape
     _lib.call('pg_pack_dgrad_weights', _p(w), _p(wt), ks, cout, cin, _stream())

@@ -57,6 +57,10 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
     return _ret(y, out)
 
 
+def conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=False):
+    conv2d_wgrad(x, gz, dw, db, N, H, W, 3, 1, scale, ups=ups)
+
+
 def pack_dgrad_weights_batched(flat_w, flat_wt, layers):
     for off, ks, co, ci in layers:
         w = flat_w[off:off + ks * ks * co * ci].view(ks, ks, co, ci)

@@ -104,3 +104,33 @@ def test_conv2d_wino_kernel(case):
         assert rel_err(yp, E.conv2d_pool(x, w, None, N, H, H, 3, 1, 0.37, a=4.0)[1]) < tol
         yu = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.37, mask_slope=0.2, unpool=True, upmask=dev(um), up_mul=0.7)
         assert rel_err(yu, E.conv2d_unpool(x, w, N, H, H, 3, 1, 0.37, upmask=um, mul=0.7, mask_slope=0.2)) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2, 16, 32, 32, 0), (3, 16, 64, 96, 0), (1, 32, 36, 48, 0), (9, 16, 128, 64, 0), (2, 64, 32, 64, 1),
+                                  (5, 32, 8, 40, 1), (1, 128, 32, 32, 0), (7, 16, 100, 36, 0), (2, 16, 32, 32, 1)])
+def test_conv2d_wgrad_wino_kernel(case):
+    """csrc/conv_wino_wgrad.hip vs the torch restatement of the weight gradient, accumulating onto non-zero dw/db;
+    ragged channel counts (not multiples of the 32x32 block) and the upsample-fused input included."""
+    N, H, ci, co, ups = case
+    ops = pg.ops
+    hin = H // 2 if ups else H
+    x, gz = rnd(N, hin, hin, ci), rnd(N, H, H, co, seed=1)
+    dw0, db0 = rnd(3, 3, co, ci, seed=2), rnd(co, seed=3)
+    rdw, rdb = dw0.clone(), db0.clone()
+    E.conv2d_wgrad(x, gz, rdw, rdb, N, H, H, 3, 1, 0.41, ups=bool(ups))
+    dw, db = dw0.cuda(), db0.cuda()
+    ops.conv2d_wgrad_wino(x.cuda(), gz.cuda(), dw, db, N, H, H, 0.41, ups=bool(ups))
+    assert pg._lib.load().pg_debug_last_wino_wgrad_kernel().decode() == 'conv_wino_wgrad_kernel'
+    assert rel_err(dw, rdw) < 2e-5 and rel_err(db, rdb) < 2e-5
+    dw2 = dw0.cuda()
+    ops.conv2d_wgrad_wino(x.cuda(), gz.cuda(), dw2, None, N, H, H, 0.41, ups=bool(ups))
+    assert rel_err(dw2, rdw) < 2e-5
+
+
+@pytest.mark.gpu
+def test_conv2d_wgrad_wino_rejects_small_maps():
+    ops = pg.ops
+    x, gz = torch.zeros(2, 8, 8, 32, device='cuda'), torch.zeros(2, 8, 8, 32, device='cuda')
+    with pytest.raises(RuntimeError):
+        ops.conv2d_wgrad_wino(x, gz, torch.zeros(3, 3, 32, 32, device='cuda'), None, 2, 8, 8, 1.0)
