@@ -5,7 +5,9 @@
 //
 // so the 16 Winograd-domain products M[xi][co][ci] = sum over 2x2 output tiles of Z[xi][tile][co] * V[xi][tile][ci] are
 // sixteen GEMMs with K = tiles: 16 MFMAs per 4 tiles (16 pixels) instead of 36 for the direct formulation.  A workgroup
-// owns a 32(cout) x 32(cin) block of dW (2 x 2 waves, 16 x 16 each, all four waves walk the same tiles: no reduction),
+// owns a 16*NCO(cout) x 16*NCI(cin) block of dW: NCO x NCI waves of 16 x 16 each; with 32 x 32 blocks all four waves walk
+// the same tiles (no reduction), the 16-channel layers (NCO or NCI = 1) split the tiles of a region over the spare waves
+// instead and every wave commits its own partial sum.  The workgroup
 // stages a region of 32 tiles (16x8 pixels: gz rows + x halo rows) in LDS, every lane transforms ITS (tile, channel)
 // values in registers: Z from the 2x2 gz values (A operand: row = cout, k = tile), V from the 4x4 x patch (B operand:
 // col = cin, k = tile).  M stays in 16 accumulators; G^T M G is lane-local at the end and commits 9 taps with atomics.
@@ -30,16 +32,22 @@ struct WWP {
 constexpr int RTW = 8, RTH = 4;                // tiles per region: 8 wide x 4 high = 32 tiles = 16 x 8 pixels
 constexpr int PW = 2 * RTW, PH = 2 * RTH;      // 16 x 8 output pixels
 constexpr int HW_ = PW + 2, HH_ = PH + 2;      // 18 x 10 input halo pixels
-constexpr int SC = 40;                         // LDS pixel stride (floats) for 32 channels: the 4 tiles of a k-step (2 px apart) land 16 banks apart
+// LDS pixel stride (floats): the 4 tiles of a k-step (2 px apart) land 16 banks apart -- 40 for 32 channels, 24 for 16
+constexpr int stride_for(int nw) { return nw == 2 ? 40 : 24; }
 
+template <int NCO, int NCI>
 __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
 {
-    __shared__ __align__(16) float gzt[PH * PW * SC];      // [128 px][32 co]
-    __shared__ __align__(16) float xt[HH_ * HW_ * SC];     // [180 px][32 ci]
+    constexpr int SZ = stride_for(NCO), SX = stride_for(NCI);
+    constexpr int KSPL = 4 / (NCO * NCI);                  // waves sharing one 16 x 16 block: they split the k-steps
+    constexpr int VZ = 4 * NCO, VX = 4 * NCI;              // float4 per pixel
+    __shared__ __align__(16) float smem[PH * PW * SZ + HH_ * HW_ * SX];
+    float* gzt = smem;                                     // [128 px][16*NCO co]
+    float* xt = smem + PH * PW * SZ;                       // [180 px][16*NCI ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
-    const int wave_co = wave & 1, wave_ci = wave >> 1;
-    const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    const int wave_co = wave % NCO, wave_ci = (wave / NCO) % NCI, wk = wave / (NCO * NCI);
+    const int co0 = blockIdx.y * (16 * NCO), ci0 = blockIdx.z * (16 * NCI);
     const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
     const bool do_bias = p.db != nullptr && blockIdx.z == 0 && wave_ci == 0;
 
@@ -48,9 +56,9 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
-    // load descriptors: gz 128 px x 8 float4, x 180 px x 8 float4
-    constexpr int ZPT = (PH * PW * 8) / 256;               // 4
-    constexpr int XPT = (HH_ * HW_ * 8 + 255) / 256;       // 6
+    // load descriptors: gz 128 px x VZ float4, x 180 px x VX float4
+    constexpr int ZPT = (PH * PW * VZ) / 256;              // 4 (2)
+    constexpr int XPT = (HH_ * HW_ * VX + 255) / 256;      // 6 (3)
     float4 zreg[ZPT], xreg[XPT];
     auto fetch = [&](int region) {
         int r = region;
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) {
             const int idx = tid + 256 * i;
-            const int q = idx >> 3, v = idx & 7;
+            const int q = idx / VZ, v = idx % VZ;
             const int py = q / PW, px = q - py * PW;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (co0 + 4 * v < p.Cout)
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int idx = tid + 256 * i;
-            const int q = idx >> 3, v = idx & 7;
+            const int q = idx / VX, v = idx % VX;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < HH_ * HW_) {
                 const int py = q / HW_, px = q - py * HW_;
@@ -90,22 +98,22 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) {
             const int idx = tid + 256 * i;
-            *reinterpret_cast<float4*>(gzt + (idx >> 3) * SC + 4 * (idx & 7)) = zreg[i];
+            *reinterpret_cast<float4*>(gzt + (idx / VZ) * SZ + 4 * (idx % VZ)) = zreg[i];
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int idx = tid + 256 * i;
-            if ((idx >> 3) < HH_ * HW_) *reinterpret_cast<float4*>(xt + (idx >> 3) * SC + 4 * (idx & 7)) = xreg[i];
+            if (idx / VX < HH_ * HW_) *reinterpret_cast<float4*>(xt + (idx / VX) * SX + 4 * (idx % VX)) = xreg[i];
         }
         __syncthreads();
         if (region + 1 < r_end) fetch(region + 1);
         // 32 tiles = 8 k-steps of 4 tiles; lane (li, kk): tile 4*step + kk, A channel co = wave_co*16 + li, B channel ci = wave_ci*16 + li
 #pragma unroll 2
-        for (int step = 0; step < 8; ++step) {
+        for (int step = wk; step < 8; step += KSPL) {
             const int t = 4 * step + kk;
             const int ttx = t & (RTW - 1), tty = t >> 3;
-            const float* gp = gzt + ((2 * tty) * PW + 2 * ttx) * SC + wave_co * 16 + li;
-            const float y00 = gp[0], y01 = gp[SC], y10 = gp[PW * SC], y11 = gp[(PW + 1) * SC];
+            const float* gp = gzt + ((2 * tty) * PW + 2 * ttx) * SZ + wave_co * 16 + li;
+            const float y00 = gp[0], y01 = gp[SZ], y10 = gp[PW * SZ], y11 = gp[(PW + 1) * SZ];
             bsum += (y00 + y01) + (y10 + y11);
             // Z = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
             const float c0a = y00, c0b = y01;                 // rows of (A dY): r0 = y0., r1 = y0. + y1., r2 = y0. - y1., r3 = -y1.
@@ -118,12 +126,12 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
             z[8] = c2a; z[9] = c2a + c2b; z[10] = c2a - c2b; z[11] = -c2b;
             z[12] = c3a; z[13] = c3a + c3b; z[14] = c3a - c3b; z[15] = -c3b;
             // V = B^T d B from the 4x4 patch of x
-            const float* xp = xt + ((2 * tty) * HW_ + 2 * ttx) * SC + wave_ci * 16 + li;
+            const float* xp = xt + ((2 * tty) * HW_ + 2 * ttx) * SX + wave_ci * 16 + li;
             float d[4][4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) d[a][c] = xp[(a * HW_ + c) * SC];
+                for (int c = 0; c < 4; ++c) d[a][c] = xp[(a * HW_ + c) * SX];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
@@ -140,10 +148,9 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
         __syncthreads();
     }
     // dg = G^T M G, lane-local: acc[xi][r] is M[xi] for cout co0 + wave_co*16 + 4*kk + r, cin ci0 + wave_ci*16 + li
-    const int ci = ci0 + wave_ci * 16 + li;
+    float g[4][9];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int co = co0 + wave_co * 16 + 4 * kk + r;
         float m[4][4];
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = acc[xi][r];
@@ -153,16 +160,49 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
             const float s = 0.5f * (m[1][j] + m[2][j]), dlt = 0.5f * (m[1][j] - m[2][j]);
             t[0][j] = m[0][j] + s; t[1][j] = dlt; t[2][j] = s + m[3][j];
         }
-        if (co < p.Cout && ci < p.Cin) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float s = 0.5f * (t[a][1] + t[a][2]), dlt = 0.5f * (t[a][1] - t[a][2]);
-                const float g0 = t[a][0] + s, g1 = dlt, g2 = s + t[a][3];
-                float* dst = p.dw + ((size_t)(a * 3) * p.Cout + co) * p.Cin + ci;
-                atomicAdd(dst, g0 * p.scale);
-                atomicAdd(dst + (size_t)p.Cout * p.Cin, g1 * p.scale);
-                atomicAdd(dst + (size_t)2 * p.Cout * p.Cin, g2 * p.scale);
+        for (int a = 0; a < 3; ++a) {
+            const float s = 0.5f * (t[a][1] + t[a][2]), dlt = 0.5f * (t[a][1] - t[a][2]);
+            g[r][3 * a] = t[a][0] + s; g[r][3 * a + 1] = dlt; g[r][3 * a + 2] = s + t[a][3];
+        }
+    }
+    if (KSPL > 1) {                                           // waves that split the tiles of one block: fold them in LDS, wave wk = 0 commits
+        static_assert((KSPL - 1) * NCO * NCI * 36 * 64 <= PH * PW * SZ + HH_ * HW_ * SX, "reduction slots reuse the tile buffers");
+        const int blk = wave % (NCO * NCI);
+        if (wk > 0) {
+            float* dst = smem + ((wk - 1) * (NCO * NCI) + blk) * (36 * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int v = 0; v < 9; ++v) dst[(9 * r + v) * 64] = g[r][v];
+        }
+        __syncthreads();
+        if (wk > 0) {
+            if (do_bias) {                                    // the bias partial still goes out from every wave
+                bsum += __shfl_xor(bsum, 16, 64);
+                bsum += __shfl_xor(bsum, 32, 64);
+                const int co = co0 + wave_co * 16 + li;
+                if (kk == 0 && co < p.Cout) atomicAdd(p.db + co, bsum);
             }
+            return;
+        }
+#pragma unroll
+        for (int k = 1; k < KSPL; ++k) {
+            const float* src = smem + ((k - 1) * (NCO * NCI) + blk) * (36 * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int v = 0; v < 9; ++v) g[r][v] += src[(9 * r + v) * 64];
+        }
+    }
+    const int ci = ci0 + wave_ci * 16 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wave_co * 16 + 4 * kk + r;
+        if (co < p.Cout && ci < p.Cin) {
+            float* dst = p.dw + (size_t)co * p.Cin + ci;
+#pragma unroll
+            for (int v = 0; v < 9; ++v) atomicAdd(dst + (size_t)v * p.Cout * p.Cin, g[r][v] * p.scale);
         }
     }
     if (do_bias) {                                            // lane (li = co, kk): sum over its tiles; fold the 4 kk lanes
@@ -193,7 +233,8 @@ extern "C" int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float*
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups; p.scale = scale;
     p.blocksW = W / PW; p.blocksH = H / PH;
     p.nregions = N * p.blocksW * p.blocksH;
-    const int gy = (Cout + 31) / 32, gz_ = (Cin + 31) / 32;
+    const int nco = Cout <= 16 ? 1 : 2, nci = Cin <= 16 ? 1 : 2;
+    const int gy = (Cout + 16 * nco - 1) / (16 * nco), gz_ = (Cin + 16 * nci - 1) / (16 * nci);
     // ~512 workgroups: best of a 256/384/512/1024 sweep (tools/sweep_wino_wgrad.py); more workgroups pay for
     // themselves in the per-workgroup G^T M G commit (9216 atomics each), fewer leave CUs idle.
     static const int target = [] { const char* t = getenv("PG_WW_TARGET"); return t ? atoi(t) : 512; }();
@@ -202,7 +243,11 @@ extern "C" int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float*
     if (chunks < 1) chunks = 1;
     p.regions_per_block = (p.nregions + chunks - 1) / chunks;
     chunks = (p.nregions + p.regions_per_block - 1) / p.regions_per_block;
-    snprintf(g_ww_last, sizeof(g_ww_last), "conv_wino_wgrad_kernel");
-    hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3(chunks, gy, gz_), dim3(256), 0, (hipStream_t)stream, p);
+    snprintf(g_ww_last, sizeof(g_ww_last), "conv_wino_wgrad_kernel<%d, %d>", nco, nci);
+    const dim3 grid(chunks, gy, gz_);
+    if (nco == 2 && nci == 2) hipLaunchKernelGGL((conv_wino_wgrad_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (nco == 1 && nci == 2) hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (nco == 2 && nci == 1) hipLaunchKernelGGL((conv_wino_wgrad_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
