@@ -265,6 +265,60 @@ __global__ __launch_bounds__(256) void torgb_bwd_data_kernel(
     }
 }
 
+// Narrow layers on big maps (the 256^2 .. 1024^2 toRGB: 8 / 16 / 32 features): thread -> pixel with all CI x C partial sums in
+// registers, one shuffle + LDS fold per workgroup -- the per-(pixel, channel) thread mapping above spends its time on index math.
+template <int CI>
+__global__ __launch_bounds__(256) void torgb_wgrad_small_kernel(
+    const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
+    int N, int C, int H, int W, int down, float mul_scale, float mul)
+{
+    constexpr int NV = (CI + 1) * MAXC;
+    __shared__ float red[4][NV];
+    float acc[CI + 1][MAXC];                      // row CI: sum of g (bias)
+#pragma unroll
+    for (int i = 0; i <= CI; ++i)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) acc[i][c] = 0.f;
+    const unsigned total = (unsigned)N * H * W, HW = (unsigned)H * W;
+    for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < total; pix += gridDim.x * 256u) {
+        const unsigned n = pix / HW, hw = pix - n * HW;
+        const int h = (int)(hw / (unsigned)W), wv = (int)(hw - (unsigned)h * W);
+        float gv[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) gv[c] = c < C ? g_fetch(g, (int)n, c, h, wv, C, H, W, down) : 0.f;
+        const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)pix * CI);
+#pragma unroll
+        for (int i4 = 0; i4 < CI / 4; ++i4) {
+            const float4 v = x4[i4];
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) acc[4 * i4 + j][c] = fmaf(gv[c], xv[j], acc[4 * i4 + j][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) acc[CI][c] += gv[c];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i <= CI; ++i)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            float v = acc[i][c];
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
+            if (lane == 0) red[wave][i * MAXC + c] = v;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256) {
+        const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        const int ci = i / MAXC, c = i % MAXC;
+        if (c >= C) continue;
+        if (ci < CI) atomicAdd(dw + (size_t)c * CI + ci, v * mul_scale);
+        else if (db) atomicAdd(db + c, v * mul);
+    }
+}
+
 // dw[c][ci] += mul_scale * sum_pix g[pix,c]*x[pix,ci];  db[c] += mul * sum_pix g[pix,c]
 __global__ __launch_bounds__(256) void torgb_wgrad_kernel(
     const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
@@ -517,6 +571,14 @@ extern "C" int pg_torgb_wgrad(const float* g, const float* x, float* dw, float* 
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cin & 3) return PG_E_ALIGN;
     const size_t total = (size_t)N * H * W;
+    if (total >= 65536 && total < (1ull << 31) && (Cin == 8 || Cin == 16 || Cin == 32)) {
+        const int gr = grid_for(total, 256, 1024);
+        hipStream_t s = (hipStream_t)stream;
+        if (Cin == 8) hipLaunchKernelGGL(torgb_wgrad_small_kernel<8>, dim3(gr), dim3(256), 0, s, g, x, dw, db, N, C, H, W, down, mul_scale, mul);
+        else if (Cin == 16) hipLaunchKernelGGL(torgb_wgrad_small_kernel<16>, dim3(gr), dim3(256), 0, s, g, x, dw, db, N, C, H, W, down, mul_scale, mul);
+        else hipLaunchKernelGGL(torgb_wgrad_small_kernel<32>, dim3(gr), dim3(256), 0, s, g, x, dw, db, N, C, H, W, down, mul_scale, mul);
+        return (int)hipGetLastError();
+    }
     int blocks = grid_for(total, 4, total < 8192 ? 256 : (total < 32768 ? 512 : 1024));     // Cin*C atomics per workgroup
     const int ppb = (int)((total + blocks - 1) / blocks);
     blocks = (int)((total + ppb - 1) / ppb);

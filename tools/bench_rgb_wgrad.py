@@ -9,7 +9,7 @@ def run(f, reps=10):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
-for (N, H, C) in [(16, 4, 512), (48, 4, 512), (16, 8, 512), (48, 8, 512), (16, 16, 512), (48, 16, 512), (16, 32, 256), (48, 32, 256), (16, 64, 128), (9, 1024, 8)]:
+for (N, H, C) in [(16, 4, 512), (48, 4, 512), (16, 8, 512), (48, 8, 512), (16, 16, 512), (48, 16, 512), (16, 32, 256), (48, 32, 256), (16, 64, 128), (9, 1024, 8), (3, 1024, 8), (3, 512, 16), (3, 256, 32)]:
     gz = torch.randn(N, H, H, C, device='cuda'); img = torch.randn(N, 3, H, H, device='cuda')
     dw = torch.zeros(C, 3, device='cuda'); db = torch.zeros(C, device='cuda')
     x = torch.randn(N, H, H, C, device='cuda'); g = torch.randn(N, 3, H, H, device='cuda'); dw2 = torch.zeros(3, C, device='cuda'); db2 = torch.zeros(3, device='cuda')
