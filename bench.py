@@ -162,6 +162,12 @@ def make_trainer(pg, res, depth, alpha, mb, seed, dp, fmap_base=4096):
     return tr
 
 
+# A cold box needs ~1 s of work before the step time settles (first launches load code objects, the caching allocator
+# grows, the clocks ramp): measured 17.2 ms on the first 30 steps of a fresh box vs 16.0 ms afterwards.  These setup
+# steps run before the W warmup steps of the contract and are reported as "priming_steps" in the JSON line.
+PRIME_STEPS = 50
+
+
 def timed_steps(tr, steps, warmup, dp):
     for _ in range(warmup):
         tr.train()
@@ -263,13 +269,15 @@ def main():
     tr = make_trainer(pg, 1024, depth, args.alpha, mb, pg.parallel.shard_seed(1337, rank), dp)
     if dp is not None:
         dp.broadcast_params(tr.G, tr.D)
+    for _ in range(PRIME_STEPS):          # setup, untimed and reported: code-object loading, allocator growth, clock ramp
+        tr.train()
     dt = timed_steps(tr, args.steps, args.warmup, dp)
     ms_per_step = 1e3 * dt / args.steps
     value = n_gpus * mb * args.steps / dt
 
     out = {
         'metric': 'images/sec, PGGAN full train step (D+GP step + G step + Adam) at %dx%d' % (res, res),
-        'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+        'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'priming_steps': PRIME_STEPS,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'PGGAN (default widths fmap_base=4096, C=3, latent 512) growth stage depth %d = %dx%d, '
@@ -346,10 +354,15 @@ def main():
             out['cpu_baseline'] = cpu_baseline(depth, mb)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
     if dp is not None:
         dp.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints its banner through C stdio, which is still buffered here
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -60,6 +60,50 @@ __global__ __launch_bounds__(256) void fromrgb_fwd_kernel(
     }
 }
 
+// thread -> pixel variant for the 8-channel stage (and 16 channels without a mask): all CO outputs of a pixel from one thread,
+// the image read once per pixel.  Measured (tools/bench_rgb_stream.py, n9 @1024^2, 8 channels): 105 us vs 239 us for the
+// (pixel, 4 couts) mapping, which is the better one from 16 masked channels on.
+template <int CO>
+__global__ __launch_bounds__(256) void fromrgb_fwd_pix_kernel(
+    const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ mask, float* __restrict__ y,
+    int N, int C, int H, int W, int pool, float scale, float slope, float mask_slope)
+{
+    const unsigned total = (unsigned)N * H * W, HW = (unsigned)H * W;
+    for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < total; pix += gridDim.x * 256u) {
+        const unsigned n = pix / HW, hw = pix - n * HW;
+        const int h = (int)(hw / (unsigned)W), wv = (int)(hw - (unsigned)h * W);
+        float xin[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) xin[c] = c < C ? img_fetch(img, (int)n, c, h, wv, C, H, W, pool) : 0.f;
+        const size_t off = (size_t)pix * CO;
+#pragma unroll
+        for (int c4 = 0; c4 < CO / 4; ++c4) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* wr = w + (4 * c4 + j) * C;
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) if (c < C) a = fmaf(xin[c], wr[c], a);
+                o[j] = a * scale;
+            }
+            if (mask) {
+                const float4 mk = *reinterpret_cast<const float4*>(mask + off + 4 * c4);
+                o[0] *= mk.x > 0.f ? 1.f : mask_slope; o[1] *= mk.y > 0.f ? 1.f : mask_slope;
+                o[2] *= mk.z > 0.f ? 1.f : mask_slope; o[3] *= mk.w > 0.f ? 1.f : mask_slope;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = o[j] + (bias ? bias[4 * c4 + j] : 0.f);
+                    o[j] = v > 0.f ? v : v * slope;
+                }
+            }
+            *reinterpret_cast<float4*>(y + off + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // thread -> pixel; loops over Cout in float4 steps.
 __global__ __launch_bounds__(256) void fromrgb_bwd_data_kernel(
     const float* __restrict__ gz, const float* __restrict__ w, float* __restrict__ gimg,
@@ -262,6 +306,59 @@ __global__ __launch_bounds__(256) void torgb_bwd_data_kernel(
         }
         *reinterpret_cast<float4*>(gx + pix * Cin + 4 * c4) =
             make_float4(o[0] * mul_scale, o[1] * mul_scale, o[2] * mul_scale, o[3] * mul_scale);
+    }
+}
+
+// Narrow layers on big maps (toRGB adjoint at 256^2 .. 1024^2): same mapping as above, 32-bit index math, compile-time CI.
+template <int CI>
+__global__ __launch_bounds__(256) void torgb_bwd_data_narrow_kernel(
+    const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ gx,
+    int N, int C, int H, int W, int down, float mul_scale)
+{
+    constexpr unsigned C4N = CI / 4;
+    const unsigned total = (unsigned)N * H * W * C4N, HW = (unsigned)H * W;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned c4 = idx % C4N, pix = idx / C4N;
+        const unsigned n = pix / HW, hw = pix - n * HW;
+        const int h = (int)(hw / (unsigned)W), wv = (int)(hw - (unsigned)h * W);
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c < C) {
+            const float gv = g_fetch(g, (int)n, c, h, wv, C, H, W, down);
+            const float4 wv4 = *reinterpret_cast<const float4*>(w + c * CI + 4 * c4);
+            o[0] = fmaf(gv, wv4.x, o[0]); o[1] = fmaf(gv, wv4.y, o[1]);
+            o[2] = fmaf(gv, wv4.z, o[2]); o[3] = fmaf(gv, wv4.w, o[3]);
+        }
+        *reinterpret_cast<float4*>(gx + (size_t)idx * 4) =
+            make_float4(o[0] * mul_scale, o[1] * mul_scale, o[2] * mul_scale, o[3] * mul_scale);
+    }
+}
+
+// thread -> pixel variant for 8 features (see fromrgb_fwd_pix_kernel).
+template <int CI>
+__global__ __launch_bounds__(256) void torgb_bwd_data_pix_kernel(
+    const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ gx,
+    int N, int C, int H, int W, int down, float mul_scale)
+{
+    const unsigned total = (unsigned)N * H * W, HW = (unsigned)H * W;
+    for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < total; pix += gridDim.x * 256u) {
+        const unsigned n = pix / HW, hw = pix - n * HW;
+        const int h = (int)(hw / (unsigned)W), wv = (int)(hw - (unsigned)h * W);
+        float gv[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) gv[c] = c < C ? g_fetch(g, (int)n, c, h, wv, C, H, W, down) : 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < CI / 4; ++c4) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) if (c < C) {
+                const float4 wv4 = *reinterpret_cast<const float4*>(w + c * CI + 4 * c4);
+                o[0] = fmaf(gv[c], wv4.x, o[0]); o[1] = fmaf(gv[c], wv4.y, o[1]);
+                o[2] = fmaf(gv[c], wv4.z, o[2]); o[3] = fmaf(gv[c], wv4.w, o[3]);
+            }
+            *reinterpret_cast<float4*>(gx + (size_t)pix * CI + 4 * c4) =
+                make_float4(o[0] * mul_scale, o[1] * mul_scale, o[2] * mul_scale, o[3] * mul_scale);
+        }
     }
 }
 
@@ -484,7 +581,15 @@ extern "C" int pg_fromrgb_fwd(const float* img, const float* w, const float* bia
     if (!img || !w || !y || N <= 0 || H <= 0 || W <= 0) return PG_E_ARG;
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cout & 3) return PG_E_ALIGN;
-    const size_t total = (size_t)N * H * W * (Cout >> 2);
+    const size_t npix = (size_t)N * H * W;
+    if (npix >= 65536 && npix < (1ull << 31) && (Cout == 8 || (Cout == 16 && !mask))) {       // measured: tools/bench_rgb_stream.py
+        const int gr = grid_for(npix, 256, 256 * 16);
+        hipStream_t s = (hipStream_t)stream;
+        if (Cout == 8) hipLaunchKernelGGL(fromrgb_fwd_pix_kernel<8>, dim3(gr), dim3(256), 0, s, img, w, bias, mask, y, N, C, H, W, pool, scale, slope, mask_slope);
+        else hipLaunchKernelGGL(fromrgb_fwd_pix_kernel<16>, dim3(gr), dim3(256), 0, s, img, w, bias, mask, y, N, C, H, W, pool, scale, slope, mask_slope);
+        return (int)hipGetLastError();
+    }
+    const size_t total = npix * (Cout >> 2);
     hipLaunchKernelGGL(fromrgb_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        img, w, bias, mask, y, N, C, H, W, Cout, pool, scale, slope, mask_slope);
     return (int)hipGetLastError();
@@ -557,7 +662,15 @@ extern "C" int pg_torgb_bwd_data(const float* g, const float* w, float* gx,
     if (!g || !w || !gx || N <= 0) return PG_E_ARG;
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cin & 3) return PG_E_ALIGN;
-    const size_t total = (size_t)N * H * W * (Cin >> 2);
+    const size_t npix = (size_t)N * H * W;
+    if (npix >= 65536 && npix < (1ull << 29) && (Cin == 8 || Cin == 16 || Cin == 32)) {      // measured: tools/bench_rgb_stream.py
+        hipStream_t s = (hipStream_t)stream;
+        if (Cin == 8) hipLaunchKernelGGL(torgb_bwd_data_pix_kernel<8>, dim3(grid_for(npix, 256, 256 * 16)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale);
+        else if (Cin == 16) hipLaunchKernelGGL(torgb_bwd_data_narrow_kernel<16>, dim3(grid_for(npix * 4, 256, 256 * 32)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale);
+        else hipLaunchKernelGGL(torgb_bwd_data_narrow_kernel<32>, dim3(grid_for(npix * 8, 256, 256 * 32)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale);
+        return (int)hipGetLastError();
+    }
+    const size_t total = npix * (Cin >> 2);
     hipLaunchKernelGGL(torgb_bwd_data_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        g, w, gx, N, C, H, W, Cin, down, mul_scale);
     return (int)hipGetLastError();

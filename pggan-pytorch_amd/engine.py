@@ -39,7 +39,7 @@ def _check_dev(t, what):
 # layers (>= 32 channels on both sides) with enough 64-tile workgroups to fill the chip (tools/sweep_wino.py).
 import os as _os
 USE_WINOGRAD = _os.environ.get('PGGAN_WINOGRAD', '1') != '0'
-WINO_MIN_WORKGROUPS = int(_os.environ.get('PGGAN_WINO_MIN_WG', '384'))
+WINO_MIN_WORKGROUPS = int(_os.environ.get('PGGAN_WINO_MIN_WG', '256'))
 WINO_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_MIN_C', '32'))
 USE_WINOGRAD_WGRAD = USE_WINOGRAD and _os.environ.get('PGGAN_WINOGRAD_WGRAD', '1') != '0'
 WINO_WGRAD_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_WGRAD_MIN_C', '16'))
