@@ -238,6 +238,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--prime', type=int, default=PRIME_STEPS, help='untimed setup steps before the warmup (see PRIME_STEPS)')
     ap.add_argument('--depth', type=int, default=8)
     ap.add_argument('--alpha', type=float, default=1.0)
     ap.add_argument('--minibatch', type=int, default=0, help='per-GPU minibatch (default: reference schedule)')
@@ -269,7 +270,7 @@ def main():
     tr = make_trainer(pg, 1024, depth, args.alpha, mb, pg.parallel.shard_seed(1337, rank), dp)
     if dp is not None:
         dp.broadcast_params(tr.G, tr.D)
-    for _ in range(PRIME_STEPS):          # setup, untimed and reported: code-object loading, allocator growth, clock ramp
+    for _ in range(args.prime):           # setup, untimed and reported: code-object loading, allocator growth, clock ramp
         tr.train()
     dt = timed_steps(tr, args.steps, args.warmup, dp)
     ms_per_step = 1e3 * dt / args.steps
@@ -277,7 +278,7 @@ def main():
 
     out = {
         'metric': 'images/sec, PGGAN full train step (D+GP step + G step + Adam) at %dx%d' % (res, res),
-        'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'priming_steps': PRIME_STEPS,
+        'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'priming_steps': args.prime,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'PGGAN (default widths fmap_base=4096, C=3, latent 512) growth stage depth %d = %dx%d, '

@@ -6,9 +6,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu --no-per-depth --steps 10 --warmup 3"
+BENCH="python $R/bench.py --no-cpu --no-per-depth --prime 10 --steps 10 --warmup 3"
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $BENCH > $OUT/bench_kt.log 2>&1
-PMCB="python $R/bench.py --no-cpu --no-per-depth --no-kernel-timing --steps 2 --warmup 1"
+PMCB="python $R/bench.py --no-cpu --no-per-depth --no-kernel-timing --prime 0 --steps 2 --warmup 1"
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $PMCB > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $PMCB > $OUT/pmc_write.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq -o p --output-format csv -- $PMCB > $OUT/pmc_sq.log 2>&1

@@ -7,7 +7,7 @@ import pggan_amd as pg
 ops, lib = pg.ops, pg._lib.load()
 SHAPES = [(9, 16, 512, 512), (3, 16, 512, 512), (9, 32, 256, 512), (3, 32, 256, 256), (9, 64, 128, 256), (3, 64, 128, 128), (9, 128, 64, 128), (3, 128, 64, 64),
           (9, 256, 32, 64), (3, 256, 32, 32), (9, 512, 16, 32), (3, 512, 16, 32), (9, 512, 32, 16), (3, 512, 32, 16), (9, 512, 16, 16), (3, 512, 16, 16),
-          (9, 1024, 8, 16), (3, 1024, 8, 8), (9, 8, 512, 512), (16, 16, 512, 512), (48, 16, 512, 512)]
+          (9, 1024, 8, 16), (3, 1024, 8, 16), (9, 1024, 8, 8), (3, 1024, 8, 8), (3, 1024, 16, 8), (6, 512, 8, 8), (9, 8, 512, 512), (16, 16, 512, 512), (48, 16, 512, 512)]
 def run(f, reps=10):
     for _ in range(2): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
