@@ -1,0 +1,20 @@
+// Raw buffer loads for the global->LDS fetch stages (gfx950).  An offset at or beyond num_records returns zeros in hardware,
+// so "outside the image / beyond the channel block" is encoded as the offset OOB instead of an exec-mask branch around
+// every load: the fetch stage becomes straight-line code the scheduler can place under the MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef unsigned int pg_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned PG_OOB = 0x80000000u;                   // never a valid byte offset: every span is checked < 2 GiB on the host
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_make_rsrc(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw, 32-bit data format
+}
+
+// one float4 at base + voff + soff (bytes); voff per lane, soff wave-uniform
+__device__ __forceinline__ float4 pg_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const pg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}

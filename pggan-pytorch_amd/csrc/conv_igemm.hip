@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "pggan_hip.h"
+#include "bufload.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -118,14 +119,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     // ---- per-thread load descriptors (element offsets without the channel-chunk offset; -1 = zero fill)
     const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
     const int npix = p.TN * HT * WT;
-    int wsrc[WPT], wdst[WPT], xsrc[XPT], xdst[XPT];
+    // global loads go through raw buffers (bufload.h): byte offsets, PG_OOB = zero fill, x relative to image n0
+    const size_t img = (size_t)xH * xW * p.Cin;
+    const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n0 * img, (unsigned)(min(p.TN, p.N - n0) * img * 4));
+    const __amdgpu_buffer_rsrc_t rw = pg_make_rsrc(p.w, (unsigned)((size_t)TAPS * p.Cout * p.Cin * 4));
+    unsigned wsrc[WPT], xsrc[XPT];
+    int wdst[WPT], xdst[XPT];
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const int idx = tid + 256 * i;
         const int r = idx / VEC, v = idx - r * VEC;
         const int tap = r / BCO, col = r - tap * BCO, co = co0 + col;
         wdst[i] = idx < WEL ? r * KCP + 4 * v : -1;
-        wsrc[i] = (idx < WEL && co < p.Cout) ? ((tap * p.Cout + co) * p.Cin + 4 * v) : -1;
+        wsrc[i] = (idx < WEL && co < p.Cout) ? 4u * (unsigned)((tap * p.Cout + co) * p.Cin + 4 * v) : PG_OOB;
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
         const bool ok = in_tile && n < p.N && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
         if (p.ups) { ih >>= 1; iw >>= 1; }
         xdst[i] = in_tile ? q * KCP + 4 * v : -1;
-        xsrc[i] = ok ? (((n * xH + ih) * xW + iw) * p.Cin + 4 * v) : -1;
+        xsrc[i] = ok ? 4u * (unsigned)(((tn * xH + ih) * xW + iw) * p.Cin + 4 * v) : PG_OOB;
     }
     int tapoff[TAPS];
 #pragma unroll
@@ -160,13 +166,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     auto fetch = [&](int kc) {
         const int k0 = kc * KC;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i)
-            wreg[i] = wsrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.w + (size_t)(unsigned)(wsrc[i] + k0))
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < WPT; ++i) wreg[i] = pg_buf_load4(rw, wsrc[i], 4u * (unsigned)k0);
 #pragma unroll
-        for (int i = 0; i < XPT; ++i)
-            xreg[i] = xsrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)(xsrc[i] + k0))
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < XPT; ++i) xreg[i] = pg_buf_load4(rx, xsrc[i], 4u * (unsigned)k0);
     };
 
     if (kc_begin < kc_end) fetch(kc_begin);
@@ -1139,6 +1141,7 @@ int launch_conv(ConvP& p, hipStream_t s)
     const int HT = (1 << g.lgTH) + KS - 1, WT = (1 << g.lgTW) + KS - 1;
     constexpr int XMAX = halo_max(KS, BPX);
     if (g.TN * HT * WT > XMAX) return PG_E_UNSUP;       // halo larger than the register-prefetch budget
+    if ((long long)g.TN * (p.ups ? p.Hin >> 1 : p.Hin) * (p.ups ? p.Win >> 1 : p.Win) * p.Cin * 4 >= (1ll << 31)) return PG_E_UNSUP;   // 32-bit buffer offsets
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     const size_t smem = (size_t)(KS * KS * BCO + g.TN * HT * WT) * KCP * sizeof(float);
     auto kern = conv_igemm_kernel<KS, VEC, WAVES_CO, WM, WN>;

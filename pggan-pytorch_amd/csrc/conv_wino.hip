@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "pggan_hip.h"
+#include "bufload.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -93,7 +94,13 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     const int ttx = t & (TTW - 1), tty = (t >> p.lgTW) & (TTH - 1), ttn = t >> (p.lgTW + p.lgTH);
     const int pbase = ((ttn * HT + 2 * tty) * WT + 2 * ttx) * KCP + VEC * kk;
 
-    int xsrc[XPT], xdst[XPT], usrc[UPT], udst[UPT];
+    // buffer resources: U whole, x from the first image of this workgroup (the host checks both spans stay below 2 GiB)
+    const size_t img = (size_t)xH * xW * p.Cin;
+    const int nimg = min(p.TN, p.N - n0);
+    const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n0 * img, (unsigned)(nimg * img * 4));
+    const __amdgpu_buffer_rsrc_t ru = pg_make_rsrc(p.u, (unsigned)((size_t)16 * p.Cout * p.Cin * 4));
+    unsigned xsrc[XPT], usrc[UPT];
+    int xdst[XPT], udst[UPT];
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
         const int idx = tid + 256 * i;
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         const bool ok = in_tile && n < p.N && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         if (p.ups) { ih >>= 1; iw >>= 1; }
         xdst[i] = in_tile ? q * KCP + 4 * v : -1;
-        xsrc[i] = ok ? (((n * xH + ih) * xW + iw) * p.Cin + 4 * v) : -1;
+        xsrc[i] = ok ? 4u * (unsigned)(((tn * xH + ih) * xW + iw) * p.Cin + 4 * v) : PG_OOB;
     }
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         const int r = idx / VEC, v = idx - r * VEC;          // r = xi*16 + co
         const int xi = r >> 4, co = co0 + (r & 15);
         udst[i] = r * KCP + 4 * v;
-        usrc[i] = co < p.Cout ? ((xi * p.Cout + co) * p.Cin + 4 * v) : -1;
+        usrc[i] = co < p.Cout ? 4u * (unsigned)((xi * p.Cout + co) * p.Cin + 4 * v) : PG_OOB;
     }
 
     f32x4 acc[16];
@@ -124,11 +131,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     float4 xreg[XPT], ureg[UPT];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < UPT; ++i)
-            ureg[i] = usrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.u + (size_t)(unsigned)(usrc[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < UPT; ++i) ureg[i] = pg_buf_load4(ru, usrc[i], 4u * (unsigned)k0);
 #pragma unroll
-        for (int i = 0; i < XPT; ++i)
-            xreg[i] = xsrc[i] >= 0 ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)(xsrc[i] + k0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < XPT; ++i) xreg[i] = pg_buf_load4(rx, xsrc[i], 4u * (unsigned)k0);
     };
     fetch(0);
     for (int k0 = 0; k0 < p.Cin; k0 += KC) {
@@ -139,7 +144,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         __syncthreads();
         if (k0 + KC < p.Cin) fetch(k0 + KC);
 
-        // the patch as pairs of floats: the transform then compiles to packed adds (v_pk_add_f32, 2 lanes-of-channel / instr)
+        // the patch as pairs of floats (the compiler still emits scalar v_add_f32: forcing v_pk_add_f32 through inline asm
+        // needs an s_nop per instruction for the VALU->MFMA hazard the assembler cannot see, and measured slower)
         v2f d[4][4][VEC / 2];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -346,6 +352,10 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
     p.blocksW = tilesW / TTW; p.blocksH = tilesH / TTH;
     const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
     if (TN * HT * WT > XMAX) return PG_E_UNSUP;
+    {   // spans addressed through 32-bit buffer offsets (offset 0x80000000 is the out-of-range marker)
+        const long long xspan = (long long)TN * (ups ? (H >> 1) : H) * (ups ? (W >> 1) : W) * Cin * 4, uspan = (long long)16 * Cout * Cin * 4;
+        if (xspan >= (1ll << 31) || uspan >= (1ll << 31)) return PG_E_UNSUP;
+    }
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     const int vec = g_wino_vec;
     const size_t smem = (size_t)(16 * 16 + TN * HT * WT) * (vec == 4 ? 24 : 12) * sizeof(float);
