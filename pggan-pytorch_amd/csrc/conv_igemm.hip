@@ -877,16 +877,24 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
     const int oh0 = th_i * TH, ow0 = tw_i << 5;
     const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
 
-    for (int e = tid; e < HT * WT * C4; e += 256) {
+    // one image through a raw buffer (bufload.h): out-of-image halo pixels are zero-filled by the hardware, no branch per load
+    const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n * xH * xW * CIN, (unsigned)((size_t)xH * xW * CIN * 4));
+    constexpr int NLD = (HT * WT * C4 + 255) / 256;
+    float4 xv[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
         const int c4 = e % C4; const int q = e / C4;
         const int tw = q % WT, th = q / WT;
         int ih = oh0 + th - 1, iw = ow0 + tw - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
-            if (p.ups) { ih >>= 1; iw >>= 1; }
-            v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * xH + ih) * xW + iw) * CIN + 4 * c4);
-        }
-        *reinterpret_cast<float4*>(xt + q * S + 4 * c4) = v;
+        const bool ok = e < HT * WT * C4 && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        if (p.ups) { ih >>= 1; iw >>= 1; }
+        xv[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)((ih * xW + iw) * CIN + 4 * c4) : PG_OOB, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
+        if (e < HT * WT * C4) *reinterpret_cast<float4*>(xt + (e / C4) * S + 4 * (e % C4)) = xv[i];
     }
     for (int e = tid; e < 9 * COUT * C4; e += 256)
         *reinterpret_cast<float4*>(wl + 4 * e) = *reinterpret_cast<const float4*>(p.w + 4 * e);
@@ -991,6 +999,7 @@ template <int COUT, int CIN, int TH>
 int launch_thin(ConvP& p, hipStream_t s)
 {
     const size_t smem = ((size_t)(TH + 2) * 34 * (CIN + 4) + 9 * COUT * CIN) * sizeof(float);
+    if ((long long)p.Hin * p.Win * CIN * 4 >= (1ll << 31)) return PG_E_UNSUP;                  // 32-bit buffer offsets per image
     auto kern = conv_thin_kernel<COUT, CIN, TH>;
     if (int rc = set_smem(kern, smem)) return rc;
     dim3 grid((unsigned)(p.N * (p.Hout / TH) * (p.Wout >> 5)));
@@ -1227,7 +1236,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_kernel(ConvP p)
         const int r = idx >> 4, v = idx & 15;                   // row (tap, cout), float4 index inside the 64 channels
         const int tap = r / BCO, col = r - tap * BCO, co = co0 + col;
         wdst[i] = idx < WEL ? r * RS + (v >> 2) * KCP + 4 * (v & 3) : -1;
-        wsrc[i] = (idx < WEL && co < p.Cout) ? (tap * p.Cout + co) * p.Cin : -1;
+        wsrc[i] = (idx < WEL && co < p.Cout) ? (tap * p.Cout + co) * p.Cin : -1;        // element offsets; -1 = zero fill
         wch[i] = 4 * v;
     }
 #pragma unroll
@@ -1253,17 +1262,18 @@ __global__ __launch_bounds__(256) void conv_ksplit_kernel(ConvP p)
     for (int n = 0; n < WN; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nsuper = (p.Cin + 63) >> 6;
+    const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x, (unsigned)((size_t)p.N * p.Hin * p.Win * p.Cin * 4));    // small-M layers: a few MB
+    const __amdgpu_buffer_rsrc_t rw = pg_make_rsrc(p.w, (unsigned)((size_t)TAPS * p.Cout * p.Cin * 4));
     float4 wreg[WPT], xreg[XPT];
     auto fetch = [&](int sc) {
         const int k0 = sc << 6;
+        // raw buffer loads (bufload.h): a select on the offset instead of a branch around every load
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            wreg[i] = (wsrc[i] >= 0 && k0 + wch[i] < p.Cin) ? *reinterpret_cast<const float4*>(p.w + (size_t)(unsigned)(wsrc[i] + k0 + wch[i]))
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            wreg[i] = pg_buf_load4(rw, (wsrc[i] >= 0 && k0 + wch[i] < p.Cin) ? 4u * (unsigned)(wsrc[i] + k0 + wch[i]) : PG_OOB, 0);
 #pragma unroll
         for (int i = 0; i < XPT; ++i)
-            xreg[i] = (xsrc[i] >= 0 && k0 + xch[i] < p.Cin) ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)(xsrc[i] + k0 + xch[i]))
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            xreg[i] = pg_buf_load4(rx, (xsrc[i] >= 0 && k0 + xch[i] < p.Cin) ? 4u * (unsigned)(xsrc[i] + k0 + xch[i]) : PG_OOB, 0);
     };
     fetch(0);
     for (int sc = 0; sc < nsuper; ++sc) {
@@ -1343,6 +1353,7 @@ int launch_ksplit(ConvP& p, hipStream_t s)
     const int HT = (1 << g.lgTH) + 2, WT = (1 << g.lgTW) + 2;
     constexpr int XMAX = BPX <= 16 ? 36 : (BPX * 9) / 4;
     if (g.TN * HT * WT > XMAX) return PG_E_UNSUP;
+    if ((long long)p.N * p.Hin * p.Win * p.Cin * 4 >= (1ll << 31) || (long long)9 * p.Cout * p.Cin * 4 >= (1ll << 31)) return PG_E_UNSUP;   // 32-bit buffer offsets
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     size_t smem = (size_t)(9 * 16 + g.TN * HT * WT) * 96 * sizeof(float);
     const size_t red = (size_t)3 * WN * 256 * sizeof(float);
