@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "pggan_hip.h"
+#include "bufload.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -59,36 +60,44 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     // load descriptors: gz 128 px x VZ float4, x 180 px x VX float4
     constexpr int ZPT = (PH * PW * VZ) / 256;              // 4 (2)
     constexpr int XPT = (HH_ * HW_ * VX + 255) / 256;      // 6 (3)
+    // per-thread load descriptors (region-invariant part), raw buffer loads per image (bufload.h): PG_OOB = zero fill
+    unsigned zoff[ZPT];
+    int xpy[XPT], xpx[XPT], xcv[XPT];
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / VZ, v = idx % VZ;
+        const int py = q / PW, px = q - py * PW;
+        zoff[i] = co0 + 4 * v < p.Cout ? 4u * (unsigned)((py * p.W + px) * p.Cout + 4 * v) : PG_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / VX, v = idx % VX;
+        const int py = q / HW_, px = q - py * HW_;
+        const bool live = q < HH_ * HW_ && ci0 + 4 * v < p.Cin;
+        xpy[i] = live ? py - 1 : -(1 << 20);                // a row far outside every image: the bounds test below fails
+        xpx[i] = px - 1;
+        xcv[i] = 4 * v;
+    }
+    const unsigned zimg = (unsigned)((size_t)p.H * p.W * p.Cout * 4), ximg = (unsigned)((size_t)xH * xW * p.Cin * 4);
     float4 zreg[ZPT], xreg[XPT];
     auto fetch = [&](int region) {
         int r = region;
         const int bw = r % p.blocksW; r /= p.blocksW;
         const int bh = r % p.blocksH; const int n = r / p.blocksH;
         const int oy0 = bh * PH, ox0 = bw * PW;
+        const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(p.gz + (size_t)n * p.H * p.W * p.Cout + co0, zimg - 4u * (unsigned)co0);
+        const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n * xH * xW * p.Cin + ci0, ximg - 4u * (unsigned)ci0);
+        const unsigned zbase = 4u * (unsigned)((oy0 * p.W + ox0) * p.Cout);
 #pragma unroll
-        for (int i = 0; i < ZPT; ++i) {
-            const int idx = tid + 256 * i;
-            const int q = idx / VZ, v = idx % VZ;
-            const int py = q / PW, px = q - py * PW;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co0 + 4 * v < p.Cout)
-                val = *reinterpret_cast<const float4*>(p.gz + (((size_t)n * p.H + oy0 + py) * p.W + ox0 + px) * p.Cout + co0 + 4 * v);
-            zreg[i] = val;
-        }
+        for (int i = 0; i < ZPT; ++i) zreg[i] = pg_buf_load4(rz, zoff[i], zbase);
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            const int idx = tid + 256 * i;
-            const int q = idx / VX, v = idx % VX;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < HH_ * HW_) {
-                const int py = q / HW_, px = q - py * HW_;
-                int ih = oy0 + py - 1, iw = ox0 + px - 1;
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && ci0 + 4 * v < p.Cin) {
-                    if (p.ups) { ih >>= 1; iw >>= 1; }
-                    val = *reinterpret_cast<const float4*>(p.x + (((size_t)n * xH + ih) * xW + iw) * p.Cin + ci0 + 4 * v);
-                }
-            }
-            xreg[i] = val;
+            int ih = oy0 + xpy[i], iw = ox0 + xpx[i];
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            if (p.ups) { ih >>= 1; iw >>= 1; }
+            xreg[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)((ih * xW + iw) * p.Cin + xcv[i]) : PG_OOB, 0);
         }
     };
     const int r_begin = blockIdx.x * p.regions_per_block;
@@ -228,6 +237,7 @@ extern "C" int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float*
     if (!pow2(H) || !pow2(W) || H < PH || W < PW) return PG_E_UNSUP;
     if (ups && ((H | W) & 1)) return PG_E_ARG;
     if ((long long)N * H * W * Cin >= (1ll << 31) || (long long)N * H * W * Cout >= (1ll << 31)) return PG_E_UNSUP;
+    if ((long long)H * W * Cin * 4 >= (1ll << 31) || (long long)H * W * Cout * 4 >= (1ll << 31)) return PG_E_UNSUP;      // 32-bit buffer offsets per image
     WWP p;
     p.x = x; p.gz = gz; p.dw = dw; p.db = db;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups; p.scale = scale;
