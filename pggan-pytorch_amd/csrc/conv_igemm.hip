@@ -1567,31 +1567,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
         const int th_i = t % p.tilesH; t /= p.tilesH;
         const int n0 = t * p.TN;
         const int oh0 = th_i << p.lgTH, ow0 = tw_i << p.lgTW;
+        // raw buffers over the TN images of this tile (bufload.h): PG_OOB = zero fill, no branch per load
+        const int nimg = min(p.TN, p.N - n0);
+        const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(p.gz + (size_t)n0 * p.Hout * p.Wout * CO, (unsigned)((size_t)nimg * p.Hout * p.Wout * CO * 4));
+        const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n0 * xH * xW * CI, (unsigned)((size_t)nimg * xH * xW * CI * 4));
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) {
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (zq[i] >= 0) {
-                const int q = zq[i];
-                const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
-                const int n = n0 + tn;
-                if (n < p.N)
-                    val = *reinterpret_cast<const float4*>(p.gz + (((size_t)n * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * CO + zc[i]);
-            }
-            zreg[i] = val;
+            const int q = zq[i];
+            const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
+            const bool ok = q >= 0 && tn < nimg;
+            zreg[i] = pg_buf_load4(rz, ok ? 4u * (unsigned)(((tn * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * CO + zc[i]) : PG_OOB, 0);
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xq[i] >= 0) {
-                const int tw = xq[i] & 1023, th = (xq[i] >> 10) & 1023, tn = xq[i] >> 20;
-                const int n = n0 + tn;
-                int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
-                if (n < p.N && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
-                    if (p.ups) { ih >>= 1; iw >>= 1; }                       // nearest-x2 upsample fused into the gather
-                    val = *reinterpret_cast<const float4*>(p.x + (((size_t)n * xH + ih) * xW + iw) * CI + xc[i]);
-                }
-            }
-            xreg[i] = val;
+            const int tw = xq[i] & 1023, th = (xq[i] >> 10) & 1023, tn = xq[i] >> 20;
+            int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
+            const bool ok = xq[i] >= 0 && tn < nimg && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+            if (p.ups) { ih >>= 1; iw >>= 1; }                           // nearest-x2 upsample fused into the gather
+            xreg[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)(((tn * xH + ih) * xW + iw) * CI + xc[i]) : PG_OOB, 0);
         }
     };
 
@@ -1697,6 +1690,7 @@ int launch_wgrad_thin(WgP& p, hipStream_t s)
     p.lgTW = g.lgTW; p.lgTH = g.lgTH; p.TN = g.TN; p.tilesW = g.tilesW; p.tilesH = g.tilesH; p.ntiles = g.ntiles;
     const int HT = (1 << g.lgTH) + 2, WT = (1 << g.lgTW) + 2;
     if (g.TN * HT * WT > (BPX * 9) / 4) return PG_E_UNSUP;
+    if ((long long)g.TN * p.Hout * p.Wout * (p.Cout > p.Cin ? p.Cout : p.Cin) * 4 >= (1ll << 31)) return PG_E_UNSUP;     // 32-bit buffer offsets
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     const int sz = p.Cout == 16 ? 16 : p.Cout + 16, sx = p.Cin == 16 ? 16 : p.Cin + 16;      // PixStride<C>
     size_t smem = ((size_t)BPX * sz + (size_t)g.TN * HT * WT * sx) * sizeof(float);
