@@ -70,12 +70,13 @@ template <int VEC>
 __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
 {
     constexpr int KC = 4 * VEC, KCP = WRow<VEC>::value;
+    constexpr int KXP = VEC == 4 ? 20 : KCP;                // pixel stride of the input region (see the lane -> tile map below)
     constexpr int XPT = (XMAX * VEC + 255) / 256;           // float4 per thread for the halo region (KC channels)
     constexpr int UPT = VEC;                                 // 16 xi x 16 couts x VEC float4 / 256 threads
     typedef float fragv __attribute__((ext_vector_type(VEC)));
     extern __shared__ __align__(16) float lds[];
     float* ut = lds;                                         // [16 xi][16 co][KCP]
-    float* xt = lds + 16 * 16 * KCP;                         // [TN][HT][WT][KCP]
+    float* xt = lds + 16 * 16 * KCP;                         // [TN][HT][WT][KXP]
     const int TTW = 1 << p.lgTW, TTH = 1 << p.lgTH;
     const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,9 +91,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     const int npix = p.TN * HT * WT;
 
     // this lane's tile inside the block
-    const int t = wave * 16 + li;
+    // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with 8 tiles per row the map
+    // li -> (li&3) + 4*(li>>3) + 8*(bit2 ^ bit3) gives every group one full row of 8 tiles per kk; tiles are 2 pixels =
+    // KXP/2 = 10 sixteen-byte slots apart, so the 8 tiles cover the even (kk 0) / odd (kk 1) slots of the 256-byte bank row
+    // exactly once (stride 24 puts tiles t and t+4 on the same banks: 2-way conflicts on all 16 patch reads).
+    const int lt = p.lgTW == 3 ? (li & 3) + 4 * (li >> 3) + 8 * (((li >> 2) ^ (li >> 3)) & 1) : li;
+    const int t = wave * 16 + lt;
     const int ttx = t & (TTW - 1), tty = (t >> p.lgTW) & (TTH - 1), ttn = t >> (p.lgTW + p.lgTH);
-    const int pbase = ((ttn * HT + 2 * tty) * WT + 2 * ttx) * KCP + VEC * kk;
+    const int pbase = ((ttn * HT + 2 * tty) * WT + 2 * ttx) * KXP + VEC * kk;
 
     // buffer resources: U whole, x from the first image of this workgroup (the host checks both spans stay below 2 GiB)
     const size_t img = (size_t)xH * xW * p.Cin;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         const bool in_tile = q < npix;
         const bool ok = in_tile && n < p.N && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         if (p.ups) { ih >>= 1; iw >>= 1; }
-        xdst[i] = in_tile ? q * KCP + 4 * v : -1;
+        xdst[i] = in_tile ? q * KXP + 4 * v : -1;
         xsrc[i] = ok ? 4u * (unsigned)(((tn * xH + ih) * xW + iw) * p.Cin + 4 * v) : PG_OOB;
     }
 #pragma unroll
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const fragv t = *reinterpret_cast<const fragv*>(xt + pbase + (a * WT + c) * KCP);
+                const fragv t = *reinterpret_cast<const fragv*>(xt + pbase + (a * WT + c) * KXP);
 #pragma unroll
                 for (int h = 0; h < VEC / 2; ++h) d[a][c][h] = v2f{t[2 * h], t[2 * h + 1]};
             }
@@ -358,7 +364,7 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
     }
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     const int vec = g_wino_vec;
-    const size_t smem = (size_t)(16 * 16 + TN * HT * WT) * (vec == 4 ? 24 : 12) * sizeof(float);
+    const size_t smem = ((size_t)16 * 16 * (vec == 4 ? 24 : 12) + (size_t)TN * HT * WT * (vec == 4 ? 20 : 12)) * sizeof(float);
     dim3 grid((unsigned)(((N + TN - 1) / TN) * p.blocksH * p.blocksW), (unsigned)((Cout + 15) / 16));
     snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino_kernel<%d>", vec);
     if (vec == 4) {
