@@ -11,7 +11,9 @@ backward + Adam(G), on one synthetic minibatch already resident in HBM.  Headlin
 1024x1024 growth stage (depth 8) of the default-width (fmap_base 4096) CelebA-HQ-shape network with
 the reference's per-depth minibatch (3 per GPU, plugins.py:20), fp32.  Data-parallel: one process
 per GPU, minibatch per rank fixed (weak scaling), one RCCL sum-all-reduce of each network's flat
-gradient buffer per iteration.  Rank 0 prints ONE JSON line.
+gradient buffer per iteration.  Rank 0 prints ONE JSON line (the last line of stdout).
+Setup before the W warmup steps: --prime (default 50) untimed steps that load the code objects, grow the
+caching allocator and let the clocks settle; the count is reported as "priming_steps".
 """
 import argparse
 import json
