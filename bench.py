@@ -194,18 +194,27 @@ def d_step_ms(tr, steps):
     """per-depth 'D+GP ms' = wgan_gp_D_loss + backward + Adam(D)."""
     real = next(tr.dataiter)
     z = tr.random_latents_generator()
-    for _ in range(2):
+    def one():
         c = tr.D_loss(tr.D, tr.G, real, z)[0]
         c.backward()
+        if tr.parallel is not None:                          # the D-step of Trainer.train(): gradients summed over ranks
+            tr.parallel.all_reduce_grads(tr.D)
         tr.optimizer_d.step()
+    for _ in range(2):
+        one()
+    if tr.parallel is not None:
+        tr.parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        c = tr.D_loss(tr.D, tr.G, real, z)[0]
-        c.backward()
-        tr.optimizer_d.step()
+        one()
     torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0) / steps
+    dt = time.perf_counter() - t0
+    if tr.parallel is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    return 1e3 * dt / steps
 
 
 def cpu_baseline(depth, mb):
@@ -334,18 +343,20 @@ def main():
             tr.train()
     pg.wgan_gp_loss.enable_graphs(True if args.graphs else 'auto')
 
-    if not args.no_per_depth and dp is None:
+    if not args.no_per_depth:
         per = []
         del tr
         torch.cuda.empty_cache()
         for d in range(0, 9):
             m = REF_MINIBATCH.get(d, 16)
-            t = make_trainer(pg, 1024, d, 1.0, m, 1337, None)
+            t = make_trainer(pg, 1024, d, 1.0, m, pg.parallel.shard_seed(1337, rank), dp)
+            if dp is not None:
+                dp.broadcast_params(t.G, t.D)
             k = 100 if d <= 1 else (40 if d <= 3 else (20 if d <= 5 else (8 if d <= 7 else 5)))
-            tt = timed_steps(t, k, 5 if d <= 3 else 3, None)
+            tt = timed_steps(t, k, 5 if d <= 3 else 3, dp)            # max over ranks; minibatch m PER RANK (weak scaling)
             dms = d_step_ms(t, k)
             Wd = 18 * F_D[d] * 1e9
-            per.append({'depth': d, 'res': 4 * 2 ** d, 'minibatch': m, 'images_per_sec': m * k / tt,
+            per.append({'depth': d, 'res': 4 * 2 ** d, 'minibatch': m, 'images_per_sec': n_gpus * m * k / tt,
                         'ms_per_step': 1e3 * tt / k, 'd_step_gp_ms': dms,
                         'mfma_frac': Wd * (m * k / tt) / MFMA_F32_PEAK})
             del t
