@@ -3,9 +3,9 @@
 The reference has no distributed code; the sharding is defined by BASELINE.json's north_star and
 SURVEY.md §8e: each rank runs the full step on its own minibatch (DepthManager's minibatch size is
 PER RANK — weak scaling), minibatch-stddev is evaluated on the local shard, and there is exactly one
-exchange step per network per iteration: a SUM all-reduce of the network's flat gradient buffer
+exchange step per network per iteration: a SUM all-reduce of the live spans of the network's flat gradient buffer
 (``backend='nccl'`` is RCCL on ROCm); the 1/world_size is folded into the fused Adam
-(``FusedAdam.grad_scale``).  One collective of <=73 MB per network instead of one per tensor:
+(``FusedAdam.grad_scale``).  One or two collectives of up to 92 MB per network instead of one per tensor:
 xGMI is point-to-point, so few large messages are what keeps the links busy."""
 import os
 
@@ -64,12 +64,45 @@ class DataParallel(object):
         return flat
 
     def all_reduce_grads(self, net):
+        """SUM all-reduce of the gradients of the layers that are live at the current growth stage: the parameters
+        whose ``.grad`` the backward pass attached (a function of depth / alpha only, so every rank derives the same
+        ranges) form a few contiguous spans of the flat gradient buffer — at 4x4 that is 26 MB instead of the whole
+        92 MB buffer, at 1024x1024 everything, in one or two collectives."""
         if net._flat_grad is None:
             raise RuntimeError('all_reduce_grads called before any backward pass')
-        return self.all_reduce_flat(net._flat_grad)
+        flat = net._flat_grad
+        for s, e in active_grad_spans(net):
+            self.all_reduce_flat(flat[s:e])
+        return flat
 
     def barrier(self):
         dist.barrier()
+
+
+MERGE_GAP = 1 << 16        # spans closer than 256 KB travel in one collective (the gap is zeros: inactive layers)
+
+
+def active_grad_spans(net):
+    """[(start, end)] element ranges of net._flat_grad that hold the gradients attached by the last backward pass."""
+    flat = net._flat_grad
+    base, total = flat.data_ptr(), flat.numel()
+    spans = []
+    for p in net.parameters():
+        g = p.grad
+        if g is None:
+            continue
+        off = (g.data_ptr() - base) // 4
+        if off < 0 or off + g.numel() > total:
+            return [(0, total)]                              # a gradient outside the flat buffer: reduce everything
+        spans.append((off, off + g.numel()))
+    spans.sort()
+    merged = []
+    for s, e in spans:
+        if merged and s - merged[-1][1] <= MERGE_GAP:
+            merged[-1][1] = max(merged[-1][1], e)
+        else:
+            merged.append([s, e])
+    return [(s, e) for s, e in merged]
 
 
 def shard_seed(base_seed, rank):

@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, res):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -39,10 +39,11 @@ def _worker(rank, world, port, out_path):
     dp = pg.DataParallel()
     assert dp.world_size == world and dp.rank == rank
     torch.manual_seed(100 + rank)                      # deliberately different init per rank ...
-    shape = (1, 3, 16, 16)
+    shape = (1, 3, res, res)
     kw = dict(fmap_base=64, fmap_max=16)
     G = pg.Generator(shape, latent_size=16, **kw)
     D = pg.Discriminator(shape, **kw)
+    pg.parallel.MERGE_GAP = 0                          # tiny layers: keep the live spans apart so the span logic is exercised
     dp.broadcast_params(G, D)                          # ... made identical by the broadcast from rank 0
     G.depth = D.depth = 2
     G.alpha = D.alpha = 0.5
@@ -79,6 +80,7 @@ def _worker(rank, world, port, out_path):
         key = 'D' if net is D else 'G'
         if key not in first:                               # summed (not yet averaged) gradients, iteration 0
             first[key] = {k: v.clone() for k, v in reference_grads(net).items()}
+            first[key + '_reduced'] = (sum(e - s for s, e in pg.parallel.active_grad_spans(net)), net._flat_grad.numel())
         return r
     dp.all_reduce_grads = recording_all_reduce
     tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, DS(), loader(), rlg, parallel=dp)
@@ -102,10 +104,11 @@ def _err(a, b):
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-3))
 
 
-def test_two_rank_data_parallel_matches_oracle(tmp_path, oracle):
+@pytest.mark.parametrize('res', [16, 32])               # 32: the last growth stage is not live at depth 2 -> partial all-reduce
+def test_two_rank_data_parallel_matches_oracle(tmp_path, oracle, res):
     world = 2
     out_path = str(tmp_path / 'dp.pt')
-    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out_path, res), nprocs=world, join=True)
     got = torch.load(out_path, weights_only=False)
     # oracle: same start (rank 0's init), per-shard gradients averaged
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -113,12 +116,15 @@ def test_two_rank_data_parallel_matches_oracle(tmp_path, oracle):
     from helpers import synthetic
     from conftest import rel_err
     torch.manual_seed(100)
-    shape = (1, 3, 16, 16)
+    shape = (1, 3, res, res)
     kw = dict(fmap_base=64, fmap_max=16)
     G = pg.Generator(shape, latent_size=16, **kw)
     D = pg.Discriminator(shape, **kw)
     gp, dp_ = G.reference_state_dict(), D.reference_state_dict()
-    cfg = oracle.NetCfg(16, 3, latent_size=16, **kw)
+    cfg = oracle.NetCfg(res, 3, latent_size=16, **kw)
+    for key in ('D', 'G'):
+        reduced, total = got['first'][key + '_reduced']
+        assert reduced <= total and (total - reduced > 300) == (res > 16), (key, reduced, total)   # only the live layers travel
     og, od = oracle.AdamState(), oracle.AdamState()
     for it in range(2):
         shards = [synthetic(pg.parallel.shard_seed(900 + 10 * it, r), 3, 3, 16, 16) for r in range(world)]
