@@ -192,6 +192,32 @@ def _join_side():
         torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
 
 
+def defer_to_side(net, fn):
+    """Run ``fn()`` — the tail of a network's update: gradient all-reduce, Adam, derived weights — on the side stream,
+    after everything queued so far on the current stream.  The current stream picks the result up in ``wait_pending``
+    at its next use of the network's weights, so the tail of the D update overlaps the generator forward that opens
+    the G step (the G step touches D only after G(z))."""
+    if not (ASYNC_WGRAD and net._flat_param.is_cuda):
+        fn()
+        return
+    main = torch.cuda.current_stream()
+    side = _side_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+        ev = torch.cuda.Event()
+        ev.record(side)
+    net._pending = ev
+
+
+def wait_pending(net):
+    """The current stream waits for a deferred update of ``net`` (no-op when there is none)."""
+    ev = getattr(net, '_pending', None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+        net._pending = None
+
+
 def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False):
     """Weight (and bias) gradient of one conv layer on the side stream.  The wide 3x3 layers take the Winograd form
     (2.25x fewer MFMAs, 1.3-1.7x faster from 16x16 up, 16-channel sides included); the 8-channel layers and the
@@ -220,6 +246,7 @@ def _ones(n, device):
 # ------------------------------------------------------------------------------------------
 def generator_forward(G, z, save=False, out=None):
     """reference network.py:118-139.  z [N,latent] -> NCHW image [N,C,r,r] (written into ``out``)."""
+    wait_pending(G)
     ops.require_gpu()
     z = _check_dev(z, 'latents')
     N, L = z.shape
@@ -274,6 +301,7 @@ def generator_forward(G, z, save=False, out=None):
 
 def generator_backward(G, ctx, g_out):
     """Adjoint sweep of generator_forward: accumulates into G's flat gradient buffer."""
+    wait_pending(G)
     G._ensure_buffers()
     N, depth, alpha = ctx['N'], ctx['depth'], ctx['alpha']
     C = G.num_channels
@@ -328,6 +356,7 @@ def generator_backward(G, ctx, g_out):
 def d_forward(D, x, groups=1):
     """reference network.py:225-240 on a batch of ``groups`` independent minibatches stacked along
     N (minibatch-stddev is evaluated per group).  Returns (scores [NB], ctx with every activation)."""
+    wait_pending(D)
     NB, C, r, _ = x.shape
     depth, alpha = int(D.depth), float(D.alpha)
     if r != 4 * 2 ** depth or C != D.num_channels:
@@ -404,6 +433,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
     hvp         : (n_head, tx, tstats, gy_first) — the last ``NB-n_head`` images form one extra group
                   whose score gradient is zero and which only receives the minibatch-stddev
                   Hessian-vector injection; ``gscore`` then has n_head entries."""
+    wait_pending(D)
     if getattr(D, 'pixelnorm', False):
         return _d_backward_pn(D, ctx, gscore, full, want_gimg, save_adjoints, hvp)
     D._ensure_buffers()
@@ -611,6 +641,7 @@ def d_tangent_wgrad(D, sub, adj, u):
     """Gradient-penalty second-order term, steps (i)+(ii): push the seed ``u`` (NCHW, same shape as the
     mixed batch) through the masked linear maps of D and accumulate, per layer,
     dW += c * wgrad(tangent_input, first_backward_adjoint).  Returns the minibatch-stddev HVP inputs."""
+    wait_pending(D)
     D._ensure_buffers()
     N, alpha = sub['NB'], sub['alpha']
     C = D.num_channels

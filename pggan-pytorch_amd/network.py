@@ -278,6 +278,7 @@ class _FlatParamsMixin(object):
         d['_flat_wu'] = d['_flat_wtu'] = None
         d['_wino_layers'] = None
         d['_derived_ver'] = None
+        d['_pending'] = None
         d['_lin_gw'] = d['_lin_gb'] = None
         return d
 

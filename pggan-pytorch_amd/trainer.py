@@ -10,6 +10,9 @@ Additions for the MI355X data-parallel path (both optional, default off):
     function of the number of images shown;
   * inputs that are not yet on the device are moved there (the reference's ``.cuda()`` calls)."""
 import heapq
+import os
+
+from . import engine
 
 
 def _to_device(t):
@@ -96,6 +99,22 @@ class Trainer(object):
                 self.call_plugins('epoch', self.cur_tick)
         self.call_plugins('end', 1)
 
+    def _d_update(self):
+        if self.parallel is not None:
+            self.parallel.all_reduce_grads(self.D)
+        self.optimizer_d.step()                                                   # reference trainer.py:100
+        if getattr(self.D, '_flat_param', None) is not None and self.D._flat_param.is_cuda:
+            engine._derived(self.D)
+
+    def _can_overlap_d_update(self):
+        """Only with the product's own G loss (it reaches D's weights through the engine, which waits for the deferred
+        update) and when the step is launched eagerly (a captured hipGraph step has no second stream to overlap with)."""
+        from . import wgan_gp_loss
+        if os.environ.get('PGGAN_OVERLAP_D_UPDATE', '1') == '0':
+            return False
+        return (self.G_loss is wgan_gp_loss.wgan_gp_G_loss and hasattr(self.D, '_flat_param')
+                and not wgan_gp_loss._graphs_on(self.D) and not wgan_gp_loss._graphs_on(self.G))
+
     def train(self):
         """One iteration.  reference trainer.py:85-115."""
         world = 1 if self.parallel is None else self.parallel.world_size
@@ -108,9 +127,12 @@ class Trainer(object):
             d_losses = tuple(d_losses)
             D_loss = d_losses[0]
             D_loss.backward()                                                     # :98
-            if self.parallel is not None:
-                self.parallel.all_reduce_grads(self.D)
-            self.optimizer_d.step()                                               # :100
+            if i == self.D_training_repeats - 1 and self._can_overlap_d_update():
+                # the tail of the last D update (all-reduce, Adam, derived weights) runs on the second stream under the
+                # generator forward that opens the G step; the main stream re-joins at its first use of D (engine.wait_pending)
+                engine.defer_to_side(self.D, self._d_update)
+            else:
+                self._d_update()
             fake_latents_in = _to_device(self.random_latents_generator())         # :103
         g_losses = self.G_loss(self.G, self.D, fake_latents_in)                   # :105
         if type(g_losses) is list:
@@ -122,5 +144,6 @@ class Trainer(object):
         if self.parallel is not None:
             self.parallel.all_reduce_grads(self.G)
         self.optimizer_g.step()                                                   # :112
+        engine.wait_pending(self.D)                  # (a G_loss that never ran D: nothing may outlive the iteration)
         self.iterations += 1
         self.call_plugins('iteration', self.iterations, *(g_losses + d_losses))   # :115

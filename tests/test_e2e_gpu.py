@@ -494,3 +494,47 @@ def test_full_schedule_soak_reference_widths():
     assert torch.isfinite(D._flat_param).all() and torch.isfinite(G._flat_param).all()
     moved = (D._flat_param != p0)
     assert float(moved.float().mean()) > 0.99            # every D parameter (incl. all fromRGB layers) was updated
+
+
+@pytest.mark.gpu
+def test_deferred_d_update_matches_inline(monkeypatch):
+    """Trainer runs the tail of the D update (all-reduce, Adam, derived weights) on the second stream under the G
+    forward of the G step (engine.defer_to_side).  Same seeds with the overlap switched off must give the same
+    weights (up to the atomic-add order of the weight gradients), and the deferred path must really be taken."""
+    def run(overlap):
+        monkeypatch.setenv('PGGAN_OVERLAP_D_UPDATE', '1' if overlap else '0')
+        torch.manual_seed(23)
+        shape = (1, 3, 64, 64)
+        kw = dict(fmap_base=512, fmap_max=64)
+        G = pg.Generator(shape, latent_size=64, **kw).to(DEV)
+        D = pg.Discriminator(shape, **kw).to(DEV)
+        G.depth = D.depth = 4
+        rs = np.random.RandomState(5)
+        reals = iter([torch.from_numpy(rs.rand(4, 3, 64, 64).astype(np.float32) * 2 - 1) for _ in range(4)])
+        zs = iter([torch.from_numpy(rs.randn(4, 64).astype(np.float32)) for _ in range(8)])
+        mixes = iter([torch.from_numpy(rs.rand(4, 1).astype(np.float32)) for _ in range(4)])
+
+        def d_loss(Dm, Gm, real, z):
+            pg.wgan_gp_loss.set_mixing_factors(next(mixes))
+            return pg.wgan_gp_D_loss(Dm, Gm, real, z)
+        opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+        opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+        tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, None, reals, lambda: next(zs))
+        taken = []
+        orig = pg.engine.defer_to_side
+        monkeypatch.setattr(pg.engine, 'defer_to_side', lambda net, fn: (taken.append(1), orig(net, fn))[1])
+        for _ in range(3):
+            tr.train()
+        monkeypatch.setattr(pg.engine, 'defer_to_side', orig)
+        torch.cuda.synchronize()
+        assert getattr(D, '_pending', None) is None
+        return G.reference_state_dict(), D.reference_state_dict(), len(taken)
+    g1, d1, n1 = run(True)
+    g0, d0, n0 = run(False)
+    assert n1 == 3 and n0 == 0
+    for a, b in ((g1, g0), (d1, d0)):
+        for k, v in a.items():
+            if torch.is_tensor(v):
+                # Adam with beta1 = 0 is sign-like: a weight-gradient element within atomic round-off of zero may flip
+                assert float((v - b[k]).abs().max()) <= 2 * 0.001 * 3 + 1e-6, k
+                assert rel_err(v.cpu(), b[k].cpu()) < 2e-2, k
