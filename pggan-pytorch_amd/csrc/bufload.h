@@ -18,3 +18,12 @@ __device__ __forceinline__ float4 pg_buf_load4(__amdgpu_buffer_rsrc_t r, unsigne
     const pg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+
+// XCD-aware workgroup order (MI355X: 8 XCDs x 32 CUs, one private L2 per XCD; the dispatcher places block b on XCD b % 8).
+// Neighbouring tiles share halo rows / columns, so each XCD gets a CONTIGUOUS range of the tile sequence instead of
+// every 8th tile: the halo is then re-read from that XCD's L2 instead of from HBM.  Bijective for any grid size.
+__device__ __forceinline__ unsigned pg_xcd_remap(unsigned b, unsigned n)
+{
+    const unsigned q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     const int wave_co = wave % WAVES_CO, wave_px = wave / WAVES_CO;
     const int li = lane & 15, kk = lane >> 4;
 
-    int t = blockIdx.x;
+    int t = (int)pg_xcd_remap(blockIdx.x, gridDim.x);       // contiguous tile ranges per XCD (bufload.h)
     const int tw_i = t % p.tilesW; t /= p.tilesW;
     const int th_i = t % p.tilesH; t /= p.tilesH;
     const int n0 = t * p.TN;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p)
         }
     };
 
-    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_begin = (int)pg_xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;   // neighbouring tile ranges on one XCD
     const int t_end = min(t_begin + p.tiles_per_block, p.ntiles);
     constexpr int NSTEPS = BPX / 4;
 
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
     float* wl = lds + HT * WT * S;               // [9][COUT][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = lane >> 2, j = lane & 3, qo = blk % QO, qp = blk / QO;
-    int b = blockIdx.x;
+    int b = (int)pg_xcd_remap(blockIdx.x, gridDim.x);         // contiguous tile ranges per XCD: halos come from its L2
     const int tw_i = b % (p.Wout >> 5); b /= (p.Wout >> 5);
     const int th_i = b % (p.Hout / TH); const int n = b / (p.Hout / TH);
     const int oh0 = th_i * TH, ow0 = tw_i << 5;
@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
         }
     };
 
-    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_begin = (int)pg_xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;   // neighbouring tile ranges on one XCD
     const int t_end = min(t_begin + p.tiles_per_block, p.ntiles);
     constexpr int NSTEPS = BPX / PPM, T = NSTEPS / 4;            // k-steps per tile / per wave
 

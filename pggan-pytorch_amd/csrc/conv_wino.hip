@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
-    int b = blockIdx.x;
+    int b = (int)pg_xcd_remap(blockIdx.x, gridDim.x);       // contiguous tile-block ranges per XCD (bufload.h)
     const int bw = b % p.blocksW; b /= p.blocksW;
     const int bh = b % p.blocksH; b /= p.blocksH;
     const int n0 = b * p.TN;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
             xreg[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)((ih * xW + iw) * p.Cin + xcv[i]) : PG_OOB, 0);
         }
     };
-    const int r_begin = blockIdx.x * p.regions_per_block;
+    const int r_begin = (int)pg_xcd_remap(blockIdx.x, gridDim.x) * p.regions_per_block;   // neighbouring region ranges on one XCD
     const int r_end = min(r_begin + p.regions_per_block, p.nregions);
     if (r_begin < r_end) fetch(r_begin);
     for (int region = r_begin; region < r_end; ++region) {
