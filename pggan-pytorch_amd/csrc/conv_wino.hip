@@ -27,7 +27,7 @@ struct WinoP {
     const float* x; const float* u; const float* bias; const float* mask; float* y;
     int N, H, W, Cin, Cout, ups;
     float scale, slope, mask_slope;
-    int lgTW, lgTH, TN, blocksW, blocksH;      // workgroup = TN images x 2^lgTH x 2^lgTW tiles (64 tiles)
+    int lgTW, lgTH, TN, blocksW, blocksH, ncob, cout_minor; // workgroup = TN images x 2^lgTH x 2^lgTW tiles (64 tiles); cout blocks of 16
     unsigned mWT, mHT;                         // magic reciprocals of the halo region width / height in pixels
     // fused epilogues (same semantics as the direct kernel, see pggan_hip.h)
     float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
@@ -81,12 +81,20 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
-    int b = (int)pg_xcd_remap(blockIdx.x, gridDim.x);       // contiguous tile-block ranges per XCD (bufload.h)
+    // 1-D grid, cout blocks minor: after the XCD remap (bufload.h) the workgroups that share an input region (same tiles,
+    // different couts) run back to back on ONE XCD, so the region comes from HBM once and from that L2 afterwards; each XCD
+    // walks a contiguous range of tile blocks (halo rows / columns shared with the neighbours stay in its L2 too).
+    // Layers whose Winograd weights do not fit an L2 (> 2 MB: the 256/512-channel layers) keep the tile-minor order
+    // instead, where all concurrently running workgroups share one 16-cout slice of U.
+    int b = (int)pg_xcd_remap(blockIdx.x, gridDim.x);
+    int cob;
+    if (p.cout_minor) { cob = b % p.ncob; b /= p.ncob; }
+    else { const int ntb = (int)gridDim.x / p.ncob; cob = b / ntb; b -= cob * ntb; }
     const int bw = b % p.blocksW; b /= p.blocksW;
     const int bh = b % p.blocksH; b /= p.blocksH;
     const int n0 = b * p.TN;
     const int ty0 = bh << p.lgTH, tx0 = bw << p.lgTW;        // first tile of the block
-    const int co0 = blockIdx.y * 16;
+    const int co0 = cob * 16;
     const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
     const int npix = p.TN * HT * WT;
 
@@ -365,7 +373,9 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     const int vec = g_wino_vec;
     const size_t smem = ((size_t)16 * 16 * (vec == 4 ? 24 : 12) + (size_t)TN * HT * WT * (vec == 4 ? 20 : 12)) * sizeof(float);
-    dim3 grid((unsigned)(((N + TN - 1) / TN) * p.blocksH * p.blocksW), (unsigned)((Cout + 15) / 16));
+    p.ncob = (Cout + 15) / 16;
+    p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20);      // measured: tools/sweep_wino.py
+    dim3 grid((unsigned)(((N + TN - 1) / TN) * p.blocksH * p.blocksW * p.ncob));
     snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino_kernel<%d>", vec);
     if (vec == 4) {
         if (smem > 48 * 1024) {
