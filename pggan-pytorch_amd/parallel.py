@@ -5,7 +5,7 @@ SURVEY.md §8e: each rank runs the full step on its own minibatch (DepthManager'
 PER RANK — weak scaling), minibatch-stddev is evaluated on the local shard, and there is exactly one
 exchange step per network per iteration: a SUM all-reduce of the live spans of the network's flat gradient buffer
 (``backend='nccl'`` is RCCL on ROCm); the 1/world_size is folded into the fused Adam
-(``FusedAdam.grad_scale``).  One or two collectives of up to 92 MB per network instead of one per tensor:
+(``FusedAdam.grad_scale``).  One or two collectives of up to 73 MB per network instead of one per tensor:
 xGMI is point-to-point, so few large messages are what keeps the links busy."""
 import os
 
@@ -67,7 +67,7 @@ class DataParallel(object):
         """SUM all-reduce of the gradients of the layers that are live at the current growth stage: the parameters
         whose ``.grad`` the backward pass attached (a function of depth / alpha only, so every rank derives the same
         ranges) form a few contiguous spans of the flat gradient buffer — at 4x4 that is 26 MB instead of the whole
-        92 MB buffer, at 1024x1024 everything, in one or two collectives."""
+        73 MB buffer, at 1024x1024 everything, in one or two collectives."""
         if net._flat_grad is None:
             raise RuntimeError('all_reduce_grads called before any backward pass')
         flat = net._flat_grad
