@@ -758,7 +758,11 @@ def d_loss_backward(state, scale=1.0):
     hvp = d_tangent_wgrad(D, state['sub'], state['adj'], state['u'])
     gs = state['gscore'][:2 * N]
     d_backward(D, ctx, gs, full=True, want_gimg=False, hvp=(2 * N,) + hvp)
-    _join_side()
+    if not (getattr(D, '_skip_join', False) and scale == 1.0):
+        _join_side()         # default: the gradients are complete for whatever the caller does next on this stream
+    # (Trainer sets _skip_join when the whole D update follows on the second stream, in order behind the weight
+    #  gradients: the main stream then goes straight on to the G step instead of idling under the last, largest
+    #  weight-gradient launches of the 1024^2 layers)
     if scale != 1.0:
         ops.axpby_mask(D._flat_grad, a=scale, out=D._flat_grad)
     _assign_grads(D, d_active_params(D, ctx['depth'], ctx['alpha']), linear=True)

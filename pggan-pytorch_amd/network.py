@@ -279,6 +279,7 @@ class _FlatParamsMixin(object):
         d['_wino_layers'] = None
         d['_derived_ver'] = None
         d['_pending'] = None
+        d['_skip_join'] = False
         d['_lin_gw'] = d['_lin_gb'] = None
         return d
 

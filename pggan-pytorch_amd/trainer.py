@@ -126,8 +126,13 @@ class Trainer(object):
             d_losses = self.D_loss(self.D, self.G, real_images_expr, fake_latents_in)   # :95
             d_losses = tuple(d_losses)
             D_loss = d_losses[0]
-            D_loss.backward()                                                     # :98
-            if i == self.D_training_repeats - 1 and self._can_overlap_d_update():
+            defer = i == self.D_training_repeats - 1 and self._can_overlap_d_update()
+            self.D._skip_join = defer                # the update runs on the second stream, behind the weight gradients
+            try:
+                D_loss.backward()                                                 # :98
+            finally:
+                self.D._skip_join = False
+            if defer:
                 # the tail of the last D update (all-reduce, Adam, derived weights) runs on the second stream under the
                 # generator forward that opens the G step; the main stream re-joins at its first use of D (engine.wait_pending)
                 engine.defer_to_side(self.D, self._d_update)

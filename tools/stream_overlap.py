@@ -1,0 +1,54 @@
+"""Occupancy of the two HIP streams from a rocprofv3 kernel trace of bench.py (run on the GPU box):
+
+    cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace -d $OUT -o kt --output-format csv -- python bench.py --no-cpu --no-per-depth --no-kernel-timing --prime 10 --steps 10 --warmup 3
+    python tools/stream_overlap.py $OUT/**/kt_kernel_trace.csv
+
+Takes the last 10 train steps (delimited by the Adam launches of the generator), and reports per queue: busy time,
+share of the wall time; the union of both queues (GPU never idle?) and the sum of kernel durations per step."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+path = glob.glob(sys.argv[1], recursive=True)[0]
+rows = []
+with open(path) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r.get('Queue_Id', r.get('Stream_Id', '0')), r['Kernel_Name']))
+rows.sort()
+# the last 10 steps of the timed loop: 20 Adam "big" launches (2 networks) -> cut at the 31st-last adam launch group
+adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[3]]
+per_step = 3                                          # measured: 3 adam launches per train step at depth 8
+nsteps = 10
+first = adam[-per_step * nsteps - 1] + 1 if len(adam) > per_step * nsteps else 0
+last = adam[-1]
+win = rows[first:last + 1]
+t0, t1 = win[0][0], max(r[1] for r in win)
+wall = t1 - t0
+
+
+def union(intervals):
+    tot, cur_s, cur_e = 0, None, None
+    for s, e in sorted(intervals):
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        tot += cur_e - cur_s
+    return tot
+
+
+byq = defaultdict(list)
+for s, e, q, name in win:
+    byq[q].append((s, e))
+print('window: %d kernels, %.2f ms wall = %.3f ms per step (%d steps)' % (len(win), wall / 1e6, wall / 1e6 / nsteps, nsteps))
+for q, iv in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
+    busy = union(iv)
+    print('queue %s: %5d kernels, busy %.2f ms (%.1f %% of wall), sum of durations %.2f ms' % (
+        q, len(iv), busy / 1e6, 100.0 * busy / wall, sum(e - s for s, e in iv) / 1e6))
+allbusy = union([(s, e) for s, e, _, _ in win])
+print('any queue busy: %.1f %% of wall; sum of all kernel durations %.3f ms per step (%.2fx the wall time)' % (
+    100.0 * allbusy / wall, sum(e - s for s, e, _, _ in win) / 1e6 / nsteps, sum(e - s for s, e, _, _ in win) / wall))
