@@ -170,7 +170,7 @@ class _on_side(object):
     def __enter__(self):
         if not self.active:
             return self
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(torch._C._cuda_getDevice())      # explicit index: skips the slow device lookup
         self.side = _side_stream()
         self.side.wait_stream(main)
         self.ctx = torch.cuda.stream(self.side)
@@ -189,7 +189,7 @@ class _on_side(object):
 def _join_side():
     """Main stream waits for every weight-gradient launch (call before the optimizer / all-reduce)."""
     if ASYNC_WGRAD and torch.cuda.is_available() and torch.cuda.current_device() in _SIDE:
-        torch.cuda.current_stream().wait_stream(_SIDE[torch.cuda.current_device()])
+        torch.cuda.current_stream(torch._C._cuda_getDevice()).wait_stream(_SIDE[torch.cuda.current_device()])
 
 
 def defer_to_side(net, fn):
@@ -200,7 +200,7 @@ def defer_to_side(net, fn):
     if not (ASYNC_WGRAD and net._flat_param.is_cuda):
         fn()
         return
-    main = torch.cuda.current_stream()
+    main = torch.cuda.current_stream(torch._C._cuda_getDevice())
     side = _side_stream()
     side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -214,7 +214,7 @@ def wait_pending(net):
     """The current stream waits for a deferred update of ``net`` (no-op when there is none)."""
     ev = getattr(net, '_pending', None)
     if ev is not None:
-        torch.cuda.current_stream().wait_event(ev)
+        torch.cuda.current_stream(torch._C._cuda_getDevice()).wait_event(ev)
         net._pending = None
 
 

@@ -52,3 +52,31 @@ for q, iv in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
 allbusy = union([(s, e) for s, e, _, _ in win])
 print('any queue busy: %.1f %% of wall; sum of all kernel durations %.3f ms per step (%.2fx the wall time)' % (
     100.0 * allbusy / wall, sum(e - s for s, e, _, _ in win) / 1e6 / nsteps, sum(e - s for s, e, _, _ in win) / wall))
+
+# where nothing runs: the largest gaps of the union, with the kernels on either side, and the gap histogram
+iv = sorted((s, e, name) for s, e, _, name in win)
+gaps = []
+cur_e, cur_name = iv[0][1], iv[0][2]
+for s, e, name in iv[1:]:
+    if s > cur_e:
+        gaps.append((s - cur_e, cur_name, name))
+    if e > cur_e:
+        cur_e, cur_name = e, name
+
+
+def short(n):
+    import re
+    m = re.search(r'([A-Za-z_0-9]+_kernel(<[^>]*>)?|__amd_rocclr_\w+)', n)
+    return m.group(1) if m else n[:40]
+
+
+tot = sum(g[0] for g in gaps)
+print('idle (no queue busy): %.3f ms per step in %d gaps per step; gaps > 20 us: %.3f ms per step' % (
+    tot / 1e6 / nsteps, len(gaps) // nsteps, sum(g[0] for g in gaps if g[0] > 20000) / 1e6 / nsteps))
+agg = defaultdict(lambda: [0, 0])
+for g, a, b in gaps:
+    k = short(a) + ' -> ' + short(b)
+    agg[k][0] += g
+    agg[k][1] += 1
+for k, (g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
+    print('  %7.1f us per step in %4.1f gaps per step: %s' % (g / 1e3 / nsteps, c / nsteps, k))
