@@ -92,8 +92,21 @@ int pg_conv2d_pnbwd_nhwc(const float* x, const float* w, const float* ysaved, co
  * `y` ([N][Hout][Wout][Cout]) is scratch: written only when the launch cannot fuse (split-K / small-M / thin
  * kernels), in which case pg_avgpool2_bwd runs as a second pass.  Bit-identical to that pair.  upmask may be NULL. */
 int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, float* y, float* yup,
-                          int N, int Hin, int Win, int Cin, int Cout, int KS, int pad,
+                          int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int flags,
                           float scale, float up_mul, float mask_slope, pg_stream_t stream);
+
+/* Sign-byte activations.  An activation that is only ever used for its sign -- the c2 output of a DBlock before the
+ * avg_pool2d of network.py:229/238: its LeakyReLU' mask in the backward / tangent sweeps -- need not exist in fp32.
+ * Flag bits passed in the `ups` / `flags` argument of the pool / unpool / Winograd entry points:
+ *   PG_FLAG_UPSAMPLE    bit 0: nearest x2 upsample of x fused into the gather (the historic meaning of `ups`)
+ *   PG_FLAG_MASK_BYTES  `mask` / `upmask` point to sign bytes: uint8 [N][H][W][C/4], bit j of a byte = (channel 4q+j > 0)
+ *   PG_FLAG_Y_BYTES     `y` points to such a byte array and receives the signs of the activated output (needs ypool)
+ * Only the fused epilogues of the tile kernels know the format: PG_E_UNSUP means "redo this launch with fp32 masks"
+ * (pg_signbytes_to_mask expands a byte array to a +1 / -1 fp32 mask for that case).                              */
+#define PG_FLAG_UPSAMPLE   1
+#define PG_FLAG_MASK_BYTES 2
+#define PG_FLAG_Y_BYTES    4
+int pg_signbytes_to_mask(const unsigned char* bytes, float* mask, int64_t nbytes, pg_stream_t stream);
 
 /* Winograd F(2x2,3x3) path for the wide 3x3 layers (pad 1; Cin % 16 == 0; H, W powers of two >= 8): 2.25x fewer MFMAs
  * than the direct implicit GEMM, same fp32 sums re-associated (transform coefficients +-1, 1/2; ~1e-6 relative).

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class PgganLibraryError(RuntimeError):
@@ -28,7 +28,8 @@ SIGNATURES = {
     'pg_conv2d_pool_nhwc': [P, P, P, P, P, P, P, F, F, I, I, I, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_pixelnorm_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_pnbwd_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, F, F, P],
-    'pg_conv2d_unpool_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, F, F, F, P],
+    'pg_conv2d_unpool_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
+    'pg_signbytes_to_mask': [P, P, L, P],
     'pg_wino_transform_weights': [P, P, I, I, P],
     'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P],
     'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
@@ -107,9 +108,13 @@ _ERR = {-1: 'PG_E_ARG (bad dimension / null pointer)', -2: 'PG_E_ALIGN (channel 
         -3: 'PG_E_UNSUP (unsupported configuration)'}
 
 
+class Unsupported(RuntimeError):
+    """PG_E_UNSUP: the entry point does not take this configuration (callers with a fallback catch exactly this)."""
+
+
 def check(rc, name):
     if rc != 0:
-        raise RuntimeError('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
+        raise (Unsupported if rc == -3 else RuntimeError)('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
 
 
 def call(name, *args):

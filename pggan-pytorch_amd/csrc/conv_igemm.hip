@@ -61,7 +61,19 @@ struct ConvP {
     // fused adjoint of (LeakyReLU -> PixelNorm) applied to the conv result g (pg_conv2d_pnbwd_nhwc):
     //   y = r[pix] * (g - pnb_y * mean_c(g * pnb_y)) * lrelu'(pnb_y)
     const float* pnb_y; const float* pnb_r;
+    // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES): one byte per float4, bit j = (channel 4q+j > 0)
+    int mask_bytes, y_bytes;
 };
+
+// LeakyReLU' factors of four channels from a sign byte / the sign byte of four activated outputs
+__device__ __forceinline__ float4 pg_sign_factors(unsigned char b, float slope)
+{
+    return make_float4((b & 1) ? 1.f : slope, (b & 2) ? 1.f : slope, (b & 4) ? 1.f : slope, (b & 8) ? 1.f : slope);
+}
+__device__ __forceinline__ unsigned char pg_sign_byte(float4 o)
+{
+    return (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+}
 
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
 //   VEC=4 (ds_read_b128, 4x16 lanes, 64 banks): 24   VEC=2 (ds_read_b64): 12   VEC=1: 8
@@ -342,9 +354,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
                 continue;
             }
             if (p.mask) {
-                const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
-                o.x *= mk.x > 0.f ? 1.f : p.mask_slope; o.y *= mk.y > 0.f ? 1.f : p.mask_slope;
-                o.z *= mk.z > 0.f ? 1.f : p.mask_slope; o.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+                float4 f;
+                if (p.mask_bytes) f = pg_sign_factors(reinterpret_cast<const unsigned char*>(p.mask)[off >> 2], p.mask_slope);
+                else {
+                    const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
+                    f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
+                                    mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
+                }
+                o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
             } else {
                 o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
                 o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
@@ -359,15 +376,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
                     const size_t uo = ubase + ((size_t)(d >> 1) * W2 + (d & 1)) * p.Cout;
                     float4 v = make_float4(o.x * k, o.y * k, o.z * k, o.w * k);
                     if (p.upmask) {
-                        const float4 mk = *reinterpret_cast<const float4*>(p.upmask + uo);
-                        v.x *= mk.x > 0.f ? 1.f : p.mask_slope; v.y *= mk.y > 0.f ? 1.f : p.mask_slope;
-                        v.z *= mk.z > 0.f ? 1.f : p.mask_slope; v.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+                        float4 f;
+                        if (p.mask_bytes) f = pg_sign_factors(reinterpret_cast<const unsigned char*>(p.upmask)[uo >> 2], p.mask_slope);
+                        else {
+                            const float4 mk = *reinterpret_cast<const float4*>(p.upmask + uo);
+                            f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
+                                            mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
+                        }
+                        v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
                     }
                     *reinterpret_cast<float4*>(p.yup + uo) = v;
                 }
                 continue;
             }
-            if (!(pooling && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
+            if (p.y_bytes) reinterpret_cast<unsigned char*>(p.y)[off >> 2] = pg_sign_byte(o);     // only the sign is kept (pooled output below)
+            else if (!(pooling && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
             ov[n] = o;
         }
         if (pooling) {
@@ -1169,7 +1192,7 @@ int launch_conv(ConvP& p, hipStream_t s)
         const int cper = (nchunks + ksplit - 1) / ksplit;
         ksplit = (nchunks + cper - 1) / cper;
     }
-    if (ksplit > 1 && (p.yup || p.pn_r || p.pnb_y)) return PG_E_UNSUP;      // the unpool / PixelNorm epilogues need complete sums
+    if (ksplit > 1 && (p.yup || p.pn_r || p.pnb_y || p.mask_bytes || p.y_bytes)) return PG_E_UNSUP;   // these epilogues need complete sums
     if ((p.pn_r || p.pnb_y) && (WAVES_CO != 1 || ncob != 1)) return PG_E_UNSUP;  // ... and every cout of a pixel inside one wave
     p.ksplit = ksplit;
     const size_t npix = (size_t)p.N * p.Hout * p.Wout;
@@ -1775,7 +1798,10 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
 {
     if (!x || !w || !y || N <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
     if ((Cin & 3) || (Cout & 3)) return PG_E_ALIGN;
+    const int flags = ups;                                  // PG_FLAG_*: bit 0 = nearest x2 upsample of x
+    ups = flags & PG_FLAG_UPSAMPLE;
     ConvP p;
+    p.mask_bytes = (flags & PG_FLAG_MASK_BYTES) ? 1 : 0; p.y_bytes = (flags & PG_FLAG_Y_BYTES) ? 1 : 0;
     p.x = x; p.w = w; p.bias = bias; p.mask = mask; p.y = y;
     p.N = N; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout; p.KS = KS; p.pad = pad; p.ups = ups;
     p.Hout = Hin + 2 * pad - KS + 1; p.Wout = Win + 2 * pad - KS + 1;
@@ -1796,6 +1822,14 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     p.pn_r = nullptr; p.pn_eps = pn_eps; p.pnb_y = nullptr; p.pnb_r = pnb_r;
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    if (p.mask_bytes || p.y_bytes) {
+        // sign-byte activations exist in the fused epilogues of the generic tile kernel only (no split-K, no second pass):
+        // PG_E_UNSUP tells the caller to redo the layer with fp32 masks
+        if (KS != 3 || (p.y_bytes && !ypool) || pn_r || pnb_y) return PG_E_UNSUP;
+        p.ypool = ypool;
+        p.yup = yup;
+        return dispatch_conv_generic_nosplit(p, s);
+    }
     if (pnb_y && pnb_r && KS == 3 && Cout <= 32 && g_tune[3] != 12) {
         p.pnb_y = pnb_y;
         const bool thin_pn = pad == 1 && Cout == 8 && (Cin == 8 || Cin == 16) && (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
@@ -1878,11 +1912,11 @@ extern "C" int pg_conv2d_pnbwd_nhwc(const float* x, const float* w, const float*
 }
 
 extern "C" int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, float* y, float* yup,
-                                     int N, int Hin, int Win, int Cin, int Cout, int KS, int pad,
+                                     int N, int Hin, int Win, int Cin, int Cout, int KS, int pad, int flags,
                                      float scale, float up_mul, float mask_slope, pg_stream_t stream)
 {
     if (!yup) return PG_E_ARG;
-    return conv2d_impl(x, w, nullptr, nullptr, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, 0,
+    return conv2d_impl(x, w, nullptr, nullptr, y, nullptr, nullptr, 1.f, 0.f, 0, N, Hin, Win, Cin, Cout, KS, pad, flags & PG_FLAG_MASK_BYTES,
                        scale, 1.0f, mask_slope, stream, yup, upmask, up_mul);
 }
 

@@ -32,10 +32,16 @@ struct WinoP {
     // fused epilogues (same semantics as the direct kernel, see pggan_hip.h)
     float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
     float* yup; const float* upmask; float up_mul;
+    int mask_bytes, y_bytes;                   // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES, pggan_hip.h)
 };
 
 template <int VEC> struct WRow { static constexpr int value = VEC == 4 ? 24 : 12; };   // LDS row stride (floats), conflict-free b128 / b64
 constexpr int XMAX = 400;                      // halo pixels per workgroup: 18x18 (8x8 tiles) .. 4 x 10x10 (8x8 images)
+
+__device__ __forceinline__ float4 sign_factors(unsigned char b, float slope)
+{
+    return make_float4((b & 1) ? 1.f : slope, (b & 2) ? 1.f : slope, (b & 4) ? 1.f : slope, (b & 8) ? 1.f : slope);
+}
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -220,9 +226,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         const size_t off = (((size_t)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1)) * p.Cout + cb;
         float4 o = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
         if (p.mask) {
-            const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
-            o.x *= mk.x > 0.f ? 1.f : p.mask_slope; o.y *= mk.y > 0.f ? 1.f : p.mask_slope;
-            o.z *= mk.z > 0.f ? 1.f : p.mask_slope; o.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+            float4 f;
+            if (p.mask_bytes) f = sign_factors(reinterpret_cast<const unsigned char*>(p.mask)[off >> 2], p.mask_slope);
+            else {
+                const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
+                f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
+                                mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
+            }
+            o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
         } else {
             o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
             o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
@@ -238,12 +249,20 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
                 const size_t uo = ubase + ((size_t)(dd >> 1) * W2 + (dd & 1)) * p.Cout;
                 float4 w4 = make_float4(o.x * k, o.y * k, o.z * k, o.w * k);
                 if (p.upmask) {
-                    const float4 mk = *reinterpret_cast<const float4*>(p.upmask + uo);
-                    w4.x *= mk.x > 0.f ? 1.f : p.mask_slope; w4.y *= mk.y > 0.f ? 1.f : p.mask_slope;
-                    w4.z *= mk.z > 0.f ? 1.f : p.mask_slope; w4.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+                    float4 f;
+                    if (p.mask_bytes) f = sign_factors(reinterpret_cast<const unsigned char*>(p.upmask)[uo >> 2], p.mask_slope);
+                    else {
+                        const float4 mk = *reinterpret_cast<const float4*>(p.upmask + uo);
+                        f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
+                                        mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
+                    }
+                    w4.x *= f.x; w4.y *= f.y; w4.z *= f.z; w4.w *= f.w;
                 }
                 *reinterpret_cast<float4*>(p.yup + uo) = w4;
             }
+        } else if (p.y_bytes) {                                  // only the sign is kept (the pooled output follows)
+            reinterpret_cast<unsigned char*>(p.y)[off >> 2] =
+                (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
         } else if (!(p.ypool && p.pool_only)) {
             *reinterpret_cast<float4*>(p.y + off) = o;
         }
@@ -354,7 +373,11 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
         return PG_E_UNSUP;
     WinoP p;
     p.x = x; p.u = u; p.bias = bias; p.mask = mask; p.y = y;
+    const int flags = ups;                                  // PG_FLAG_* (pggan_hip.h)
+    ups = flags & PG_FLAG_UPSAMPLE;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups;
+    p.mask_bytes = (flags & PG_FLAG_MASK_BYTES) ? 1 : 0; p.y_bytes = (flags & PG_FLAG_Y_BYTES) ? 1 : 0;
+    if (p.y_bytes && !ypool) return PG_E_UNSUP;
     p.scale = scale; p.slope = slope; p.mask_slope = mask_slope;
     p.ypool = ypool; p.pool_other = pool_other; p.pool_a = pool_a; p.pool_b = pool_b; p.pool_only = pool_only;
     p.yup = yup; p.upmask = upmask; p.up_mul = up_mul;

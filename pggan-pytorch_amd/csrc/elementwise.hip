@@ -600,7 +600,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__); \
     return (int)hipGetLastError()
 
-extern "C" int pg_abi_version(void) { return 14; }
+namespace {
+__global__ __launch_bounds__(256) void signbytes_to_mask_kernel(const unsigned char* __restrict__ b, float* __restrict__ m, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned char v = b[i];
+        reinterpret_cast<float4*>(m)[i] = make_float4((v & 1) ? 1.f : -1.f, (v & 2) ? 1.f : -1.f, (v & 4) ? 1.f : -1.f, (v & 8) ? 1.f : -1.f);
+    }
+}
+}  // namespace
+
+extern "C" int pg_signbytes_to_mask(const unsigned char* bytes, float* mask, int64_t nbytes, pg_stream_t stream)
+{
+    if (!bytes || !mask || nbytes <= 0) return PG_E_ARG;
+    size_t g = ((size_t)nbytes + 255) / 256; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(signbytes_to_mask_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, bytes, mask, (size_t)nbytes);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_abi_version(void) { return 15; }
 
 extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
                                float a, float b, pg_stream_t stream)

@@ -43,6 +43,11 @@ WINO_MIN_WORKGROUPS = int(_os.environ.get('PGGAN_WINO_MIN_WG', '256'))
 WINO_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_MIN_C', '32'))
 USE_WINOGRAD_WGRAD = USE_WINOGRAD and _os.environ.get('PGGAN_WINOGRAD_WGRAD', '1') != '0'
 WINO_WGRAD_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_WGRAD_MIN_C', '16'))
+# The c2 output of a DBlock is pooled at once (network.py:229,238); at full resolution only its SIGN is ever used again
+# (LeakyReLU' in the backward / tangent sweeps), so from 64x64 up it is kept as sign bytes (1 byte per 4 channels)
+# instead of fp32: the fp32 write and its re-reads are the largest avoidable HBM traffic of the high-resolution stages.
+USE_SIGN_BYTES = _os.environ.get('PGGAN_SIGN_BYTES', '1') != '0'
+SIGN_BYTES_MIN_H = int(_os.environ.get('PGGAN_SIGN_BYTES_MIN_H', '64'))
 
 
 def _derived(net):
@@ -97,16 +102,29 @@ def _conv(x, layer, N, H, act=True, mask=None, bias=True, ups=False, out=None):
                       mask=mask, mask_slope=layer.slope, ups=ups, out=out)
 
 
-def _conv_pool(x, layer, N, H, bias=True, mask=None, other=None, a=1.0, b=0.0, pool_only=False):
-    """conv (+bias+act | mask) followed by the 2x2 average pool / fade-in blend, one launch."""
-    u = _wino(layer, N, H, layer.conv.weight.shape[2])
-    if u is not None:
-        return ops.conv2d_wino(x, u, layer.conv.bias.data if bias else None, N, H, H, layer.c,
-                               layer.slope if mask is None else 1.0, mask=mask, mask_slope=layer.slope,
-                               pool=True, other=other, a=a, b=b, pool_only=pool_only)
-    return ops.conv2d_pool(x, layer.conv.weight.data, layer.conv.bias.data if bias else None, N, H, H, layer.ksize, layer.pad,
-                           layer.c, layer.slope if mask is None else 1.0, mask=mask, mask_slope=layer.slope,
-                           other=other, a=a, b=b, pool_only=pool_only)
+def _mask32(m):
+    """fp32 view of a LeakyReLU' mask that may be stored as sign bytes (paths without a byte-aware kernel)."""
+    return ops.signbytes_to_mask(m) if m is not None and m.dtype == torch.uint8 else m
+
+
+def _conv_pool(x, layer, N, H, bias=True, mask=None, other=None, a=1.0, b=0.0, pool_only=False, y_bytes=False):
+    """conv (+bias+act | mask) followed by the 2x2 average pool / fade-in blend, one launch.  ``y_bytes``: the
+    full-resolution output is returned as sign bytes (falls back to fp32 when the launch cannot fuse)."""
+    def run(mask, y_bytes):
+        u = _wino(layer, N, H, layer.conv.weight.shape[2])
+        if u is not None:
+            return ops.conv2d_wino(x, u, layer.conv.bias.data if bias else None, N, H, H, layer.c,
+                                   layer.slope if mask is None else 1.0, mask=mask, mask_slope=layer.slope,
+                                   pool=True, other=other, a=a, b=b, pool_only=pool_only, y_bytes=y_bytes)
+        return ops.conv2d_pool(x, layer.conv.weight.data, layer.conv.bias.data if bias else None, N, H, H, layer.ksize, layer.pad,
+                               layer.c, layer.slope if mask is None else 1.0, mask=mask, mask_slope=layer.slope,
+                               other=other, a=a, b=b, pool_only=pool_only, y_bytes=y_bytes)
+    if y_bytes or (mask is not None and mask.dtype == torch.uint8):
+        try:
+            return run(mask, y_bytes)
+        except ops.Unsupported:
+            return run(_mask32(mask), False)
+    return run(mask, False)
 
 
 def _dgrad(net, gz, layer, N, Hout, mask=None, mask_slope=0.2):
@@ -132,8 +150,14 @@ def _dgrad_unpool(net, gz, layer, N, H, upmask, mul, mask_slope):
     u = _wino(layer, N, H, layer.conv.weight.shape[3], transposed=True)
     if u is not None:
         return ops.conv2d_wino(gz, u, None, N, H, H, layer.c, 1.0, mask_slope=mask_slope, unpool=True, upmask=upmask, up_mul=mul)
-    return ops.conv2d_unpool(gz, _wt(net, layer), N, H, H, layer.ksize, layer.ksize - 1 - layer.pad, layer.c,
-                             upmask=upmask, mul=mul, mask_slope=mask_slope)
+    try:
+        return ops.conv2d_unpool(gz, _wt(net, layer), N, H, H, layer.ksize, layer.ksize - 1 - layer.pad, layer.c,
+                                 upmask=upmask, mul=mul, mask_slope=mask_slope)
+    except ops.Unsupported:
+        if upmask is None or upmask.dtype != torch.uint8:
+            raise
+        return ops.conv2d_unpool(gz, _wt(net, layer), N, H, H, layer.ksize, layer.ksize - 1 - layer.pad, layer.c,
+                                 upmask=_mask32(upmask), mul=mul, mask_slope=mask_slope)
 
 
 def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
@@ -399,7 +423,7 @@ def d_forward(D, x, groups=1):
                 a2, rec['r2'] = ops.pixelnorm_fwd(a2, inplace=True)
                 cur = ops.avgpool2_fwd(a2, pf, pa, pb)                        # :229,238
             else:                                                             # pool (+ fade-in blend) in the conv epilogue
-                a2, cur = _conv_pool(a1, blk.c2, NB, H, other=pf, a=pa, b=pb)
+                a2, cur = _conv_pool(a1, blk.c2, NB, H, other=pf, a=pa, b=pb, y_bytes=USE_SIGN_BYTES and H >= SIGN_BYTES_MIN_H)
             rec.update(a1=a1, a2=a2)
             H //= 2
         ctx['recs'].append(rec)
@@ -513,7 +537,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             prev = recs[idx - 1]
             pc2 = prev['blk'].c2
             if prev['first'] and alpha < 1.0:
-                g = ops.avgpool2_bwd(gin, prev['a2'], alpha, pc2.slope)
+                g = ops.avgpool2_bwd(gin, _mask32(prev['a2']), alpha, pc2.slope)
                 pfr = blk.fromRGB                                             # the block whose fromRGB fed the fade-in
                 gpf = ops.axpby_mask(gin, mask=prev['pf'], a=1.0 - alpha, mask_slope=pfr.slope)
                 if save_adjoints:
@@ -525,7 +549,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             elif not rec['last'] and g_fused is not None:
                 g = g_fused
             else:
-                g = ops.avgpool2_bwd(gin, prev['a2'], 1.0, pc2.slope)
+                g = ops.avgpool2_bwd(gin, _mask32(prev['a2']), 1.0, pc2.slope)
     return gimg, adj
 
 

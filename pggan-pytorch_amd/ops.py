@@ -19,8 +19,8 @@ def _p(t):
     """Device pointer of a checked tensor (None -> NULL)."""
     if t is None:
         return None
-    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
-        raise ValueError('expected a contiguous fp32 device tensor, got %s %s contiguous=%s on %s'
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.uint8) or not t.is_contiguous():
+        raise ValueError('expected a contiguous fp32 (or sign-byte uint8) device tensor, got %s %s contiguous=%s on %s'
                          % (tuple(t.shape), t.dtype, t.is_contiguous(), t.device))
     return t.data_ptr()
 
@@ -67,15 +67,35 @@ def wino_transform_weights_batched(flat_w, flat_u, layers):
               ctypes.cast(uoff, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), ctypes.cast(ci, ctypes.c_void_p), _stream())
 
 
+FLAG_UPSAMPLE, FLAG_MASK_BYTES, FLAG_Y_BYTES = 1, 2, 4           # PG_FLAG_* of include/pggan_hip.h
+Unsupported = _lib.Unsupported
+
+
+def _is_bytes(t):
+    return t is not None and t.dtype == torch.uint8
+
+
+def signbytes_to_mask(b):
+    """uint8 sign bytes [..., C/4] -> fp32 +1/-1 mask [..., C] (fallback when an entry point does not take sign bytes)."""
+    m = torch.empty(tuple(b.shape[:-1]) + (4 * b.shape[-1],), device=b.device, dtype=torch.float32)
+    _lib.call('pg_signbytes_to_mask', _p(b), _p(m), b.numel(), _stream())
+    return m
+
+
 def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None,
-                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0):
-    """3x3 pad-1 conv on Winograd-domain weights (+ the fused pool / unpool epilogues).  Returns y, (y, ypool) or yup."""
+                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0, y_bytes=False):
+    """3x3 pad-1 conv on Winograd-domain weights (+ the fused pool / unpool epilogues).  Returns y, (y, ypool) or yup.
+    uint8 ``mask`` / ``upmask`` are sign bytes; ``y_bytes`` (with ``pool``) returns the sign bytes of y instead of y."""
     cout, cin = u.shape[1], u.shape[2]
-    y = out if out is not None else torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    flags = (FLAG_UPSAMPLE if ups else 0) | (FLAG_MASK_BYTES if _is_bytes(mask) or _is_bytes(upmask) else 0) | (FLAG_Y_BYTES if y_bytes else 0)
+    if y_bytes:
+        y = torch.empty((N, H, W, cout // 4), device=x.device, dtype=torch.uint8)
+    else:
+        y = out if out is not None else torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
     yp = torch.empty((N, H // 2, W // 2, cout), device=x.device, dtype=torch.float32) if pool else None
     yu = torch.empty((N, 2 * H, 2 * W, cout), device=x.device, dtype=torch.float32) if unpool else None
     _lib.call('pg_conv2d_wino_nhwc', _p(x), _p(u), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
-              _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, 1 if ups else 0, scale, slope, mask_slope, _stream())
+              _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, flags, scale, slope, mask_slope, _stream())
     if pool:
         return y, yp
     if unpool:
@@ -84,15 +104,21 @@ def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2
 
 
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
-                pool_only=False):
+                pool_only=False, y_bytes=False):
     """conv2d with the following 2x2 average pool (+ fade-in blend a*pool + b*other) fused into the epilogue.
-    Returns (y, ypool); with ``pool_only`` the full-resolution y may be left unwritten (do not read it)."""
+    Returns (y, ypool); with ``pool_only`` the full-resolution y may be left unwritten (do not read it).  A uint8
+    ``mask`` holds sign bytes; ``y_bytes`` returns the sign bytes of y instead of y (raises ops.Unsupported when the
+    launch cannot fuse -- redo with fp32)."""
     cout, cin = w.shape[2], w.shape[3]
     ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
-    y = torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
+    flags = (FLAG_MASK_BYTES if _is_bytes(mask) else 0) | (FLAG_Y_BYTES if y_bytes else 0)
+    if y_bytes:
+        y = torch.empty((N, ho, wo, cout // 4), device=x.device, dtype=torch.uint8)
+    else:
+        y = torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
     yp = torch.empty((N, ho // 2, wo // 2, cout), device=x.device, dtype=torch.float32)
     _lib.call('pg_conv2d_pool_nhwc', _p(x), _p(w), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
-              N, Hin, Win, cin, cout, ks, pad, 0, scale, slope, mask_slope, _stream())
+              N, Hin, Win, cin, cout, ks, pad, flags, scale, slope, mask_slope, _stream())
     return y, yp
 
 
@@ -124,7 +150,7 @@ def conv2d_unpool(x, w, N, Hin, Win, ks, pad, scale, upmask=None, mul=1.0, mask_
     y = torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)          # scratch (unfused fallback)
     yup = torch.empty((N, 2 * ho, 2 * wo, cout), device=x.device, dtype=torch.float32)
     _lib.call('pg_conv2d_unpool_nhwc', _p(x), _p(w), _p(upmask), _p(y), _p(yup), N, Hin, Win, cin, cout, ks, pad,
-              scale, mul, mask_slope, _stream())
+              FLAG_MASK_BYTES if _is_bytes(upmask) else 0, scale, mul, mask_slope, _stream())
     return yup
 
 

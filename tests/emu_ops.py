@@ -29,7 +29,24 @@ def _ret(y, out):
     return y
 
 
+class Unsupported(RuntimeError):
+    pass
+
+
+def signbytes_of(y):
+    """fp32 [..., C] -> uint8 sign bytes [..., C/4] (bit j of a byte = channel 4q+j > 0): the product's format."""
+    b = (y > 0).to(torch.uint8).reshape(tuple(y.shape[:-1]) + (y.shape[-1] // 4, 4))
+    return (b[..., 0] | (b[..., 1] << 1) | (b[..., 2] << 2) | (b[..., 3] << 3)).contiguous()
+
+
+def signbytes_to_mask(b):
+    bits = torch.stack([(b >> j) & 1 for j in range(4)], dim=-1).reshape(tuple(b.shape[:-1]) + (4 * b.shape[-1],))
+    return bits.to(torch.float32) * 2 - 1
+
+
 def _maskmul(v, mask, slope):
+    if mask.dtype == torch.uint8:
+        mask = signbytes_to_mask(mask)
     return v * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, slope))
 
 
@@ -99,23 +116,23 @@ def _unwino(u):
 
 
 def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None,
-                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0):
+                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0, y_bytes=False):
     w = _unwino(u)
     y = conv2d(x, w, bias, N, H, W, 3, 1, scale, slope=slope, mask=mask, mask_slope=mask_slope, ups=ups)
     if out is not None:
         out.copy_(y)
         y = out
     if pool:
-        return y, avgpool2_fwd(y, other, a, b)
+        return (signbytes_of(y) if y_bytes else y), avgpool2_fwd(y, other, a, b)
     if unpool:
         return avgpool2_bwd(y, upmask, up_mul, mask_slope)
     return y
 
 
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
-                pool_only=False):
+                pool_only=False, y_bytes=False):
     y = conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=slope, mask=mask, mask_slope=mask_slope)
-    return y, avgpool2_fwd(y, other, a, b)
+    return (signbytes_of(y) if y_bytes else y), avgpool2_fwd(y, other, a, b)
 
 
 def conv2d_pixelnorm(x, w, bias, N, Hin, Win, ks, pad, scale, slope, eps=1e-8, ups=False):

@@ -135,3 +135,22 @@ def test_conv2d_wgrad_wino_rejects_small_maps():
     x, gz = torch.zeros(2, 8, 8, 32, device='cuda'), torch.zeros(2, 8, 8, 32, device='cuda')
     with pytest.raises(RuntimeError):
         ops.conv2d_wgrad_wino(x, gz, torch.zeros(3, 3, 32, 32, device='cuda'), None, 2, 8, 8, 1.0)
+
+
+@pytest.mark.parametrize('depth,alpha,n', [(2, 1.0, 2), (3, 0.6, 2)])
+def test_engine_with_sign_bytes_host(emu, monkeypatch, depth, alpha, n):
+    """DBlock c2 activations kept as sign bytes (engine.USE_SIGN_BYTES) from 8x8 up: host emulation vs the oracle."""
+    monkeypatch.setattr(pg.engine, 'SIGN_BYTES_MIN_H', 8)
+    monkeypatch.setattr(pg.engine, 'USE_SIGN_BYTES', True)
+    _engine_vs_oracle('cpu', monkeypatch, 32, depth, alpha, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('depth,alpha,n,wino', [(3, 1.0, 3, True), (4, 0.6, 2, True), (4, 1.0, 2, False)])
+def test_engine_with_sign_bytes_gpu(monkeypatch, depth, alpha, n, wino):
+    """Same on the GPU with the byte format forced down to 8x8 maps (Winograd and direct kernels)."""
+    monkeypatch.setattr(pg.engine, 'SIGN_BYTES_MIN_H', 8)
+    monkeypatch.setattr(pg.engine, 'USE_SIGN_BYTES', True)
+    if not wino:
+        monkeypatch.setattr(pg.engine, 'USE_WINOGRAD', False)
+    _engine_vs_oracle('cuda', monkeypatch, 64, depth, alpha, n)
