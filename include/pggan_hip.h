@@ -101,11 +101,15 @@ int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, f
  *   PG_FLAG_UPSAMPLE    bit 0: nearest x2 upsample of x fused into the gather (the historic meaning of `ups`)
  *   PG_FLAG_MASK_BYTES  `mask` / `upmask` point to sign bytes: uint8 [N][H][W][C/4], bit j of a byte = (channel 4q+j > 0)
  *   PG_FLAG_Y_BYTES     `y` points to such a byte array and receives the signs of the activated output (needs ypool)
+ *   PG_FLAG_SIGNS_OUT   forward mode (no mask): the otherwise unused `mask` argument points to a byte array that receives the
+ *                       signs of y IN ADDITION to the fp32 y (activations that stay in fp32 for the weight gradients but
+ *                       are re-read as LeakyReLU' masks: DBlock c1 and fromRGB outputs).  Also `pool` of pg_fromrgb_fwd.
  * Only the fused epilogues of the tile kernels know the format: PG_E_UNSUP means "redo this launch with fp32 masks"
  * (pg_signbytes_to_mask expands a byte array to a +1 / -1 fp32 mask for that case).                              */
 #define PG_FLAG_UPSAMPLE   1
 #define PG_FLAG_MASK_BYTES 2
 #define PG_FLAG_Y_BYTES    4
+#define PG_FLAG_SIGNS_OUT  8
 int pg_signbytes_to_mask(const unsigned char* bytes, float* mask, int64_t nbytes, pg_stream_t stream);
 
 /* Winograd F(2x2,3x3) path for the wide 3x3 layers (pad 1; Cin % 16 == 0; H, W powers of two >= 8): 2.25x fewer MFMAs

@@ -63,6 +63,7 @@ struct ConvP {
     const float* pnb_y; const float* pnb_r;
     // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES): one byte per float4, bit j = (channel 4q+j > 0)
     int mask_bytes, y_bytes;
+    unsigned char* ysigns;      // PG_FLAG_SIGNS_OUT: the sign bytes of y are written here IN ADDITION to y (forward mode)
 };
 
 // LeakyReLU' factors of four channels from a sign byte / the sign byte of four activated outputs
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
             }
             if (p.y_bytes) reinterpret_cast<unsigned char*>(p.y)[off >> 2] = pg_sign_byte(o);     // only the sign is kept (pooled output below)
             else if (!(pooling && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
+            if (p.ysigns) p.ysigns[off >> 2] = pg_sign_byte(o);
             ov[n] = o;
         }
         if (pooling) {
@@ -961,13 +963,19 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
         const size_t off = (((size_t)n * p.Hout + oy) * p.Wout + ox) * COUT + 4 * qo;
         float4 o = make_float4(acc[g][0] * p.scale, acc[g][1] * p.scale, acc[g][2] * p.scale, acc[g][3] * p.scale);
         if (p.mask) {
-            const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
-            o.x *= mk.x > 0.f ? 1.f : p.mask_slope; o.y *= mk.y > 0.f ? 1.f : p.mask_slope;
-            o.z *= mk.z > 0.f ? 1.f : p.mask_slope; o.w *= mk.w > 0.f ? 1.f : p.mask_slope;
+            float4 f;
+            if (p.mask_bytes) f = pg_sign_factors(reinterpret_cast<const unsigned char*>(p.mask)[off >> 2], p.mask_slope);
+            else {
+                const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
+                f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
+                                mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
+            }
+            o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
         } else {
             o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
             o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
             o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+            if (p.ysigns) p.ysigns[off >> 2] = pg_sign_byte(o);
         }
         if (p.pnb_y) {                               // adjoint of the previous layer's (LeakyReLU -> PixelNorm), see ConvP
             const float4 yv = *reinterpret_cast<const float4*>(p.pnb_y + off);
@@ -1192,7 +1200,7 @@ int launch_conv(ConvP& p, hipStream_t s)
         const int cper = (nchunks + ksplit - 1) / ksplit;
         ksplit = (nchunks + cper - 1) / cper;
     }
-    if (ksplit > 1 && (p.yup || p.pn_r || p.pnb_y || p.mask_bytes || p.y_bytes)) return PG_E_UNSUP;   // these epilogues need complete sums
+    if (ksplit > 1 && (p.yup || p.pn_r || p.pnb_y || p.mask_bytes || p.y_bytes || p.ysigns)) return PG_E_UNSUP;   // these epilogues need complete sums
     if ((p.pn_r || p.pnb_y) && (WAVES_CO != 1 || ncob != 1)) return PG_E_UNSUP;  // ... and every cout of a pixel inside one wave
     p.ksplit = ksplit;
     const size_t npix = (size_t)p.N * p.Hout * p.Wout;
@@ -1802,6 +1810,12 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     ups = flags & PG_FLAG_UPSAMPLE;
     ConvP p;
     p.mask_bytes = (flags & PG_FLAG_MASK_BYTES) ? 1 : 0; p.y_bytes = (flags & PG_FLAG_Y_BYTES) ? 1 : 0;
+    p.ysigns = nullptr;
+    if (flags & PG_FLAG_SIGNS_OUT) {                        // forward mode: the (otherwise unused) mask argument is the byte output
+        if (!mask || p.mask_bytes) return PG_E_ARG;
+        p.ysigns = reinterpret_cast<unsigned char*>(const_cast<float*>(mask));
+        mask = nullptr;
+    }
     p.x = x; p.w = w; p.bias = bias; p.mask = mask; p.y = y;
     p.N = N; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout; p.KS = KS; p.pad = pad; p.ups = ups;
     p.Hout = Hin + 2 * pad - KS + 1; p.Wout = Win + 2 * pad - KS + 1;
@@ -1822,12 +1836,15 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     p.pn_r = nullptr; p.pn_eps = pn_eps; p.pnb_y = nullptr; p.pnb_r = pnb_r;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (p.mask_bytes || p.y_bytes) {
-        // sign-byte activations exist in the fused epilogues of the generic tile kernel only (no split-K, no second pass):
-        // PG_E_UNSUP tells the caller to redo the layer with fp32 masks
+    if (p.mask_bytes || p.y_bytes || p.ysigns) {
+        // sign-byte activations exist in the epilogues of the generic tile kernel (no split-K, no second pass) and of the
+        // 8-cout block-MFMA kernel only: PG_E_UNSUP tells the caller to redo the layer with fp32 masks
         if (KS != 3 || (p.y_bytes && !ypool) || pn_r || pnb_y) return PG_E_UNSUP;
         p.ypool = ypool;
         p.yup = yup;
+        const bool thin_b = pad == 1 && !p.y_bytes && !yup && !ypool && ((Cout == 8 && (Cin == 8 || Cin == 16)) || (Cout == 16 && Cin == 8 && mask)) &&
+                            (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
+        if (thin_b) return dispatch_thin(p, s);
         return dispatch_conv_generic_nosplit(p, s);
     }
     if (pnb_y && pnb_r && KS == 3 && Cout <= 32 && g_tune[3] != 12) {

@@ -33,6 +33,7 @@ struct WinoP {
     float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
     float* yup; const float* upmask; float up_mul;
     int mask_bytes, y_bytes;                   // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES, pggan_hip.h)
+    unsigned char* ysigns;                     // PG_FLAG_SIGNS_OUT
 };
 
 template <int VEC> struct WRow { static constexpr int value = VEC == 4 ? 24 : 12; };   // LDS row stride (floats), conflict-free b128 / b64
@@ -266,6 +267,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         } else if (!(p.ypool && p.pool_only)) {
             *reinterpret_cast<float4*>(p.y + off) = o;
         }
+        if (p.ysigns)
+            p.ysigns[off >> 2] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
     }
     if (p.ypool) {                                           // the 2x2 outputs of a tile ARE one pooled pixel
         float4 v;
@@ -378,6 +381,12 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups;
     p.mask_bytes = (flags & PG_FLAG_MASK_BYTES) ? 1 : 0; p.y_bytes = (flags & PG_FLAG_Y_BYTES) ? 1 : 0;
     if (p.y_bytes && !ypool) return PG_E_UNSUP;
+    p.ysigns = nullptr;
+    if (flags & PG_FLAG_SIGNS_OUT) {
+        if (!mask || p.mask_bytes || yup) return PG_E_ARG;
+        p.ysigns = reinterpret_cast<unsigned char*>(const_cast<float*>(mask));
+        p.mask = nullptr;
+    }
     p.scale = scale; p.slope = slope; p.mask_slope = mask_slope;
     p.ypool = ypool; p.pool_other = pool_other; p.pool_a = pool_a; p.pool_b = pool_b; p.pool_only = pool_only;
     p.yup = yup; p.upmask = upmask; p.up_mul = up_mul;

@@ -22,7 +22,7 @@ __device__ __forceinline__ float img_fetch(const float* img, int n, int c, int h
 __global__ __launch_bounds__(256) void fromrgb_fwd_kernel(
     const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ mask, float* __restrict__ y,
-    int N, int C, int H, int W, int Cout, int pool, float scale, float slope, float mask_slope)
+    int N, int C, int H, int W, int Cout, int pool, float scale, float slope, float mask_slope, int mbytes, unsigned char* __restrict__ ysigns)
 {
     const int c4n = Cout >> 2;
     const size_t total = (size_t)N * H * W * c4n;
@@ -46,15 +46,22 @@ __global__ __launch_bounds__(256) void fromrgb_fwd_kernel(
         }
         const size_t off = pix * Cout + 4 * c4;
         if (mask) {
-            const float4 mk = *reinterpret_cast<const float4*>(mask + off);
-            o[0] *= mk.x > 0.f ? 1.f : mask_slope; o[1] *= mk.y > 0.f ? 1.f : mask_slope;
-            o[2] *= mk.z > 0.f ? 1.f : mask_slope; o[3] *= mk.w > 0.f ? 1.f : mask_slope;
+            if (mbytes) {
+                const unsigned char b = reinterpret_cast<const unsigned char*>(mask)[off >> 2];
+                o[0] *= (b & 1) ? 1.f : mask_slope; o[1] *= (b & 2) ? 1.f : mask_slope;
+                o[2] *= (b & 4) ? 1.f : mask_slope; o[3] *= (b & 8) ? 1.f : mask_slope;
+            } else {
+                const float4 mk = *reinterpret_cast<const float4*>(mask + off);
+                o[0] *= mk.x > 0.f ? 1.f : mask_slope; o[1] *= mk.y > 0.f ? 1.f : mask_slope;
+                o[2] *= mk.z > 0.f ? 1.f : mask_slope; o[3] *= mk.w > 0.f ? 1.f : mask_slope;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = o[j] + (bias ? bias[4 * c4 + j] : 0.f);
                 o[j] = v > 0.f ? v : v * slope;
             }
+            if (ysigns) ysigns[off >> 2] = (unsigned char)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
         }
         *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -67,7 +74,7 @@ template <int CO>
 __global__ __launch_bounds__(256) void fromrgb_fwd_pix_kernel(
     const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ mask, float* __restrict__ y,
-    int N, int C, int H, int W, int pool, float scale, float slope, float mask_slope)
+    int N, int C, int H, int W, int pool, float scale, float slope, float mask_slope, int mbytes, unsigned char* __restrict__ ysigns)
 {
     const unsigned total = (unsigned)N * H * W, HW = (unsigned)H * W;
     for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < total; pix += gridDim.x * 256u) {
@@ -89,15 +96,22 @@ __global__ __launch_bounds__(256) void fromrgb_fwd_pix_kernel(
                 o[j] = a * scale;
             }
             if (mask) {
-                const float4 mk = *reinterpret_cast<const float4*>(mask + off + 4 * c4);
-                o[0] *= mk.x > 0.f ? 1.f : mask_slope; o[1] *= mk.y > 0.f ? 1.f : mask_slope;
-                o[2] *= mk.z > 0.f ? 1.f : mask_slope; o[3] *= mk.w > 0.f ? 1.f : mask_slope;
+                if (mbytes) {
+                    const unsigned char b = reinterpret_cast<const unsigned char*>(mask)[(off >> 2) + c4];
+                    o[0] *= (b & 1) ? 1.f : mask_slope; o[1] *= (b & 2) ? 1.f : mask_slope;
+                    o[2] *= (b & 4) ? 1.f : mask_slope; o[3] *= (b & 8) ? 1.f : mask_slope;
+                } else {
+                    const float4 mk = *reinterpret_cast<const float4*>(mask + off + 4 * c4);
+                    o[0] *= mk.x > 0.f ? 1.f : mask_slope; o[1] *= mk.y > 0.f ? 1.f : mask_slope;
+                    o[2] *= mk.z > 0.f ? 1.f : mask_slope; o[3] *= mk.w > 0.f ? 1.f : mask_slope;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = o[j] + (bias ? bias[4 * c4 + j] : 0.f);
                     o[j] = v > 0.f ? v : v * slope;
                 }
+                if (ysigns) ysigns[(off >> 2) + c4] = (unsigned char)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
             }
             *reinterpret_cast<float4*>(y + off + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
         }
@@ -581,17 +595,26 @@ extern "C" int pg_fromrgb_fwd(const float* img, const float* w, const float* bia
     if (!img || !w || !y || N <= 0 || H <= 0 || W <= 0) return PG_E_ARG;
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cout & 3) return PG_E_ALIGN;
+    const int flags = pool;                                 // PG_FLAG_*: bit 0 = 2x2 pooled image (the historic `pool`)
+    pool = flags & 1;
+    const int mbytes = (flags & PG_FLAG_MASK_BYTES) ? 1 : 0;
+    unsigned char* ysigns = nullptr;
+    if (flags & PG_FLAG_SIGNS_OUT) {
+        if (!mask || mbytes) return PG_E_ARG;
+        ysigns = reinterpret_cast<unsigned char*>(const_cast<float*>(mask));
+        mask = nullptr;
+    }
     const size_t npix = (size_t)N * H * W;
     if (npix >= 65536 && npix < (1ull << 31) && (Cout == 8 || (Cout == 16 && !mask))) {       // measured: tools/bench_rgb_stream.py
         const int gr = grid_for(npix, 256, 256 * 16);
         hipStream_t s = (hipStream_t)stream;
-        if (Cout == 8) hipLaunchKernelGGL(fromrgb_fwd_pix_kernel<8>, dim3(gr), dim3(256), 0, s, img, w, bias, mask, y, N, C, H, W, pool, scale, slope, mask_slope);
-        else hipLaunchKernelGGL(fromrgb_fwd_pix_kernel<16>, dim3(gr), dim3(256), 0, s, img, w, bias, mask, y, N, C, H, W, pool, scale, slope, mask_slope);
+        if (Cout == 8) hipLaunchKernelGGL(fromrgb_fwd_pix_kernel<8>, dim3(gr), dim3(256), 0, s, img, w, bias, mask, y, N, C, H, W, pool, scale, slope, mask_slope, mbytes, ysigns);
+        else hipLaunchKernelGGL(fromrgb_fwd_pix_kernel<16>, dim3(gr), dim3(256), 0, s, img, w, bias, mask, y, N, C, H, W, pool, scale, slope, mask_slope, mbytes, ysigns);
         return (int)hipGetLastError();
     }
     const size_t total = npix * (Cout >> 2);
     hipLaunchKernelGGL(fromrgb_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       img, w, bias, mask, y, N, C, H, W, Cout, pool, scale, slope, mask_slope);
+                       img, w, bias, mask, y, N, C, H, W, Cout, pool, scale, slope, mask_slope, mbytes, ysigns);
     return (int)hipGetLastError();
 }
 

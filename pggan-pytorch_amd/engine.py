@@ -91,15 +91,32 @@ def _wino(layer, N, H, cout, transposed=False):
     return layer._wtu if transposed else layer._wu
 
 
-def _conv(x, layer, N, H, act=True, mask=None, bias=True, ups=False, out=None):
-    """Forward conv (+bias+act) or, with ``mask``, the masked linear map of the tangent pass."""
-    u = _wino(layer, N, H, layer.conv.weight.shape[2])
-    if u is not None:
-        return ops.conv2d_wino(x, u, layer.conv.bias.data if bias else None, N, H, H, layer.c,
-                               layer.slope if act else 1.0, mask=mask, mask_slope=layer.slope, ups=ups, out=out)
-    return ops.conv2d(x, layer.conv.weight.data, layer.conv.bias.data if bias else None, N, H, H,
-                      layer.ksize, layer.pad, layer.c, layer.slope if act else 1.0,
-                      mask=mask, mask_slope=layer.slope, ups=ups, out=out)
+def _conv(x, layer, N, H, act=True, mask=None, bias=True, ups=False, out=None, signs_out=False):
+    """Forward conv (+bias+act) or, with ``mask``, the masked linear map of the tangent pass.  ``signs_out``: returns
+    (y, sign bytes of y) -- (y, None) when the launch cannot produce them."""
+    def run(mask, signs_out):
+        u = _wino(layer, N, H, layer.conv.weight.shape[2])
+        if u is not None:
+            return ops.conv2d_wino(x, u, layer.conv.bias.data if bias else None, N, H, H, layer.c,
+                                   layer.slope if act else 1.0, mask=mask, mask_slope=layer.slope, ups=ups, out=out,
+                                   signs_out=signs_out)
+        return ops.conv2d(x, layer.conv.weight.data, layer.conv.bias.data if bias else None, N, H, H,
+                          layer.ksize, layer.pad, layer.c, layer.slope if act else 1.0,
+                          mask=mask, mask_slope=layer.slope, ups=ups, out=out, signs_out=signs_out)
+    if signs_out:
+        try:
+            return run(mask, True)
+        except ops.Unsupported:
+            return run(mask, False), None
+    if isinstance(mask, tuple):                    # (fp32 activation, its sign bytes or None): bytes first, fp32 as the fallback
+        m32, mb = mask
+        if mb is not None:
+            try:
+                return run(mb, False)
+            except ops.Unsupported:
+                pass
+        return run(m32, False)
+    return run(mask, False)
 
 
 def _mask32(m):
@@ -129,11 +146,21 @@ def _conv_pool(x, layer, N, H, bias=True, mask=None, other=None, a=1.0, b=0.0, p
 
 def _dgrad(net, gz, layer, N, Hout, mask=None, mask_slope=0.2):
     """Adjoint of the conv wrt its input: gz [N,Hout,Hout,Cout] -> [N,Hin,Hin,Cin_store] (* mask)."""
-    u = _wino(layer, N, Hout, layer.conv.weight.shape[3], transposed=True) if layer.ksize == 3 and layer.pad == 1 else None
-    if u is not None:
-        return ops.conv2d_wino(gz, u, None, N, Hout, Hout, layer.c, 1.0, mask=mask, mask_slope=mask_slope)
-    return ops.conv2d(gz, _wt(net, layer), None, N, Hout, Hout, layer.ksize, layer.ksize - 1 - layer.pad,
-                      layer.c, 1.0, mask=mask, mask_slope=mask_slope)
+    def run(mask):
+        u = _wino(layer, N, Hout, layer.conv.weight.shape[3], transposed=True) if layer.ksize == 3 and layer.pad == 1 else None
+        if u is not None:
+            return ops.conv2d_wino(gz, u, None, N, Hout, Hout, layer.c, 1.0, mask=mask, mask_slope=mask_slope)
+        return ops.conv2d(gz, _wt(net, layer), None, N, Hout, Hout, layer.ksize, layer.ksize - 1 - layer.pad,
+                          layer.c, 1.0, mask=mask, mask_slope=mask_slope)
+    if isinstance(mask, tuple):                    # (fp32 activation, its sign bytes or None)
+        m32, mb = mask
+        if mb is not None:
+            try:
+                return run(mb)
+            except ops.Unsupported:
+                pass
+        return run(m32)
+    return run(mask)
 
 
 def _dgrad_pool(net, gz, layer, N, H, other=None, a=1.0, b=0.0):
@@ -391,13 +418,20 @@ def d_forward(D, x, groups=1):
     ctx = dict(NB=NB, groups=groups, depth=depth, alpha=alpha, x=x, recs=[])
     pn = bool(getattr(D, 'pixelnorm', False))
     fr = D.blocks[e].fromRGB
-    cur = ops.fromrgb_fwd(x, fr.conv.weight.data, fr.conv.bias.data, NB, C, r, r, fr.c, fr.slope)
+    sb = USE_SIGN_BYTES and not pn                                            # byte copies of the fp32 activations (masks)
+    curb = None
+    if sb and r >= SIGN_BYTES_MIN_H:
+        cur, curb = ops.fromrgb_fwd(x, fr.conv.weight.data, fr.conv.bias.data, NB, C, r, r, fr.c, fr.slope, signs_out=True)
+    else:
+        cur = ops.fromrgb_fwd(x, fr.conv.weight.data, fr.conv.bias.data, NB, C, r, r, fr.c, fr.slope)
     H = r
     a2 = None
     for k, j in enumerate(range(e, nb)):
         blk = D.blocks[j]
         last = (j == nb - 1)
         rec = dict(blk=blk, inp=cur, H=H, first=(k == 0), last=last)
+        if k == 0 and curb is not None:
+            rec['inpb'] = curb
         if last:
             mb, stats = ops.mbstd_fwd(cur, groups, blk.c1.cin_store)          # :168
             a1 = _conv(mb, blk.c1, NB, H)
@@ -408,7 +442,12 @@ def d_forward(D, x, groups=1):
                 a2, rec['r2'] = ops.pixelnorm_fwd(a2, inplace=True)
             rec.update(mb=mb, stats=stats, a1=a1, a2=a2)
         else:
-            a1 = _conv(cur, blk.c1, NB, H)
+            if sb and H >= SIGN_BYTES_MIN_H:
+                a1, a1b = _conv(cur, blk.c1, NB, H, signs_out=True)
+                if a1b is not None:
+                    rec['a1b'] = a1b
+            else:
+                a1 = _conv(cur, blk.c1, NB, H)
             if pn:                                                            # a1/a2 hold the NORMALISED outputs
                 a1, rec['r1'] = ops.pixelnorm_fwd(a1, inplace=True)
             pf = None
@@ -436,7 +475,7 @@ def _slice_ctx(ctx, a, b, g0, g1):
     sub = dict(NB=b - a, groups=g1 - g0, depth=ctx['depth'], alpha=ctx['alpha'], x=ctx['x'][a:b], recs=[])
     for rec in ctx['recs']:
         r2 = dict(rec)
-        for k in ('inp', 'a1', 'a2', 'mb', 'pf'):
+        for k in ('inp', 'a1', 'a2', 'mb', 'pf', 'inpb', 'a1b'):
             if k in rec:
                 r2[k] = rec[k][a:b]
         for k in ('r1', 'r2'):                       # PixelNorm scales, one per pixel: [NB*h*w]
@@ -505,7 +544,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             gz2 = g
             if full:
                 _wgrad(rec['a1'], gz2, c2, NB, H)
-            gz1 = _dgrad(D, gz2, c2, NB, H, mask=rec['a1'], mask_slope=c1.slope)
+            gz1 = _dgrad(D, gz2, c2, NB, H, mask=(rec['a1'], rec.get('a1b')), mask_slope=c1.slope)
             if full:
                 _wgrad(rec['inp'], gz1, c1, NB, H)
             g_fused = None
@@ -515,7 +554,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                 g_fused = _dgrad_unpool(D, gz1, c1, NB, H, pv['a2'], 1.0, pv['blk'].c2.slope)
                 gin = None
             else:
-                gin = _dgrad(D, gz1, c1, NB, H, mask=rec['inp'] if rec['first'] else None, mask_slope=fr_slope)
+                gin = _dgrad(D, gz1, c1, NB, H, mask=(rec['inp'], rec.get('inpb')) if rec['first'] else None, mask_slope=fr_slope)
             if save_adjoints:
                 adj[idx].update(gz2=gz2, gz1=gz1)
         if rec['first']:
@@ -675,7 +714,14 @@ def d_tangent_wgrad(D, sub, adj, u):
     H = rec0['H']
     with _on_side(adj[0]['gf'], u):
         ops.fromrgb_wgrad(adj[0]['gf'], u, fr._gw, None, N, C, H, H, fr.c)
-    cur = ops.fromrgb_fwd(u, fr.conv.weight.data, None, N, C, H, H, fr.c, 1.0, mask=rec0['inp'], mask_slope=fr.slope)
+    cur = None
+    if rec0.get('inpb') is not None:
+        try:
+            cur = ops.fromrgb_fwd(u, fr.conv.weight.data, None, N, C, H, H, fr.c, 1.0, mask=rec0['inpb'], mask_slope=fr.slope)
+        except ops.Unsupported:
+            cur = None
+    if cur is None:
+        cur = ops.fromrgb_fwd(u, fr.conv.weight.data, None, N, C, H, H, fr.c, 1.0, mask=rec0['inp'], mask_slope=fr.slope)
     hvp = None
     t2 = None
     pn = bool(getattr(D, 'pixelnorm', False))
@@ -696,7 +742,7 @@ def d_tangent_wgrad(D, sub, adj, u):
                 t2, injs[idx]['inj2'] = ops.pixelnorm_tangent(t2, rec['a2'], rec['r2'], adj[idx]['gy2'])
         else:
             _wgrad(cur, adj[idx]['gz1'], c1, N, H, bias=False)
-            t1 = _conv(cur, c1, N, H, mask=rec['a1'], bias=False)
+            t1 = _conv(cur, c1, N, H, mask=(rec['a1'], rec.get('a1b')), bias=False)
             if pn:
                 t1, injs[idx]['inj1'] = ops.pixelnorm_tangent(t1, rec['a1'], rec['r1'], adj[idx]['gy1'])
             _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False)

@@ -32,15 +32,29 @@ def require_gpu():
 
 
 # ------------------------------------------------------------------------------------ conv
+def _is_bytes(t):
+    return t is not None and t.dtype == torch.uint8
+
+
+FLAG_UPSAMPLE, FLAG_MASK_BYTES, FLAG_Y_BYTES, FLAG_SIGNS_OUT = 1, 2, 4, 8     # PG_FLAG_* of include/pggan_hip.h
+Unsupported = _lib.Unsupported
+
+
 def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False,
-           out=None):
-    """x: [N,Hin(/2),Win(/2),Cin]; w packed [ks,ks,Cout,Cin] -> y [N,Hout,Wout,Cout]."""
+           out=None, signs_out=False):
+    """x: [N,Hin(/2),Win(/2),Cin]; w packed [ks,ks,Cout,Cin] -> y [N,Hout,Wout,Cout].  A uint8 ``mask`` holds sign bytes;
+    ``signs_out`` (forward mode) additionally returns the sign bytes of y: (y, bytes).  Both may raise ops.Unsupported."""
     cout, cin = w.shape[2], w.shape[3]
     ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
     y = out if out is not None else torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
+    flags = (FLAG_UPSAMPLE if ups else 0) | (FLAG_MASK_BYTES if _is_bytes(mask) else 0)
+    sb = None
+    if signs_out:
+        sb = torch.empty((N, ho, wo, cout // 4), device=x.device, dtype=torch.uint8)
+        mask, flags = sb, flags | FLAG_SIGNS_OUT
     _lib.call('pg_conv2d_nhwc', _p(x), _p(w), _p(bias), _p(mask), _p(y), N, Hin, Win, cin, cout, ks, pad,
-              1 if ups else 0, scale, slope, mask_slope, _stream())
-    return y
+              flags, scale, slope, mask_slope, _stream())
+    return (y, sb) if signs_out else y
 
 
 def wino_transform_weights(w, u=None):
@@ -67,12 +81,9 @@ def wino_transform_weights_batched(flat_w, flat_u, layers):
               ctypes.cast(uoff, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), ctypes.cast(ci, ctypes.c_void_p), _stream())
 
 
-FLAG_UPSAMPLE, FLAG_MASK_BYTES, FLAG_Y_BYTES = 1, 2, 4           # PG_FLAG_* of include/pggan_hip.h
+FLAG_UPSAMPLE, FLAG_MASK_BYTES, FLAG_Y_BYTES, FLAG_SIGNS_OUT = 1, 2, 4, 8     # PG_FLAG_* of include/pggan_hip.h
 Unsupported = _lib.Unsupported
 
-
-def _is_bytes(t):
-    return t is not None and t.dtype == torch.uint8
 
 
 def signbytes_to_mask(b):
@@ -83,7 +94,8 @@ def signbytes_to_mask(b):
 
 
 def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None,
-                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0, y_bytes=False):
+                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0, y_bytes=False,
+                signs_out=False):
     """3x3 pad-1 conv on Winograd-domain weights (+ the fused pool / unpool epilogues).  Returns y, (y, ypool) or yup.
     uint8 ``mask`` / ``upmask`` are sign bytes; ``y_bytes`` (with ``pool``) returns the sign bytes of y instead of y."""
     cout, cin = u.shape[1], u.shape[2]
@@ -94,8 +106,14 @@ def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2
         y = out if out is not None else torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
     yp = torch.empty((N, H // 2, W // 2, cout), device=x.device, dtype=torch.float32) if pool else None
     yu = torch.empty((N, 2 * H, 2 * W, cout), device=x.device, dtype=torch.float32) if unpool else None
+    sb = None
+    if signs_out:                                  # plain forward launch: (y, sign bytes of y)
+        sb = torch.empty((N, H, W, cout // 4), device=x.device, dtype=torch.uint8)
+        mask, flags = sb, flags | FLAG_SIGNS_OUT
     _lib.call('pg_conv2d_wino_nhwc', _p(x), _p(u), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
               _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, flags, scale, slope, mask_slope, _stream())
+    if signs_out:
+        return y, sb
     if pool:
         return y, yp
     if unpool:
@@ -186,12 +204,17 @@ def pack_dgrad_weights_batched(flat_w, flat_wt, layers):
 
 
 # --------------------------------------------------------------------------------- from/toRGB
-def fromrgb_fwd(img, w, bias, N, C, H, W, scale, slope, pool=False, mask=None, mask_slope=0.2):
+def fromrgb_fwd(img, w, bias, N, C, H, W, scale, slope, pool=False, mask=None, mask_slope=0.2, signs_out=False):
     cout = w.shape[0]
     y = torch.empty((N, H, W, cout), device=img.device, dtype=torch.float32)
-    _lib.call('pg_fromrgb_fwd', _p(img), _p(w), _p(bias), _p(mask), _p(y), N, C, H, W, cout, 1 if pool else 0,
+    flags = (1 if pool else 0) | (FLAG_MASK_BYTES if _is_bytes(mask) else 0)
+    sb = None
+    if signs_out:
+        sb = torch.empty((N, H, W, cout // 4), device=img.device, dtype=torch.uint8)
+        mask, flags = sb, flags | FLAG_SIGNS_OUT
+    _lib.call('pg_fromrgb_fwd', _p(img), _p(w), _p(bias), _p(mask), _p(y), N, C, H, W, cout, flags,
               scale, slope, mask_slope, _stream())
-    return y
+    return (y, sb) if signs_out else y
 
 
 def fromrgb_bwd_data(gz, w, gimg, N, C, H, W, scale, pool=False, accumulate=False):

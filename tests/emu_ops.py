@@ -58,7 +58,7 @@ def _wref(w):
     return w.permute(2, 3, 0, 1)            # [ks,ks,co,ci] -> [co,ci,ks,ks]
 
 
-def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None):
+def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None, signs_out=False):
     xi = _nchw(x)
     if ups:
         xi = F.interpolate(xi, scale_factor=2, mode='nearest')
@@ -71,7 +71,8 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
         if bias is not None:
             z = z + bias
         y = _lrelu(z, slope)
-    return _ret(y, out)
+    y = _ret(y, out)
+    return (y, signbytes_of(y)) if signs_out else y
 
 
 def conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=False):
@@ -116,7 +117,8 @@ def _unwino(u):
 
 
 def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None,
-                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0, y_bytes=False):
+                pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0, y_bytes=False,
+                signs_out=False):
     w = _unwino(u)
     y = conv2d(x, w, bias, N, H, W, 3, 1, scale, slope=slope, mask=mask, mask_slope=mask_slope, ups=ups)
     if out is not None:
@@ -126,7 +128,7 @@ def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2
         return (signbytes_of(y) if y_bytes else y), avgpool2_fwd(y, other, a, b)
     if unpool:
         return avgpool2_bwd(y, upmask, up_mul, mask_slope)
-    return y
+    return (y, signbytes_of(y)) if signs_out else y
 
 
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
@@ -168,14 +170,15 @@ def _img(img, pool):
     return F.avg_pool2d(img, 2) if pool else img
 
 
-def fromrgb_fwd(img, w, bias, N, C, H, W, scale, slope, pool=False, mask=None, mask_slope=0.2):
+def fromrgb_fwd(img, w, bias, N, C, H, W, scale, slope, pool=False, mask=None, mask_slope=0.2, signs_out=False):
     xi = _img(img, pool)
     z = torch.einsum('nchw,oc->nhwo', xi, w) * scale
     if mask is not None:
         return _maskmul(z, mask, mask_slope).contiguous()
     if bias is not None:
         z = z + bias
-    return _lrelu(z, slope).contiguous()
+    y = _lrelu(z, slope).contiguous()
+    return (y, signbytes_of(y)) if signs_out else y
 
 
 def fromrgb_bwd_data(gz, w, gimg, N, C, H, W, scale, pool=False, accumulate=False):

@@ -378,3 +378,50 @@ def test_sign_byte_activations(case):
         uw = ops.conv2d_wino(dev(g), ut, None, N, H // 2, H // 2, 0.3, mask_slope=0.2, unpool=True, upmask=yb, up_mul=0.7)
         uw32 = ops.conv2d_wino(dev(g), ut, None, N, H // 2, H // 2, 0.3, mask_slope=0.2, unpool=True, upmask=y32, up_mul=0.7)
         assert rel_err(uw, uw32) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2, 64, 8, 8), (1, 64, 16, 8), (2, 32, 8, 16), (2, 32, 16, 16), (8, 32, 32, 64), (8, 32, 64, 32)])
+def test_sign_bytes_of_fp32_activations(case):
+    """PG_FLAG_SIGNS_OUT: forward launches that write y AND its sign bytes (DBlock c1 / fromRGB outputs), and masked launches
+    that read the bytes instead of the fp32 activation -- block-MFMA (8 couts), generic and Winograd kernels, fromRGB.
+    (Launches too small to fill the chip without split-K answer PG_E_UNSUP by contract: see the last test below.)"""
+    N, H, ci, co = case
+    ops = pg.ops
+    dev = lambda t: t.cuda()
+    x, w, b = rnd(N, H, H, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    y32 = ops.conv2d(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.4, 0.2)
+    y, yb = ops.conv2d(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.4, 0.2, signs_out=True)
+    assert torch.equal(y, y32) and torch.equal(yb.cpu(), E.signbytes_of(y32.cpu()))
+    g, wt = rnd(N, H, H, co, seed=3), rnd(3, 3, ci, co, seed=4) * 0.2          # backward-data direction: co -> ci, masked by x's signs
+    xb = E.signbytes_of(x).cuda()
+    d32 = ops.conv2d(dev(g), dev(wt), None, N, H, H, 3, 1, 0.3, mask=dev(x), mask_slope=0.2)
+    db = ops.conv2d(dev(g), dev(wt), None, N, H, H, 3, 1, 0.3, mask=xb, mask_slope=0.2)
+    assert rel_err(db, d32) < 2e-6
+    if ci % 16 == 0:
+        u = ops.wino_transform_weights(dev(w))
+        yw32 = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.4, 0.2)
+        yw, ywb = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.4, 0.2, signs_out=True)
+        assert torch.equal(yw, yw32) and torch.equal(ywb.cpu(), E.signbytes_of(yw32.cpu()))
+    if co % 16 == 0:
+        ut = ops.wino_transform_weights(dev(wt))
+        assert rel_err(ops.conv2d_wino(dev(g), ut, None, N, H, H, 0.3, mask=xb, mask_slope=0.2),
+                       ops.conv2d_wino(dev(g), ut, None, N, H, H, 0.3, mask=dev(x), mask_slope=0.2)) < 2e-6
+    # fromRGB: narrow per-pixel kernels (8/16 couts on >= 65536 pixels) and the generic one
+    for (n, hh, cc) in ((1, 256, 8), (1, 256, 16), (2, 16, 32)):
+        img, fw, fb = rnd(n, 3, hh, hh, seed=5), rnd(cc, 3, seed=6), rnd(cc, seed=7)
+        a32 = ops.fromrgb_fwd(dev(img), dev(fw), dev(fb), n, 3, hh, hh, 0.7, 0.2)
+        a, ab = ops.fromrgb_fwd(dev(img), dev(fw), dev(fb), n, 3, hh, hh, 0.7, 0.2, signs_out=True)
+        assert torch.equal(a, a32) and torch.equal(ab.cpu(), E.signbytes_of(a32.cpu()))
+        t32 = ops.fromrgb_fwd(dev(img), dev(fw), None, n, 3, hh, hh, 0.7, 1.0, mask=a32, mask_slope=0.2)
+        tb = ops.fromrgb_fwd(dev(img), dev(fw), None, n, 3, hh, hh, 0.7, 1.0, mask=ab, mask_slope=0.2)
+        assert torch.equal(tb, t32)
+
+
+@pytest.mark.gpu
+def test_sign_bytes_unsupported_is_reported():
+    """Configurations without a byte-aware epilogue (here a 1x1 conv) answer PG_E_UNSUP -> ops.Unsupported, never a wrong result."""
+    ops = pg.ops
+    x, w, b = rnd(2, 16, 16, 32).cuda(), (rnd(1, 1, 32, 32, seed=1) * 0.1).cuda(), rnd(32, seed=2).cuda()
+    with pytest.raises(ops.Unsupported):
+        ops.conv2d(x, w, b, 2, 16, 16, 1, 0, 0.4, 0.2, signs_out=True)
