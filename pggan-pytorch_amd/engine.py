@@ -46,6 +46,8 @@ WINO_WGRAD_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_WGRAD_MIN_C', '16'))
 # The c2 output of a DBlock is pooled at once (network.py:229,238); at full resolution only its SIGN is ever used again
 # (LeakyReLU' in the backward / tangent sweeps), so from 64x64 up it is kept as sign bytes (1 byte per 4 channels)
 # instead of fp32: the fp32 write and its re-reads are the largest avoidable HBM traffic of the high-resolution stages.
+import collections as _collections
+FALLBACKS = _collections.Counter()       # launches that answered PG_E_UNSUP to a sign-byte request and were redone in fp32
 USE_SIGN_BYTES = _os.environ.get('PGGAN_SIGN_BYTES', '1') != '0'
 SIGN_BYTES_MIN_H = int(_os.environ.get('PGGAN_SIGN_BYTES_MIN_H', '64'))
 
@@ -107,6 +109,7 @@ def _conv(x, layer, N, H, act=True, mask=None, bias=True, ups=False, out=None, s
         try:
             return run(mask, True)
         except ops.Unsupported:
+            FALLBACKS['conv signs_out %dx%d %s' % (H, H, tuple(layer.conv.weight.shape))] += 1
             return run(mask, False), None
     if isinstance(mask, tuple):                    # (fp32 activation, its sign bytes or None): bytes first, fp32 as the fallback
         m32, mb = mask
@@ -114,7 +117,7 @@ def _conv(x, layer, N, H, act=True, mask=None, bias=True, ups=False, out=None, s
             try:
                 return run(mb, False)
             except ops.Unsupported:
-                pass
+                FALLBACKS['conv masked %dx%d %s' % (H, H, tuple(layer.conv.weight.shape))] += 1
         return run(m32, False)
     return run(mask, False)
 
@@ -140,6 +143,7 @@ def _conv_pool(x, layer, N, H, bias=True, mask=None, other=None, a=1.0, b=0.0, p
         try:
             return run(mask, y_bytes)
         except ops.Unsupported:
+            FALLBACKS['conv_pool %dx%d %s' % (H, H, tuple(layer.conv.weight.shape))] += 1
             return run(_mask32(mask), False)
     return run(mask, False)
 
@@ -158,7 +162,7 @@ def _dgrad(net, gz, layer, N, Hout, mask=None, mask_slope=0.2):
             try:
                 return run(mb)
             except ops.Unsupported:
-                pass
+                FALLBACKS['dgrad masked %dx%d %s' % (Hout, Hout, tuple(layer.conv.weight.shape))] += 1
         return run(m32)
     return run(mask)
 
@@ -183,6 +187,7 @@ def _dgrad_unpool(net, gz, layer, N, H, upmask, mul, mask_slope):
     except ops.Unsupported:
         if upmask is None or upmask.dtype != torch.uint8:
             raise
+        FALLBACKS['dgrad unpool %dx%d %s' % (H, H, tuple(layer.conv.weight.shape))] += 1
         return ops.conv2d_unpool(gz, _wt(net, layer), N, H, H, layer.ksize, layer.ksize - 1 - layer.pad, layer.c,
                                  upmask=_mask32(upmask), mul=mul, mask_slope=mask_slope)
 
