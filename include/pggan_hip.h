@@ -112,6 +112,20 @@ int pg_conv2d_unpool_nhwc(const float* x, const float* w, const float* upmask, f
 #define PG_FLAG_SIGNS_OUT  8
 int pg_signbytes_to_mask(const unsigned char* bytes, float* mask, int64_t nbytes, pg_stream_t stream);
 
+/* The pool adjoint evaluated in the input gathers of its two consumers (the avg_pool2d backward between two DBlocks,
+ * network.py:229/238, fused into the backward-data conv and the weight gradient of the finer block's c2):
+ *   gz2[n][h][w][c] = gmul * g[n][h/2][w/2][c] * (bit c of gbytes[n][h][w] ? 1 : gslope)        (never materialised)
+ *   pg_conv2d_unpooled_nhwc:        y  = scale * conv3x3(gz2, w) * lrelu'(mask)     (mask: fp32 or, PG_FLAG_MASK_BYTES, sign bytes)
+ *   pg_conv2d_wgrad_unpooled_nhwc:  dw += scale * sum gz2 (x) x,   db += sum gz2
+ * g: [N][Hin/2][Win/2][C] (C = Cin of the conv / Cout of the weight gradient), gbytes: [N][Hin][Win][C/4].  Implemented
+ * for the 8/16-channel layers of the 512^2/1024^2 stages (block-MFMA kernels); PG_E_UNSUP otherwise.               */
+int pg_conv2d_unpooled_nhwc(const float* g, const float* w, const unsigned char* gbytes, float gmul, float gslope,
+                            const float* mask, float* y, int N, int Hin, int Win, int Cin, int Cout, int flags,
+                            float scale, float mask_slope, pg_stream_t stream);
+int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, const unsigned char* gbytes, float gmul, float gslope,
+                                  float* dw, float* db, int N, int Hin, int Win, int Cin, int Cout,
+                                  float scale, pg_stream_t stream);
+
 /* Winograd F(2x2,3x3) path for the wide 3x3 layers (pad 1; Cin % 16 == 0; H, W powers of two >= 8): 2.25x fewer MFMAs
  * than the direct implicit GEMM, same fp32 sums re-associated (transform coefficients +-1, 1/2; ~1e-6 relative).
  *   pg_wino_transform_weights: u[16][Cout][Cin] = G g G^T of w[3][3][Cout][Cin]   (once per weight version)

@@ -64,6 +64,8 @@ struct ConvP {
     // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES): one byte per float4, bit j = (channel 4q+j > 0)
     int mask_bytes, y_bytes;
     unsigned char* ysigns;      // PG_FLAG_SIGNS_OUT: the sign bytes of y are written here IN ADDITION to y (forward mode)
+    // pool adjoint fused into the input gather (pg_conv2d_unpooled_nhwc): xin[n][h][w][c] = gmul * x[n][h/2][w/2][c] * lrelu'(gbytes[n][h][w][c])
+    const unsigned char* gbytes; float gmul, gslope;
 };
 
 // LeakyReLU' factors of four channels from a sign byte / the sign byte of four activated outputs
@@ -486,6 +488,8 @@ struct WgP {
     int lgTW, lgTH, TN, tilesW, tilesH, ntiles, tiles_per_block;
     unsigned mWT, mHT;          // magic reciprocals of the halo tile width / height (see ConvP)
     int atomic;                 // 0: this workgroup is the only writer of its dW block -> plain +=
+    // pool adjoint fused into the gz gather (pg_conv2d_wgrad_unpooled_nhwc): gz[n][h][w][c] = gmul * g[n][h/2][w/2][c] * lrelu'(gbytes[n][h][w][c])
+    const unsigned char* gbytes; float gmul, gslope;
 };
 
 // row stride == 16 (mod 32): the two 32-lane groups of ds_read_b32 hit disjoint banks
@@ -913,8 +917,14 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
         const int tw = q % WT, th = q / WT;
         int ih = oh0 + th - 1, iw = ow0 + tw - 1;
         const bool ok = e < HT * WT * C4 && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        unsigned char gb = 0;
+        if (p.gbytes && ok) gb = p.gbytes[(((size_t)n * p.Hin + ih) * p.Win + iw) * C4 + c4];
         if (p.ups) { ih >>= 1; iw >>= 1; }
         xv[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)((ih * xW + iw) * CIN + 4 * c4) : PG_OOB, 0);
+        if (p.gbytes) {                              // pool adjoint in the gather: x 1/4 (x mul) x LeakyReLU' of the finer activation
+            const float4 f = pg_sign_factors(gb, p.gslope);
+            xv[i].x *= f.x * p.gmul; xv[i].y *= f.y * p.gmul; xv[i].z *= f.z * p.gmul; xv[i].w *= f.w * p.gmul;
+        }
     }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -1600,13 +1610,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
         const int oh0 = th_i << p.lgTH, ow0 = tw_i << p.lgTW;
         // raw buffers over the TN images of this tile (bufload.h): PG_OOB = zero fill, no branch per load
         const int nimg = min(p.TN, p.N - n0);
-        const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(p.gz + (size_t)n0 * p.Hout * p.Wout * CO, (unsigned)((size_t)nimg * p.Hout * p.Wout * CO * 4));
+        const size_t zimg = p.gbytes ? (size_t)(p.Hout >> 1) * (p.Wout >> 1) * CO : (size_t)p.Hout * p.Wout * CO;
+        const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(p.gz + (size_t)n0 * zimg, (unsigned)((size_t)nimg * zimg * 4));
         const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n0 * xH * xW * CI, (unsigned)((size_t)nimg * xH * xW * CI * 4));
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) {
             const int q = zq[i];
             const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
             const bool ok = q >= 0 && tn < nimg;
+            if (p.gbytes) {                          // gz = pool adjoint of the coarse gradient, evaluated in the gather
+                const int hh = oh0 + th, ww = ow0 + tw;
+                zreg[i] = pg_buf_load4(rz, ok ? 4u * (unsigned)(((tn * (p.Hout >> 1) + (hh >> 1)) * (p.Wout >> 1) + (ww >> 1)) * CO + zc[i]) : PG_OOB, 0);
+                const unsigned char gb = ok ? p.gbytes[((((size_t)(n0 + tn) * p.Hout + hh) * p.Wout + ww) * CO + zc[i]) >> 2] : (unsigned char)0;
+                const float4 f = pg_sign_factors(gb, p.gslope);
+                zreg[i].x *= f.x * p.gmul; zreg[i].y *= f.y * p.gmul; zreg[i].z *= f.z * p.gmul; zreg[i].w *= f.w * p.gmul;
+            } else
             zreg[i] = pg_buf_load4(rz, ok ? 4u * (unsigned)(((tn * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * CO + zc[i]) : PG_OOB, 0);
         }
 #pragma unroll
@@ -1811,6 +1829,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
     ConvP p;
     p.mask_bytes = (flags & PG_FLAG_MASK_BYTES) ? 1 : 0; p.y_bytes = (flags & PG_FLAG_Y_BYTES) ? 1 : 0;
     p.ysigns = nullptr;
+    p.gbytes = nullptr; p.gmul = 1.f; p.gslope = 1.f;
     if (flags & PG_FLAG_SIGNS_OUT) {                        // forward mode: the (otherwise unused) mask argument is the byte output
         if (!mask || p.mask_bytes) return PG_E_ARG;
         p.ysigns = reinterpret_cast<unsigned char*>(const_cast<float*>(mask));
@@ -1960,6 +1979,7 @@ extern "C" int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, 
     if (p.Hout <= 0 || p.Wout <= 0 || !is_pow2(p.Hout) || !is_pow2(p.Wout)) return PG_E_UNSUP;
     if (ups && ((Hin | Win) & 1)) return PG_E_ARG;
     p.scale = scale;
+    p.gbytes = nullptr; p.gmul = 1.f; p.gslope = 1.f;
     hipStream_t s = (hipStream_t)stream;
     if (KS == 4 && !ups && k4_dense_ok(Cin, Cout) && g_tune[3] != 1 &&
         ((pad == 3 && Hin == 1 && Win == 1) || (pad == 0 && Hin == 4 && Win == 4)))
@@ -1970,6 +1990,48 @@ extern "C" int pg_conv2d_wgrad_nhwc(const float* x, const float* gz, float* dw, 
         case 4: return dispatch_wgrad<4>(p, s);
         default: return PG_E_UNSUP;
     }
+}
+
+// Backward-data conv / weight gradient of a DBlock's c2 layer whose incoming gradient is the POOL ADJOINT of the coarser
+// block's gradient g: instead of materialising gz2 = gmul * upsample2(g) * lrelu'(a2) (16 channels at 1024^2: the largest
+// tensor of the backward sweep, written once and read twice), both consumers evaluate it in their input gathers from g
+// (a quarter of the pixels) and the sign bytes of a2.  Block-MFMA kernels of the 8/16-channel layers only (PG_E_UNSUP otherwise).
+extern "C" int pg_conv2d_unpooled_nhwc(const float* g, const float* w, const unsigned char* gbytes, float gmul, float gslope,
+                                       const float* mask, float* y, int N, int Hin, int Win, int Cin, int Cout, int flags,
+                                       float scale, float mask_slope, pg_stream_t stream)
+{
+    if (!g || !w || !gbytes || !y || N <= 0 || Hin <= 0 || Win <= 0) return PG_E_ARG;
+    if ((Hin | Win) & 1) return PG_E_ARG;
+    if (!(Cout == 8 && (Cin == 8 || Cin == 16)) || (Win & 31) || (Hin & 7) || !is_pow2(Hin) || !is_pow2(Win)) return PG_E_UNSUP;
+    if ((long long)N * Hin * Win * Cin >= (1ll << 31)) return PG_E_UNSUP;
+    ConvP p;
+    p.x = g; p.w = w; p.bias = nullptr; p.mask = mask; p.y = y;
+    p.N = N; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout; p.KS = 3; p.pad = 1; p.ups = 1;
+    p.Hout = Hin; p.Wout = Win;
+    p.scale = scale; p.slope = 1.f; p.mask_slope = mask_slope; p.ksplit = 1;
+    p.ypool = nullptr; p.pool_other = nullptr; p.pool_a = 1.f; p.pool_b = 0.f; p.pool_only = 0;
+    p.yup = nullptr; p.upmask = nullptr; p.up_mul = 1.f;
+    p.pn_r = nullptr; p.pn_eps = 0.f; p.pnb_y = nullptr; p.pnb_r = nullptr;
+    p.mask_bytes = (flags & PG_FLAG_MASK_BYTES) ? 1 : 0; p.y_bytes = 0; p.ysigns = nullptr;
+    p.gbytes = gbytes; p.gmul = gmul; p.gslope = gslope;
+    return dispatch_thin(p, (hipStream_t)stream);
+}
+
+extern "C" int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, const unsigned char* gbytes, float gmul, float gslope,
+                                             float* dw, float* db, int N, int Hin, int Win, int Cin, int Cout,
+                                             float scale, pg_stream_t stream)
+{
+    if (!x || !g || !gbytes || !dw || N <= 0 || Hin <= 0 || Win <= 0) return PG_E_ARG;
+    if ((Hin | Win) & 1) return PG_E_ARG;
+    if (!((Cout == 16 && Cin == 8) || (Cout == 8 && Cin == 8) || (Cout == 8 && Cin == 16)) || !is_pow2(Hin) || !is_pow2(Win) || Hin < 8 || Win < 8)
+        return PG_E_UNSUP;
+    WgP p;
+    p.x = x; p.gz = g; p.dw = dw; p.db = db;
+    p.N = N; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout; p.pad = 1; p.ups = 0;
+    p.Hout = Hin; p.Wout = Win;
+    p.scale = scale;
+    p.gbytes = gbytes; p.gmul = gmul; p.gslope = gslope;
+    return launch_wgrad_thin<64>(p, (hipStream_t)stream);
 }
 
 extern "C" const char* pg_debug_last_conv_kernel(void) { return g_last_kernel; }

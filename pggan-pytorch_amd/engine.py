@@ -50,6 +50,9 @@ import collections as _collections
 FALLBACKS = _collections.Counter()       # launches that answered PG_E_UNSUP to a sign-byte request and were redone in fp32
 USE_SIGN_BYTES = _os.environ.get('PGGAN_SIGN_BYTES', '1') != '0'
 SIGN_BYTES_MIN_H = int(_os.environ.get('PGGAN_SIGN_BYTES_MIN_H', '64'))
+# With the mask as sign bytes the pool adjoint between two DBlocks can be evaluated in the input gathers of its consumers
+# (backward-data conv and weight gradient of the finer block's c2) instead of being written out at the fine resolution.
+USE_LAZY_UNPOOL = _os.environ.get('PGGAN_LAZY_UNPOOL', '1') != '0'
 
 
 def _derived(net):
@@ -519,6 +522,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
     g = ops.linear1_bwd_data(gscore, D.linear.weight.data, a2[:nh], (nh,) + tuple(a2.shape[1:]), lc2.slope)
     gimg = None
     pending_prev = None
+    carry = None
     for idx in range(len(recs) - 1, -1, -1):
         rec = recs[idx]
         blk, H = rec['blk'], rec['H']
@@ -547,16 +551,38 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                 adj[idx].update(gz2=gz2, gz1=gz1, gmb=gmb)
         else:
             gz2 = g
-            if full:
-                _wgrad(rec['a1'], gz2, c2, NB, H)
-            gz1 = _dgrad(D, gz2, c2, NB, H, mask=(rec['a1'], rec.get('a1b')), mask_slope=c1.slope)
+            if carry is not None:                  # gz2 = pool adjoint of the coarser gradient, evaluated inside the two consumers
+                gc, gb, gmul, gsl = carry
+                carry = None
+                try:
+                    gz1 = ops.conv2d_unpooled(gc, _wt(D, c2), gb, gmul, gsl, NB, H, H, c2.c,
+                                              mask=rec.get('a1b') if rec.get('a1b') is not None else rec['a1'], mask_slope=c1.slope)
+                    if full:
+                        with _on_side(rec['a1'], gc, gb):
+                            ops.conv2d_wgrad_unpooled(rec['a1'], gc, gb, gmul, gsl, c2._gw, c2._gb, NB, H, H, c2.c)
+                except ops.Unsupported:                    # (shape checks are identical for both entry points: nothing was accumulated)
+                    FALLBACKS['lazy unpool %dx%d' % (H, H)] += 1
+                    gz2 = ops.avgpool2_bwd(gc, _mask32(gb), 4.0 * gmul, gsl)
+                    if full:
+                        _wgrad(rec['a1'], gz2, c2, NB, H)
+                    gz1 = _dgrad(D, gz2, c2, NB, H, mask=(rec['a1'], rec.get('a1b')), mask_slope=c1.slope)
+            else:
+                if full:
+                    _wgrad(rec['a1'], gz2, c2, NB, H)
+                gz1 = _dgrad(D, gz2, c2, NB, H, mask=(rec['a1'], rec.get('a1b')), mask_slope=c1.slope)
             if full:
                 _wgrad(rec['inp'], gz1, c1, NB, H)
             g_fused = None
             if not rec['first'] and not (recs[idx - 1]['first'] and alpha < 1.0):
-                # backward-data conv + pool adjoint + LeakyReLU' of the finer block's output in one kernel
                 pv = recs[idx - 1]
-                g_fused = _dgrad_unpool(D, gz1, c1, NB, H, pv['a2'], 1.0, pv['blk'].c2.slope)
+                pc2w = pv['blk'].c2.conv.weight.shape
+                if (USE_LAZY_UNPOOL and not save_adjoints and pv['a2'].dtype == torch.uint8 and pc2w[3] == 8 and pc2w[2] in (8, 16)
+                        and pv['blk'].c2.ksize == 3 and pv['H'] % 32 == 0):
+                    # plain coarse gradient; the finer block's c2 consumers apply the pool adjoint in their gathers
+                    carry = (_dgrad(D, gz1, c1, NB, H), pv['a2'], 0.25, pv['blk'].c2.slope)
+                else:
+                    # backward-data conv + pool adjoint + LeakyReLU' of the finer block's output in one kernel
+                    g_fused = _dgrad_unpool(D, gz1, c1, NB, H, pv['a2'], 1.0, pv['blk'].c2.slope)
                 gin = None
             else:
                 gin = _dgrad(D, gz1, c1, NB, H, mask=(rec['inp'], rec.get('inpb')) if rec['first'] else None, mask_slope=fr_slope)
@@ -592,6 +618,8 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                 pending_prev = (gpf, pfr)
             elif not rec['last'] and g_fused is not None:
                 g = g_fused
+            elif carry is not None:
+                g = None                            # consumed through ``carry`` by the next (finer) block
             else:
                 g = ops.avgpool2_bwd(gin, _mask32(prev['a2']), 1.0, pc2.slope)
     return gimg, adj

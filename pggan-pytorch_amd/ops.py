@@ -172,6 +172,23 @@ def conv2d_unpool(x, w, N, Hin, Win, ks, pad, scale, upmask=None, mul=1.0, mask_
     return yup
 
 
+def conv2d_unpooled(g, w, gbytes, gmul, gslope, N, Hin, Win, scale, mask=None, mask_slope=0.2):
+    """Backward-data 3x3 conv whose input is the pool adjoint of ``g`` [N,Hin/2,Win/2,Cin] (x gmul, x LeakyReLU' from the sign
+    bytes ``gbytes`` [N,Hin,Win,Cin/4]) evaluated in the gather.  w packed [3,3,Cout,Cin]; raises ops.Unsupported."""
+    cout, cin = w.shape[2], w.shape[3]
+    y = torch.empty((N, Hin, Win, cout), device=g.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_unpooled_nhwc', _p(g), _p(w), _p(gbytes), gmul, gslope, _p(mask), _p(y), N, Hin, Win, cin, cout,
+              FLAG_MASK_BYTES if _is_bytes(mask) else 0, scale, mask_slope, _stream())
+    return y
+
+
+def conv2d_wgrad_unpooled(x, g, gbytes, gmul, gslope, dw, db, N, Hin, Win, scale):
+    """Weight gradient with gz = pool adjoint of ``g`` evaluated in the gather (see conv2d_unpooled)."""
+    cout, cin = dw.shape[2], dw.shape[3]
+    _lib.call('pg_conv2d_wgrad_unpooled_nhwc', _p(x), _p(g), _p(gbytes), gmul, gslope, _p(dw), _p(db), N, Hin, Win, cin, cout,
+              scale, _stream())
+
+
 def conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=False):
     """Accumulates into dw [ks,ks,Cout,Cin] (and db [Cout] if given)."""
     cout, cin = dw.shape[2], dw.shape[3]

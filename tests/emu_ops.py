@@ -75,6 +75,18 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
     return (y, signbytes_of(y)) if signs_out else y
 
 
+def _unpooled(g, gbytes, gmul, gslope):
+    return avgpool2_bwd(g, gbytes, 4.0 * gmul, gslope)
+
+
+def conv2d_unpooled(g, w, gbytes, gmul, gslope, N, Hin, Win, scale, mask=None, mask_slope=0.2):
+    return conv2d(_unpooled(g, gbytes, gmul, gslope), w, None, N, Hin, Win, 3, 1, scale, mask=mask, mask_slope=mask_slope)
+
+
+def conv2d_wgrad_unpooled(x, g, gbytes, gmul, gslope, dw, db, N, Hin, Win, scale):
+    conv2d_wgrad(x, _unpooled(g, gbytes, gmul, gslope), dw, db, N, Hin, Win, 3, 1, scale)
+
+
 def conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=False):
     conv2d_wgrad(x, gz, dw, db, N, H, W, 3, 1, scale, ups=ups)
 

@@ -425,3 +425,28 @@ def test_sign_bytes_unsupported_is_reported():
     x, w, b = rnd(2, 16, 16, 32).cuda(), (rnd(1, 1, 32, 32, seed=1) * 0.1).cuda(), rnd(32, seed=2).cuda()
     with pytest.raises(ops.Unsupported):
         ops.conv2d(x, w, b, 2, 16, 16, 1, 0, 0.4, 0.2, signs_out=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2, 64, 16, 8), (3, 32, 8, 8), (1, 128, 16, 8)])
+def test_pool_adjoint_in_the_gather(case):
+    """pg_conv2d_unpooled_nhwc / pg_conv2d_wgrad_unpooled_nhwc: the pool adjoint (x 1/4 x mul x LeakyReLU' sign byte) of the
+    coarse gradient evaluated in the consumers' gathers == materialising it with avgpool2_bwd first."""
+    N, H, cg, co = case                                  # g has cg channels at H/2; backward-data conv cg -> co
+    ops = pg.ops
+    g, a2 = rnd(N, H // 2, H // 2, cg), rnd(N, H, H, cg, seed=1)
+    gb = E.signbytes_of(a2)
+    wt, a1 = rnd(3, 3, co, cg, seed=2) * 0.2, rnd(N, H, H, co, seed=3)
+    gz2 = E.avgpool2_bwd(g, a2, 0.7, 0.2)
+    ref = E.conv2d(gz2, wt, None, N, H, H, 3, 1, 0.3, mask=a1, mask_slope=0.2)
+    y = ops.conv2d_unpooled(g.cuda(), wt.cuda(), gb.cuda(), 0.25 * 0.7, 0.2, N, H, H, 0.3, mask=E.signbytes_of(a1).cuda(), mask_slope=0.2)
+    assert rel_err(y, ref) < 2e-5
+    y = ops.conv2d_unpooled(g.cuda(), wt.cuda(), gb.cuda(), 0.25 * 0.7, 0.2, N, H, H, 0.3, mask=a1.cuda(), mask_slope=0.2)
+    assert rel_err(y, ref) < 2e-5
+    # weight gradient of the forward conv co -> cg:  dw [3,3,cg,co] += sum gz2 (x) a1
+    dw0, db0 = rnd(3, 3, cg, co, seed=4), rnd(cg, seed=5)
+    rdw, rdb = dw0.clone(), db0.clone()
+    E.conv2d_wgrad(a1, gz2, rdw, rdb, N, H, H, 3, 1, 0.41)
+    dw, db = dw0.cuda(), db0.cuda()
+    ops.conv2d_wgrad_unpooled(a1.cuda(), g.cuda(), gb.cuda(), 0.25 * 0.7, 0.2, dw, db, N, H, H, 0.41)
+    assert rel_err(dw, rdw) < 2e-5 and rel_err(db, rdb) < 2e-5

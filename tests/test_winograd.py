@@ -35,11 +35,11 @@ def emu(monkeypatch):
     yield
 
 
-def _engine_vs_oracle(dev, monkeypatch, res, depth, alpha, n):
+def _engine_vs_oracle(dev, monkeypatch, res, depth, alpha, n, kw=None):
     monkeypatch.setattr(pg.engine, 'WINO_MIN_WORKGROUPS', 0)          # every eligible layer takes the Winograd path
     torch.manual_seed(21)
     shape = (1, 3, res, res)
-    kw = dict(fmap_base=256, fmap_max=64)
+    kw = kw or dict(fmap_base=256, fmap_max=64)
     G = pg.Generator(shape, latent_size=64, **kw)
     D = pg.Discriminator(shape, **kw)
     gp, dp = G.reference_state_dict(), D.reference_state_dict()
@@ -154,3 +154,15 @@ def test_engine_with_sign_bytes_gpu(monkeypatch, depth, alpha, n, wino):
     if not wino:
         monkeypatch.setattr(pg.engine, 'USE_WINOGRAD', False)
     _engine_vs_oracle('cuda', monkeypatch, 64, depth, alpha, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('alpha', [1.0, 0.5])
+def test_engine_with_lazy_pool_adjoint_gpu(monkeypatch, alpha):
+    """128x128 network with 8/16-channel top stages: D's backward takes the pool adjoint between the 64^2 and 128^2 blocks
+    inside the consumers' gathers (engine.USE_LAZY_UNPOOL) -- checked against the oracle, and that the path is really taken."""
+    calls = []
+    orig = pg.ops.conv2d_unpooled
+    monkeypatch.setattr(pg.ops, 'conv2d_unpooled', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    _engine_vs_oracle('cuda', monkeypatch, 128, 5, alpha, 2, kw=dict(fmap_base=512, fmap_max=64))
+    assert (len(calls) > 0) == (alpha == 1.0)         # with the fade-in active the top boundary keeps the materialised form
