@@ -909,6 +909,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
     // one image through a raw buffer (bufload.h): out-of-image halo pixels are zero-filled by the hardware, no branch per load
     const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n * xH * xW * CIN, (unsigned)((size_t)xH * xW * CIN * 4));
     constexpr int NLD = (HT * WT * C4 + 255) / 256;
+    const unsigned char* gbase = p.gbytes ? p.gbytes + (size_t)n * p.Hin * p.Win * C4 : nullptr;     // this image's sign bytes
     float4 xv[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -918,7 +919,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
         int ih = oh0 + th - 1, iw = ow0 + tw - 1;
         const bool ok = e < HT * WT * C4 && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
         unsigned char gb = 0;
-        if (p.gbytes && ok) gb = p.gbytes[(((size_t)n * p.Hin + ih) * p.Win + iw) * C4 + c4];
+        if (p.gbytes && ok) gb = gbase[(ih * p.Win + iw) * C4 + c4];
         if (p.ups) { ih >>= 1; iw >>= 1; }
         xv[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)((ih * xW + iw) * CIN + 4 * c4) : PG_OOB, 0);
         if (p.gbytes) {                              // pool adjoint in the gather: x 1/4 (x mul) x LeakyReLU' of the finer activation
@@ -1621,7 +1622,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
             if (p.gbytes) {                          // gz = pool adjoint of the coarse gradient, evaluated in the gather
                 const int hh = oh0 + th, ww = ow0 + tw;
                 zreg[i] = pg_buf_load4(rz, ok ? 4u * (unsigned)(((tn * (p.Hout >> 1) + (hh >> 1)) * (p.Wout >> 1) + (ww >> 1)) * CO + zc[i]) : PG_OOB, 0);
-                const unsigned char gb = ok ? p.gbytes[((((size_t)(n0 + tn) * p.Hout + hh) * p.Wout + ww) * CO + zc[i]) >> 2] : (unsigned char)0;
+                const unsigned char gb = ok ? p.gbytes[(size_t)n0 * p.Hout * p.Wout * (CO / 4) + (unsigned)(((tn * p.Hout + hh) * p.Wout + ww) * (CO / 4) + (zc[i] >> 2))] : (unsigned char)0;
                 const float4 f = pg_sign_factors(gb, p.gslope);
                 zreg[i].x *= f.x * p.gmul; zreg[i].y *= f.y * p.gmul; zreg[i].z *= f.z * p.gmul; zreg[i].w *= f.w * p.gmul;
             } else
