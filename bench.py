@@ -111,6 +111,16 @@ class KernelTimer(object):
         self._wrap('conv2d_pnbwd', generic(1, 4, '+pn adjoint'))
         self._wrap('conv2d_wgrad', wgrad_desc)
         self._wrap('conv2d_wgrad_wino', wino_wgrad_desc)
+
+        def unpooled_desc(a, k):      # conv2d_unpooled(g, w, gbytes, gmul, gslope, N, Hin, Win, scale, ...)
+            w, n, h = a[1], a[5], a[6]
+            return (conv_flops(n, h, h, 3, 1, w.shape[2], w.shape[3]), 'conv %d->%d k3 @%d n%d pool adjoint in the gather' % (w.shape[3], w.shape[2], h, n))
+
+        def wgrad_unpooled_desc(a, k):   # conv2d_wgrad_unpooled(x, g, gbytes, gmul, gslope, dw, db, N, Hin, Win, scale)
+            dw, n, h = a[5], a[7], a[8]
+            return (conv_flops(n, h, h, 3, 1, dw.shape[2], dw.shape[3]), 'wgrad %d->%d k3 @%d n%d pool adjoint in the gather' % (dw.shape[3], dw.shape[2], h, n))
+        self._wrap('conv2d_unpooled', unpooled_desc)
+        self._wrap('conv2d_wgrad_unpooled', wgrad_unpooled_desc)
         return self
 
     def __exit__(self, *exc):

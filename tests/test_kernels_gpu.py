@@ -339,8 +339,9 @@ def test_linear_gp_loss_adam():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('slope', [0.2, 0.0])            # 0.0: ReLU (Discriminator nonlinearity flag) -- the sign byte is (y > 0) either way
 @pytest.mark.parametrize('case', [(2, 64, 16, 32), (3, 32, 8, 16), (1, 128, 32, 64), (2, 64, 64, 32), (5, 16, 16, 16)])
-def test_sign_byte_activations(case):
+def test_sign_byte_activations(case, slope):
     """PG_FLAG_Y_BYTES / PG_FLAG_MASK_BYTES: the conv+pool epilogue writes the sign bytes of its output instead of the
     fp32 activation, the unpool and masked(+pool) epilogues read them as LeakyReLU' masks -- direct and Winograd kernels.
     Results must equal the fp32-mask launches exactly (same kernels, same arithmetic, only the mask source differs)."""
@@ -350,33 +351,33 @@ def test_sign_byte_activations(case):
     x, w, b = rnd(N, H, H, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
     other = rnd(N, H // 2, H // 2, co, seed=3)
     # producer
-    y32, yp32 = ops.conv2d_pool(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.4, 0.2, other=dev(other), a=0.6, b=0.4)
-    yb, ypb = ops.conv2d_pool(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.4, 0.2, other=dev(other), a=0.6, b=0.4, y_bytes=True)
+    y32, yp32 = ops.conv2d_pool(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.4, slope, other=dev(other), a=0.6, b=0.4)
+    yb, ypb = ops.conv2d_pool(dev(x), dev(w), dev(b), N, H, H, 3, 1, 0.4, slope, other=dev(other), a=0.6, b=0.4, y_bytes=True)
     assert yb.dtype == torch.uint8 and tuple(yb.shape) == (N, H, H, co // 4)
     assert torch.equal(yb.cpu(), E.signbytes_of(y32.cpu())) and rel_err(ypb, yp32) < 2e-6
     assert torch.equal(ops.signbytes_to_mask(yb).cpu(), E.signbytes_to_mask(yb.cpu()))
     # unpool consumer: gradient at the pooled resolution -> fine resolution, masked by the signs of y
     g = rnd(N, H // 2, H // 2, co, seed=4)
     wt = rnd(3, 3, co, co, seed=5) * 0.2
-    up32 = ops.conv2d_unpool(dev(g), dev(wt), N, H // 2, H // 2, 3, 1, 0.3, upmask=y32, mul=0.7, mask_slope=0.2)
-    upb = ops.conv2d_unpool(dev(g), dev(wt), N, H // 2, H // 2, 3, 1, 0.3, upmask=yb, mul=0.7, mask_slope=0.2)
+    up32 = ops.conv2d_unpool(dev(g), dev(wt), N, H // 2, H // 2, 3, 1, 0.3, upmask=y32, mul=0.7, mask_slope=slope)
+    upb = ops.conv2d_unpool(dev(g), dev(wt), N, H // 2, H // 2, 3, 1, 0.3, upmask=yb, mul=0.7, mask_slope=slope)
     assert rel_err(upb, up32) < 2e-6
     # tangent consumer: masked conv + pool_only
-    _, t32 = ops.conv2d_pool(dev(x), dev(w), None, N, H, H, 3, 1, 0.4, 1.0, mask=y32, mask_slope=0.2, other=dev(other), a=0.6, b=0.4, pool_only=True)
-    _, tb = ops.conv2d_pool(dev(x), dev(w), None, N, H, H, 3, 1, 0.4, 1.0, mask=yb, mask_slope=0.2, other=dev(other), a=0.6, b=0.4, pool_only=True)
+    _, t32 = ops.conv2d_pool(dev(x), dev(w), None, N, H, H, 3, 1, 0.4, 1.0, mask=y32, mask_slope=slope, other=dev(other), a=0.6, b=0.4, pool_only=True)
+    _, tb = ops.conv2d_pool(dev(x), dev(w), None, N, H, H, 3, 1, 0.4, 1.0, mask=yb, mask_slope=slope, other=dev(other), a=0.6, b=0.4, pool_only=True)
     assert rel_err(tb, t32) < 2e-6
     if ci % 16 == 0 and H >= 8:                                  # the Winograd kernel's epilogues
         u = ops.wino_transform_weights(dev(w))
-        ybw, ypw = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.4, 0.2, pool=True, other=dev(other), a=0.6, b=0.4, y_bytes=True)
-        y32w, _ = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.4, 0.2, pool=True, other=dev(other), a=0.6, b=0.4)
+        ybw, ypw = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.4, slope, pool=True, other=dev(other), a=0.6, b=0.4, y_bytes=True)
+        y32w, _ = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.4, slope, pool=True, other=dev(other), a=0.6, b=0.4)
         assert torch.equal(ybw.cpu(), E.signbytes_of(y32w.cpu())) and rel_err(ypw, yp32) < 2e-5
-        _, tw = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.4, 1.0, mask=ybw, mask_slope=0.2, pool=True, other=dev(other), a=0.6, b=0.4, pool_only=True)
-        _, tw32 = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.4, 1.0, mask=y32w, mask_slope=0.2, pool=True, other=dev(other), a=0.6, b=0.4, pool_only=True)
+        _, tw = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.4, 1.0, mask=ybw, mask_slope=slope, pool=True, other=dev(other), a=0.6, b=0.4, pool_only=True)
+        _, tw32 = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.4, 1.0, mask=y32w, mask_slope=slope, pool=True, other=dev(other), a=0.6, b=0.4, pool_only=True)
         assert rel_err(tw, tw32) < 2e-6
     if co % 16 == 0 and H >= 16:
         ut = ops.wino_transform_weights(dev(wt))
-        uw = ops.conv2d_wino(dev(g), ut, None, N, H // 2, H // 2, 0.3, mask_slope=0.2, unpool=True, upmask=yb, up_mul=0.7)
-        uw32 = ops.conv2d_wino(dev(g), ut, None, N, H // 2, H // 2, 0.3, mask_slope=0.2, unpool=True, upmask=y32, up_mul=0.7)
+        uw = ops.conv2d_wino(dev(g), ut, None, N, H // 2, H // 2, 0.3, mask_slope=slope, unpool=True, upmask=yb, up_mul=0.7)
+        uw32 = ops.conv2d_wino(dev(g), ut, None, N, H // 2, H // 2, 0.3, mask_slope=slope, unpool=True, upmask=y32, up_mul=0.7)
         assert rel_err(uw, uw32) < 2e-6
 
 
