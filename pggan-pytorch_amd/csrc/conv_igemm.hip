@@ -1603,6 +1603,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
     for (int tp = 0; tp < TAPS; ++tp) tapoff[tp] = ((tp / KS) * WT + (tp % KS)) * SX;
 
     float4 zreg[ZPT], xreg[XPT];
+    unsigned char zb[ZPT];                   // sign bytes of the prefetched gz values (pool adjoint in the gather)
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) zb[i] = 0;
     auto fetch = [&](int tile) {
         int t = tile;
         const int tw_i = t % p.tilesW; t /= p.tilesW;
@@ -1622,9 +1625,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
             if (p.gbytes) {                          // gz = pool adjoint of the coarse gradient, evaluated in the gather
                 const int hh = oh0 + th, ww = ow0 + tw;
                 zreg[i] = pg_buf_load4(rz, ok ? 4u * (unsigned)(((tn * (p.Hout >> 1) + (hh >> 1)) * (p.Wout >> 1) + (ww >> 1)) * CO + zc[i]) : PG_OOB, 0);
-                const unsigned char gb = ok ? p.gbytes[(size_t)n0 * p.Hout * p.Wout * (CO / 4) + (unsigned)(((tn * p.Hout + hh) * p.Wout + ww) * (CO / 4) + (zc[i] >> 2))] : (unsigned char)0;
-                const float4 f = pg_sign_factors(gb, p.gslope);
-                zreg[i].x *= f.x * p.gmul; zreg[i].y *= f.y * p.gmul; zreg[i].z *= f.z * p.gmul; zreg[i].w *= f.w * p.gmul;
+                // the byte is applied when the prefetched value is stored to LDS (next iteration): a multiply here would
+                // wait for the load and serialise the register prefetch
+                zb[i] = ok ? p.gbytes[(size_t)n0 * p.Hout * p.Wout * (CO / 4) + (unsigned)(((tn * p.Hout + hh) * p.Wout + ww) * (CO / 4) + (zc[i] >> 2))] : (unsigned char)0;
             } else
             zreg[i] = pg_buf_load4(rz, ok ? 4u * (unsigned)(((tn * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * CO + zc[i]) : PG_OOB, 0);
         }
@@ -1646,7 +1649,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
     for (int tile = t_begin; tile < t_end; ++tile) {
 #pragma unroll
         for (int i = 0; i < ZPT; ++i)
-            if (zq[i] >= 0) *reinterpret_cast<float4*>(gzt + zq[i] * SZ + zc[i]) = zreg[i];
+            if (zq[i] >= 0) {
+                float4 v = zreg[i];
+                if (p.gbytes) {
+                    const float4 f = pg_sign_factors(zb[i], p.gslope);
+                    v.x *= f.x * p.gmul; v.y *= f.y * p.gmul; v.z *= f.z * p.gmul; v.w *= f.w * p.gmul;
+                }
+                *reinterpret_cast<float4*>(gzt + zq[i] * SZ + zc[i]) = v;
+            }
 #pragma unroll
         for (int i = 0; i < XPT; ++i)
             if (xq[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
