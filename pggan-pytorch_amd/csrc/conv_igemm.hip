@@ -1008,7 +1008,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
             o.x *= rr; o.y *= rr; o.z *= rr; o.w *= rr;
             if (qo == 0) p.pn_r[((size_t)n * p.Hout + oy) * p.Wout + ox] = rr;
         }
-        if (!(p.ypool && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
+        if (p.y_bytes) reinterpret_cast<unsigned char*>(p.y)[off >> 2] = pg_sign_byte(o);
+        else if (!(p.ypool && p.pool_only)) *reinterpret_cast<float4*>(p.y + off) = o;
         ov[g] = o;
     }
     if (p.ypool) {                               // 2x2 mean: column partner = lane^1, row partner = group g + GPR (same wave)
@@ -1872,8 +1873,9 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
         if (KS != 3 || (p.y_bytes && !ypool) || pn_r || pnb_y) return PG_E_UNSUP;
         p.ypool = ypool;
         p.yup = yup;
-        const bool thin_b = pad == 1 && !p.y_bytes && !yup && !ypool && ((Cout == 8 && (Cin == 8 || Cin == 16)) || (Cout == 16 && Cin == 8 && mask)) &&
-                            (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
+        const bool thin_plain = !p.y_bytes && !yup && !ypool && ((Cout == 8 && (Cin == 8 || Cin == 16)) || (Cout == 16 && Cin == 8 && mask));
+        const bool thin_pool = g_tune[3] != 17 && !yup && ypool && Cout == 16 && Cin == 8;      // 8->16 + pool (forward: sign bytes out; tangent: masked): +8..14 % over the generic tile kernel (tools/bench_thin16pool.py)
+        const bool thin_b = pad == 1 && (thin_plain || thin_pool) && (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
         if (thin_b) return dispatch_thin(p, s);
         return dispatch_conv_generic_nosplit(p, s);
     }
