@@ -7,7 +7,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the caller owns all
- *     buffers (no allocation, no ownership transfer, no global mutable state => re-entrant);
+ *     buffers (no allocation, no ownership transfer); the entry points declared in THIS header keep no mutable
+ *     global state => re-entrant (the only process-wide datum is the immutable table of RCCL entry points resolved on
+ *     first use of the pg_comm_* / pg_allreduce_* calls; the thread-local tuning / attribution aids used by bench.py
+ *     and tools/ are declared separately in pggan_hip_debug.h);
  *   - "feature" tensors are NHWC  [N][H][W][C]  with C % 4 == 0 and 16-byte aligned bases;
  *   - "image"   tensors are NCHW  [N][C][H][W]  (the reference's layout at the G-output/D-input);
  *   - conv weights are packed  [KH][KW][Cout][Cin]  (the K dimension contiguous);
@@ -27,6 +30,8 @@ extern "C" {
 #define PG_E_ARG     (-1)   /* bad dimension / null pointer            */
 #define PG_E_ALIGN   (-2)   /* channel count not a multiple of 4, ...  */
 #define PG_E_UNSUP   (-3)   /* unsupported kernel size / configuration */
+#define PG_E_NOLIB   (-4)   /* gradient exchange: no RCCL library could be loaded in this process */
+#define PG_E_RCCL_BASE (-16) /* gradient exchange: RCCL returned ncclResult_t r  =>  return value -16 - r */
 
 typedef void* pg_stream_t;
 
@@ -140,26 +145,12 @@ int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const
                         float* yup, const float* upmask, float up_mul,
                         int N, int H, int W, int Cin, int Cout, int ups,
                         float scale, float slope, float mask_slope, pg_stream_t stream);
-const char* pg_debug_last_wino_kernel(void);
 
 /* Winograd weight gradient of the same layers: dW[kh][kw][co][ci] += scale * sum gz*x (3x3, pad 1), db[co] += sum gz, computed as
  * G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G  -- 16 MFMAs per 4 output tiles instead of 36.  H, W powers of two with
  * H >= 8, W >= 16; commits with fp32 atomics.  Same arguments as pg_conv2d_wgrad_nhwc (KS 3, pad 1 implied).          */
 int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float* dw, float* db,
                               int N, int H, int W, int Cin, int Cout, int ups, float scale, pg_stream_t stream);
-const char* pg_debug_last_wino_wgrad_kernel(void);
-int pg_debug_set_wino(int vec);                 /* tuning aid: K-chunk of 4*vec channels (2 or 4) for the calling thread */
-
-/* Profiling aid: symbol (as rocprofv3 prints it, e.g. "conv_igemm_kernel<3, 4, 2, 2, 4>") of the conv
- * kernel instantiation most recently launched by the calling thread through the two entry points
- * above ("" before the first launch).  Thread-local; lets bench.py attribute its HIP-event timings
- * to the exact kernel symbol that rocprofv3 --kernel-trace --stats reports.                      */
-const char* pg_debug_last_conv_kernel(void);
-
-/* Tuning aid (tools/microbench_conv.py): force a tile configuration for the calling thread's next launches.
- * key 0: conv tile candidate, key 1: weight-gradient configuration, key 2: conv split-K factor; value -1 restores
- * the built-in choice. */
-int pg_debug_set_tuning(int key, int value);
 
 /* Repack forward weights [KS][KS][Cout][Cin] into the weights of the backward-data convolution
  * [KS][KS][Cin][Cout] (spatially flipped, channels transposed).                               */
@@ -329,6 +320,24 @@ int pg_pyramid_level_u8(const uint8_t* in, uint8_t* out, int64_t planes, int H, 
  * in fp32, round-half-even, clip, uint8.  grid: [grid_h*h*up][grid_w*w*up][C].                                  */
 int pg_image_grid_u8(const float* img, uint8_t* grid, int n, int C, int h, int w, int up,
                      float min_in, float max_in, pg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gradient exchange of the data-parallel step: RCCL over xGMI (SURVEY.md §8b "the all-reduce itself is a C-ABI call
+ * taking ncclComm_t, buffer, count, stream", §8e).  The reference is single-GPU and has no collective; the exchange
+ * points are after `D_loss.backward()` trainer.py:98 (before optimizer_d.step() :100) and after `G_loss.backward()`
+ * trainer.py:111 (before optimizer_g.step() :112).  One process per GPU.  Bootstrap from the host language: rank 0
+ * calls pg_comm_unique_id, the PG_COMM_ID_BYTES bytes reach the other ranks out of band (torch.distributed store),
+ * every rank calls pg_comm_init_rank (collective: all ranks must call it).  `comm` is an ncclComm_t.
+ *   pg_allreduce_sum_f32: IN-PLACE sum over ranks of buf[0..count) (fp32, device), asynchronous on `stream`; averaging
+ *   is folded into pg_adam (grad_scale = 1/world).  Calls on one communicator must be issued in the same order on
+ *   every rank (RCCL semantics).  Returns PG_E_NOLIB when no RCCL can be loaded, PG_E_RCCL_BASE - r for an RCCL error. */
+#define PG_COMM_ID_BYTES 128
+int pg_rccl_version(int* version);
+int pg_comm_unique_id(void* id_out /* host, PG_COMM_ID_BYTES */);
+int pg_comm_init_rank(void** comm_out, int nranks, const void* id /* host, PG_COMM_ID_BYTES */, int rank);
+int pg_comm_info(void* comm, int* nranks, int* rank);
+int pg_comm_destroy(void* comm);
+int pg_allreduce_sum_f32(void* comm, float* buf, int64_t count, pg_stream_t stream);
 
 /* Utility: async fill with zero bytes.                                                         */
 int pg_zero(void* p, int64_t bytes, pg_stream_t stream);

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class PgganLibraryError(RuntimeError):
@@ -21,7 +21,8 @@ L = ctypes.c_int64
 F = ctypes.c_float
 D = ctypes.c_double
 
-# name -> argtypes (stream is always the last void*).  Mirrors include/pggan_hip.h 1:1.
+# name -> argtypes (stream is always the last void*).  Mirrors include/pggan_hip.h 1:1; the thread-local diagnostic
+# exports of include/pggan_hip_debug.h are listed in DEBUG_SIGNATURES.
 SIGNATURES = {
     'pg_abi_version': [],
     'pg_conv2d_nhwc': [P, P, P, P, P, I, I, I, I, I, I, I, I, F, F, F, P],
@@ -35,13 +36,8 @@ SIGNATURES = {
     'pg_wino_transform_weights': [P, P, I, I, P],
     'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P],
     'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
-    'pg_debug_last_wino_kernel': [],
     'pg_conv2d_wgrad_wino_nhwc': [P, P, P, P, I, I, I, I, I, I, F, P],
-    'pg_debug_last_wino_wgrad_kernel': [],
-    'pg_debug_set_wino': [I],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
-    'pg_debug_last_conv_kernel': [],
-    'pg_debug_set_tuning': [I, I],
     'pg_pack_dgrad_weights': [P, P, I, I, I, P],
     'pg_pack_dgrad_weights_batched': [P, P, I, P, P, P, P, P],
     'pg_fromrgb_fwd': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
@@ -74,6 +70,21 @@ SIGNATURES = {
     'pg_image_grid_u8': [P, P, I, I, I, I, I, F, F, P],
     'pg_pyramid_level_u8': [P, P, L, I, I, I, F, F, P],
     'pg_zero': [P, L, P],
+    # gradient exchange (RCCL bound at run time inside the library)
+    'pg_rccl_version': [P],
+    'pg_comm_unique_id': [P],
+    'pg_comm_init_rank': [P, I, P, I],
+    'pg_comm_info': [P, P, P],
+    'pg_comm_destroy': [P],
+    'pg_allreduce_sum_f32': [P, P, L, P],
+}
+
+DEBUG_SIGNATURES = {
+    'pg_debug_last_conv_kernel': [],
+    'pg_debug_last_wino_kernel': [],
+    'pg_debug_last_wino_wgrad_kernel': [],
+    'pg_debug_set_tuning': [I, I],
+    'pg_debug_set_wino': [I],
 }
 
 _lib = None
@@ -92,7 +103,7 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise PgganLibraryError('cannot load %s: %s' % (LIB_PATH, e))
-    for name, argtypes in SIGNATURES.items():
+    for name, argtypes in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError:
@@ -107,7 +118,7 @@ def load():
 
 
 _ERR = {-1: 'PG_E_ARG (bad dimension / null pointer)', -2: 'PG_E_ALIGN (channel count / alignment)',
-        -3: 'PG_E_UNSUP (unsupported configuration)'}
+        -3: 'PG_E_UNSUP (unsupported configuration)', -4: 'PG_E_NOLIB (no RCCL library could be loaded)'}
 
 
 class Unsupported(RuntimeError):
@@ -116,7 +127,8 @@ class Unsupported(RuntimeError):
 
 def check(rc, name):
     if rc != 0:
-        raise (Unsupported if rc == -3 else RuntimeError)('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
+        what = _ERR.get(rc) or ('RCCL ncclResult_t %d' % (-16 - rc) if rc <= -16 else 'hipError_t %d' % rc)
+        raise (Unsupported if rc == -3 else RuntimeError)('%s failed: %s' % (name, what))
 
 
 def call(name, *args):

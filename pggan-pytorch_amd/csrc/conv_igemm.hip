@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
     for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int n = 0; n < WN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};                  // second accumulation chain of the single-tile variants
 
     const int nchunks = p.Cin / KC;
     const int cper = (nchunks + p.ksplit - 1) / p.ksplit;
@@ -229,17 +230,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
             // next to their first use and every tap starts with an exposed LDS round trip
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < VEC; ++s)
+            for (int s = 0; s < VEC; ++s) {
+                if constexpr (WM * WN == 1) {
+                    // one output tile per wave: alternate two accumulators so that two MFMAs on the same accumulator are
+                    // never adjacent (32-cycle issue, 40-cycle dependent latency, ~43 extra with anything in between)
+                    if (s & 1) acc_odd = MFMA16(a[cur][0][s], b[cur][0][s], acc_odd);
+                    else acc[0][0] = MFMA16(a[cur][0][s], b[cur][0][s], acc[0][0]);
+                } else {
 #pragma unroll
-                for (int m = 0; m < WM; ++m)
+                    for (int m = 0; m < WM; ++m)
 #pragma unroll
-                    for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(a[cur][m][s], b[cur][n][s], acc[m][n]);
+                        for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(a[cur][m][s], b[cur][n][s], acc[m][n]);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #if PG_EXP != 1
         __syncthreads();
 #endif
     }
+    if constexpr (WM * WN == 1 && VEC > 1) acc[0][0] += acc_odd;
 
     // epilogue: lane holds couts cb..cb+3 of pixel j
     if (p.pn_r != nullptr) {                     // conv -> bias -> LeakyReLU -> PixelNorm; the workgroup holds every cout of its pixels
@@ -1303,6 +1313,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_kernel(ConvP p)
     f32x4 acc[WN];
 #pragma unroll
     for (int n = 0; n < WN; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nsuper = (p.Cin + 63) >> 6;
     const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x, (unsigned)((size_t)p.N * p.Hin * p.Win * p.Cin * 4));    // small-M layers: a few MB
@@ -1340,13 +1351,20 @@ __global__ __launch_bounds__(256) void conv_ksplit_kernel(ConvP p)
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if constexpr (WN == 1) {                      // two accumulation chains: no adjacent dependent MFMAs
+                    if (s4 & 1) acc_odd = MFMA16(a[cur][s4], b[cur][0][s4], acc_odd);
+                    else acc[0] = MFMA16(a[cur][s4], b[cur][0][s4], acc[0]);
+                } else {
 #pragma unroll
-                for (int n = 0; n < WN; ++n) acc[n] = MFMA16(a[cur][s4], b[cur][n][s4], acc[n]);
+                    for (int n = 0; n < WN; ++n) acc[n] = MFMA16(a[cur][s4], b[cur][n][s4], acc[n]);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
+    if constexpr (WN == 1) acc[0] += acc_odd;
     // ---- sum the four K slices through LDS; wave 0 finishes
     float* red = lds;                                           // [3][WN][64][4]
     if (wave > 0) {

@@ -34,7 +34,17 @@ struct WinoP {
     float* yup; const float* upmask; float up_mul;
     int mask_bytes, y_bytes;                   // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES, pggan_hip.h)
     unsigned char* ysigns;                     // PG_FLAG_SIGNS_OUT
+#ifdef PG_WINO_TRACE
+    unsigned long long* trace;                 // [workgroup][wave][chunk][8] s_memtime stamps (tools/exp/wino_trace.py)
+#endif
 };
+
+#ifdef PG_WINO_TRACE
+#define PG_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (p.trace && lane == 0 && blockIdx.x < 1024 && (k0 / KC) < 8) \
+    p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + (k0 / KC)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PG_STAMP(i) do { } while (0)
+#endif
 
 template <int VEC> struct WRow { static constexpr int value = VEC == 4 ? 24 : 12; };   // LDS row stride (floats), conflict-free b128 / b64
 constexpr int XMAX = 400;                      // halo pixels per workgroup: 18x18 (8x8 tiles) .. 4 x 10x10 (8x8 images)
@@ -88,6 +98,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
+#ifdef PG_WINO_TRACE
+    if (p.trace && lane == 0 && blockIdx.x < 1024) p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + 0) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
     // 1-D grid, cout blocks minor: after the XCD remap (bufload.h) the workgroups that share an input region (same tiles,
     // different couts) run back to back on ONE XCD, so the region comes from HBM once and from that L2 afterwards; each XCD
     // walks a contiguous range of tile blocks (halo rows / columns shared with the neighbours stay in its L2 too).
@@ -158,12 +171,16 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     };
     fetch(0);
     for (int k0 = 0; k0 < p.Cin; k0 += KC) {
+        PG_STAMP(0);
 #pragma unroll
         for (int i = 0; i < UPT; ++i) *reinterpret_cast<float4*>(ut + udst[i]) = ureg[i];
 #pragma unroll
         for (int i = 0; i < XPT; ++i) if (xdst[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
+        PG_STAMP(1);
         __syncthreads();
+        PG_STAMP(2);
         if (k0 + KC < p.Cin) fetch(k0 + KC);
+        PG_STAMP(3);
 
         // the patch as pairs of floats (the compiler still emits scalar v_add_f32: forcing v_pk_add_f32 through inline asm
         // needs an s_nop per instruction for the VALU->MFMA hazard the assembler cannot see, and measured slower)
@@ -192,13 +209,30 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
                 d[a][0][h] = t0; d[a][1][h] = t1; d[a][2][h] = t2; d[a][3][h] = t3;
             }
         }
+        PG_STAMP(4);
+        // MFMA order: the four Winograd positions of a row are interleaved, so that two MFMAs on the SAME accumulator are
+        // never adjacent (v_mfma_f32_16x16x4_f32 issues every 32 cycles but a dependent accumulate needs 40, and any other
+        // instruction between two dependent MFMAs costs ~43 more: MI355X_MICROARCH.md "Per-instruction cycle constants").
+        fragv af[2][4];
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            const fragv a = *reinterpret_cast<const fragv*>(ut + (xi * 16 + li) * KCP + VEC * kk);
+        for (int j = 0; j < 4; ++j) af[0][j] = *reinterpret_cast<const fragv*>(ut + (j * 16 + li) * KCP + VEC * kk);
 #pragma unroll
-            for (int s4 = 0; s4 < VEC; ++s4) acc[xi] = MFMA16(a[s4], d[xi >> 2][xi & 3][s4 >> 1][s4 & 1], acc[xi]);
+        for (int g = 0; g < 4; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    af[nxt][j] = *reinterpret_cast<const fragv*>(ut + (((g + 1) * 4 + j) * 16 + li) * KCP + VEC * kk);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < VEC; ++s4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[4 * g + j] = MFMA16(af[cur][j][s4], d[g][j][s4 >> 1][s4 & 1], acc[4 * g + j]);
         }
+        PG_STAMP(5);
         __syncthreads();
+        PG_STAMP(6);
     }
 
     // ---- output transform Y = A^T M A (lane-local), then the fused epilogue on the 2x2 outputs
@@ -282,6 +316,10 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
         *reinterpret_cast<float4*>(p.ypool + poff) = v;
     }
+#ifdef PG_WINO_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.trace && lane == 0 && blockIdx.x < 1024) p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + 1) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // all layers of a network in one launch (layer l: w at wbase + woff[l], u at ubase + uoff[l])
@@ -327,11 +365,17 @@ inline int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 thread_local char g_wino_last[64] = "";
+#ifdef PG_WINO_TRACE
+thread_local unsigned long long* g_wino_trace = nullptr;
+#endif
 thread_local int g_wino_vec = 4;               // K-chunk = 4*vec channels (pg_debug_set_wino)
 
 }  // namespace
 
 extern "C" const char* pg_debug_last_wino_kernel(void) { return g_wino_last; }
+#ifdef PG_WINO_TRACE
+extern "C" int pg_debug_wino_trace(void* buf) { g_wino_trace = (unsigned long long*)buf; return 0; }
+#endif
 extern "C" int pg_debug_set_wino(int vec) { if (vec != 2 && vec != 4) return PG_E_ARG; g_wino_vec = vec; return 0; }
 
 extern "C" int pg_wino_transform_weights(const float* w, float* u, int Cout, int Cin, pg_stream_t stream)
@@ -376,6 +420,9 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
         return PG_E_UNSUP;
     WinoP p;
     p.x = x; p.u = u; p.bias = bias; p.mask = mask; p.y = y;
+#ifdef PG_WINO_TRACE
+    p.trace = g_wino_trace;
+#endif
     const int flags = ups;                                  // PG_FLAG_* (pggan_hip.h)
     ups = flags & PG_FLAG_UPSAMPLE;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups;

@@ -277,6 +277,18 @@ def wait_pending(net):
         net._pending = None
 
 
+def _grads_ready(net, layers):
+    """Tell the gradient exchange (``parallel.GradExchange``, installed by ``Trainer`` as ``net._grad_hook`` under data
+    parallelism) that every weight-gradient launch of ``layers`` has been enqueued: their spans of the flat gradient
+    buffer can start travelling while the sweep goes on."""
+    hook = getattr(net, '_grad_hook', None)
+    if hook is not None:
+        side = None
+        if ASYNC_WGRAD and net._flat_param.is_cuda:
+            side = _SIDE.get(torch.cuda.current_device())
+        hook(layers, side)
+
+
 def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False):
     """Weight (and bias) gradient of one conv layer on the side stream.  The wide 3x3 layers take the Winograd form
     (2.25x fewer MFMAs, 1.3-1.7x faster from 16x16 up, 16-channel sides included); the 8-channel layers and the
@@ -307,6 +319,7 @@ def generator_forward(G, z, save=False, out=None):
     """reference network.py:118-139.  z [N,latent] -> NCHW image [N,C,r,r] (written into ``out``)."""
     wait_pending(G)
     ops.require_gpu()
+    G._sync_version()                 # also notice torch-side updates (torch.optim.*, load_state_dict) before any derived weight is used
     z = _check_dev(z, 'latents')
     N, L = z.shape
     if L != G.latent_size or L % 4:
@@ -388,6 +401,7 @@ def generator_backward(G, ctx, g_out):
                                 1 - alpha, down=True)
             g_extra = ops.torgb_bwd_data(g_out, pt.conv.weight.data, N, C, H // 2, H // 2, (1 - alpha) * pt.c, down=True)
             active.append(pt)
+    _grads_ready(G, active[2:])
     for rec in reversed(ctx['recs']):
         blk, H = rec['blk'], rec['H']
         c1, c2 = blk.c1, blk.c2
@@ -401,11 +415,13 @@ def generator_backward(G, ctx, g_out):
         g = _dgrad_pool(G, gz1, c1, N, H, other=g_extra, a=4.0, b=1.0)
         g_extra = None
         active += [c1, c2]
+        _grads_ready(G, [c1, c2])
     gz2 = ops.pixelnorm_lrelu_bwd(g, ctx['y2'], ctx['r2'], b0.c2.slope, inplace=True)
     _wgrad(ctx['y1'], gz2, b0.c2, N, 4)
     g1 = _dgrad(G, gz2, b0.c2, N, 4)
     gz1 = ops.pixelnorm_lrelu_bwd(g1, ctx['y1'], ctx['r1'], b0.c1.slope, inplace=True)
     _wgrad(ctx['zn'].view(N, 1, 1, -1), gz1, b0.c1, N, 1)
+    _grads_ready(G, [b0.c1, b0.c2])
     return active
 
 
@@ -416,6 +432,7 @@ def d_forward(D, x, groups=1):
     """reference network.py:225-240 on a batch of ``groups`` independent minibatches stacked along
     N (minibatch-stddev is evaluated per group).  Returns (scores [NB], ctx with every activation)."""
     wait_pending(D)
+    D._sync_version()
     NB, C, r, _ = x.shape
     depth, alpha = int(D.depth), float(D.alpha)
     if r != 4 * 2 ** depth or C != D.num_channels:
@@ -622,7 +639,22 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                 g = None                            # consumed through ``carry`` by the next (finer) block
             else:
                 g = ops.avgpool2_bwd(gin, _mask32(prev['a2']), 1.0, pc2.slope)
+        if full:
+            _grads_ready(D, _d_block_done(D, recs, idx, alpha))
     return gimg, adj
+
+
+def _d_block_done(D, recs, idx, alpha):
+    """Layers whose weight gradients are complete once block ``idx`` of the batched backward sweep has been processed
+    (the tangent pass ran before the sweep, so nothing else accumulates into them)."""
+    rec = recs[idx]
+    blk = rec['blk']
+    done = [blk.c1, blk.c2]
+    if rec['last']:
+        done.append(D._lin_layer)
+    if rec['first'] or (recs[idx - 1]['first'] and alpha < 1.0):
+        done.append(blk.fromRGB)                 # the entry block's fromRGB / the fade-in branch's fromRGB
+    return done
 
 
 def _pn_bwd(gy, y, r, slope, nh, inj):
@@ -730,6 +762,8 @@ def _d_backward_pn(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=Non
                 pending_prev = (gpf, pfr)
             else:
                 g = ops.avgpool2_bwd(gin, None, 1.0)
+        if full:
+            _grads_ready(D, _d_block_done(D, recs, idx, alpha))
     return gimg, adj
 
 
@@ -810,6 +844,24 @@ def d_active_params(D, depth, alpha):
     return layers
 
 
+def d_exchange_layers(D, depth, alpha):
+    """Everything that receives a gradient in a D step at (depth, alpha): the active conv / fromRGB layers + linear."""
+    D._ensure_buffers()
+    return d_active_params(D, depth, alpha) + [D._lin_layer]
+
+
+def g_exchange_layers(G, depth, alpha):
+    """Layers that receive a gradient in a G step at (depth, alpha) (the ``active`` list of generator_backward)."""
+    G._ensure_buffers()
+    layers = [G.block0.c1, G.block0.c2]
+    for i in range(depth):
+        layers += [G.blocks[i].c1, G.blocks[i].c2]
+    layers.append(G.blocks[depth - 1].toRGB if depth > 0 else G.block0.toRGB)
+    if depth > 0 and alpha < 1.0:
+        layers.append(G.blocks[depth - 2].toRGB if depth > 1 else G.block0.toRGB)
+    return layers
+
+
 def discriminator_forward(D, x):
     """Plain ``D(x)`` (network.py:225-240): NCHW image batch -> scores [N,1]."""
     ops.require_gpu()
@@ -858,6 +910,8 @@ def d_loss_backward(state, scale=1.0):
     D, ctx, N = state['D'], state['ctx'], state['N']
     D._ensure_buffers()
     ops.zero_(D._flat_grad)
+    if scale != 1.0:
+        D._grad_hook = None                      # the gradients are rescaled after the sweep: nothing may travel early
     hvp = d_tangent_wgrad(D, state['sub'], state['adj'], state['u'])
     gs = state['gscore'][:2 * N]
     d_backward(D, ctx, gs, full=True, want_gimg=False, hvp=(2 * N,) + hvp)
@@ -889,6 +943,8 @@ def g_loss_backward(state, scale=1.0):
     G, D = state['G'], state['D']
     G._ensure_buffers()
     ops.zero_(G._flat_grad)
+    if scale != 1.0:
+        G._grad_hook = None
     gimg, _ = d_backward(D, state['dctx'], state['gscore'], full=False, want_gimg=True)
     active = generator_backward(G, state['gctx'], gimg)
     _join_side()

@@ -50,7 +50,7 @@ def _g_active_conv(G, depth):
 
 def d_step(D, G, real, latents, mix, lam, eps, target):
     """Graphed ``d_loss_forward`` + ``d_loss_backward``.  Returns (d_cost, d_real_loss, d_fake_loss)."""
-    key = ('D', id(D), id(G), int(D.depth), tuple(real.shape), tuple(latents.shape), float(lam), float(eps), float(target))
+    key = ('D', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(D.depth), tuple(real.shape), tuple(latents.shape), float(lam), float(eps), float(target))
     g = _CACHE.get(key)
     if g is None:
         g = _CACHE[key] = _Graphed()
@@ -67,18 +67,20 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
             return body()
         torch.cuda.synchronize()
         _force_repack(D, _d_active_conv(D, int(D.depth)))
+        _force_repack(G, _g_active_conv(G, int(G.depth)))     # the captured body runs G(z) on G's derived (Winograd) weights
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             g.static_out = body()
         g.graph = graph
     g.graph.replay()
     engine._assign_grads(D, engine.d_active_params(D, int(D.depth), 1.0), linear=True)
-    return g.static_out
+    # the static outputs are overwritten by the next replay: hand out copies (a plugin may keep loss tensors)
+    return tuple(t.clone() for t in g.static_out)
 
 
 def g_step(G, D, latents):
     """Graphed ``g_loss_forward`` + ``g_loss_backward``.  Returns g_cost."""
-    key = ('G', id(D), id(G), int(G.depth), tuple(latents.shape))
+    key = ('G', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(G.depth), tuple(latents.shape))
     g = _CACHE.get(key)
     if g is None:
         g = _CACHE[key] = _Graphed()
@@ -101,4 +103,4 @@ def g_step(G, D, latents):
         g.graph = graph
     g.graph.replay()
     engine._assign_grads(G, g.static_out[1])
-    return g.static_out[0]
+    return g.static_out[0].clone()

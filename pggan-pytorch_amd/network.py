@@ -162,6 +162,14 @@ class DLastBlock(nn.Module):
         self.c2 = PGConv2d(ch_in, ch_out, 4, 1, 0, **layer_settings)
 
 
+class _GradViews(object):
+    """(_gw, _gb) pair of a parameter group that is not a PGConv2d (the final nn.Linear): lets the gradient exchange
+    treat it like a layer."""
+
+    def __init__(self, gw, gb):
+        self._gw, self._gb = gw, gb
+
+
 class _FlatParamsMixin(object):
     """All parameters of the network live in one flat fp32 buffer (+ one flat gradient buffer)."""
 
@@ -253,6 +261,7 @@ class _FlatParamsMixin(object):
             ow, ob = byptr[id(self.linear.weight)], byptr[id(self.linear.bias)]
             self._lin_gw = self._flat_grad[ow:ow + self.linear.weight.numel()].view(self.linear.weight.shape)
             self._lin_gb = self._flat_grad[ob:ob + 1].view(1)
+            self._lin_layer = _GradViews(self._lin_gw, self._lin_gb)
 
     def zero_grad(self, set_to_none=True):
         """torch>=2 semantics (grads -> None) so that inactive parameters are skipped by Adam, as
@@ -280,7 +289,8 @@ class _FlatParamsMixin(object):
         d['_derived_ver'] = None
         d['_pending'] = None
         d['_skip_join'] = False
-        d['_lin_gw'] = d['_lin_gb'] = None
+        d['_lin_gw'] = d['_lin_gb'] = d['_lin_layer'] = None
+        d['_grad_hook'] = d['_grad_exchange'] = None
         return d
 
     def __setstate__(self, state):

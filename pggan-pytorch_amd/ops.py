@@ -81,11 +81,6 @@ def wino_transform_weights_batched(flat_w, flat_u, layers):
               ctypes.cast(uoff, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), ctypes.cast(ci, ctypes.c_void_p), _stream())
 
 
-FLAG_UPSAMPLE, FLAG_MASK_BYTES, FLAG_Y_BYTES, FLAG_SIGNS_OUT = 1, 2, 4, 8     # PG_FLAG_* of include/pggan_hip.h
-Unsupported = _lib.Unsupported
-
-
-
 def signbytes_to_mask(b):
     """uint8 sign bytes [..., C/4] -> fp32 +1/-1 mask [..., C] (fallback when an entry point does not take sign bytes)."""
     m = torch.empty(tuple(b.shape[:-1]) + (4 * b.shape[-1],), device=b.device, dtype=torch.float32)

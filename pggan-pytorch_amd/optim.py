@@ -37,10 +37,33 @@ class FusedAdam(torch.optim.Optimizer):
         return self
 
     def _flat_state(self, gi, group):
-        if gi in self._flat:
-            return self._flat[gi]
         params = group['params']
         base = min(p.data_ptr() for p in params)
+        if gi in self._flat:
+            if self._flat[gi][0] == base:
+                return self._flat[gi]
+            return self._rebase(gi, group, base)          # the network was re-flattened (.to() / .cuda() / .float())
+        return self._new_flat_state(gi, group, base)
+
+    def _rebase(self, gi, group, base):
+        """The parameters moved to a new flat buffer: rebuild the flat moments at the new location and carry the old
+        ones over (per-parameter offsets inside the buffer are unchanged by a re-flatten)."""
+        old_base, m_old, v_old = self._flat.pop(gi)
+        entry = self._new_flat_state(gi, group, base)
+        _, m_new, v_new = entry
+        for p in group['params']:
+            st = self.state.get(p)
+            if not st:
+                continue
+            off = (p.data_ptr() - base) // 4
+            for key, flat in (('exp_avg', m_new), ('exp_avg_sq', v_new)):
+                view = flat[off:off + p.numel()].view(p.shape)
+                view.copy_(st[key].to(view.device))
+                st[key] = view
+        return entry
+
+    def _new_flat_state(self, gi, group, base):
+        params = group['params']
         top = max(p.data_ptr() + _padded(p.numel()) * 4 for p in params)
         total = (top - base) // 4
         if total != sum(_padded(p.numel()) for p in params):

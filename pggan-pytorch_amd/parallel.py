@@ -1,16 +1,30 @@
 """Data-parallel sharding of the train step: one process per GPU, RCCL over xGMI.
 
-The reference has no distributed code; the sharding is defined by BASELINE.json's north_star and
-SURVEY.md §8e: each rank runs the full step on its own minibatch (DepthManager's minibatch size is
-PER RANK — weak scaling), minibatch-stddev is evaluated on the local shard, and there is exactly one
-exchange step per network per iteration: a SUM all-reduce of the live spans of the network's flat gradient buffer
-(``backend='nccl'`` is RCCL on ROCm); the 1/world_size is folded into the fused Adam
-(``FusedAdam.grad_scale``).  One or two collectives of up to 73 MB per network instead of one per tensor:
-xGMI is point-to-point, so few large messages are what keeps the links busy."""
+The reference has no distributed code; the sharding is defined by BASELINE.json's north_star and SURVEY.md §8e: each
+rank runs the full step on its own minibatch (DepthManager's minibatch size is PER RANK — weak scaling), minibatch-stddev
+is evaluated on the local shard, and the only exchange is a SUM all-reduce of the live spans of each network's flat
+gradient buffer (after reference trainer.py:98 for D, after :111 for G); the 1/world_size is folded into the fused Adam
+(``FusedAdam.grad_scale``) or, for a foreign optimizer, applied right after the reduction.
+
+Data plane: the library's own RCCL communicator, driven through the C-ABI (``pg_comm_init_rank`` /
+``pg_allreduce_sum_f32``, include/pggan_hip.h) on a dedicated HIP stream.  ``torch.distributed`` is the control plane
+only: rendezvous, the broadcast of the communicator id and of the initial weights, barriers.  (On a CPU-only host — the
+world-size-2 gloo tests — the reduction itself goes through ``torch.distributed`` as well.)
+
+Overlap: the backward sweeps of ``engine`` report every block whose weight gradients have been enqueued
+(``net._grad_hook``); ``GradExchange`` collects them into buckets of ~``BUCKET_BYTES`` and issues each bucket's
+all-reduce on the exchange stream behind an event of the weight-gradient stream, so the 512-channel blocks of D (85 % of
+the bytes, finished in the first quarter of the sweep) travel under the rest of the backward pass and only the last
+bucket is exposed.  xGMI is point-to-point (7 links per GPU): a few multi-MB messages keep the links busy, hence
+buckets of tens of MB rather than one collective per tensor."""
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
+
+BUCKET_BYTES = int(os.environ.get('PGGAN_DP_BUCKET_MB', '16')) << 20
+MERGE_GAP = 1 << 16        # spans closer than 256 KB travel in one collective (the gap is zeros: inactive layers)
 
 
 class DataParallel(object):
@@ -22,6 +36,39 @@ class DataParallel(object):
         self.rank = dist.get_rank()
         self.world_size = dist.get_world_size()
         self.device = device
+        self.comm = None                      # ncclComm_t of the library's communicator (GPU only)
+        self.comm_ranks = 0
+        self._stream = None
+        self.stats = dict(collectives=0, bytes=0)
+        if torch.cuda.is_available() and os.environ.get('PGGAN_DP_TORCH_ALLREDUCE', '0') != '1':
+            self._init_comm()
+
+    # ---------------------------------------------------------------- bootstrap
+    def _init_comm(self):
+        """RCCL communicator of the C-ABI: rank 0 draws the id, the control plane carries it, every rank joins."""
+        from . import _lib
+        lib = _lib.load()
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.pg_comm_unique_id(ident), 'pg_comm_unique_id')
+        box = [ident.raw if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ident = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        _lib.check(lib.pg_comm_init_rank(ctypes.byref(comm), self.world_size, ident, self.rank), 'pg_comm_init_rank')
+        n, r = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.pg_comm_info(comm, ctypes.byref(n), ctypes.byref(r)), 'pg_comm_info')
+        if n.value != self.world_size or r.value != self.rank:
+            raise RuntimeError('RCCL communicator reports rank %d of %d, expected %d of %d'
+                               % (r.value, n.value, self.rank, self.world_size))
+        self.comm, self.comm_ranks = comm, n.value
+
+    def close(self):
+        if self.comm is not None:
+            from . import _lib
+            torch.cuda.synchronize()
+            _lib.load().pg_comm_destroy(self.comm)
+            self.comm = None
 
     @staticmethod
     def from_env(force=False):
@@ -38,6 +85,8 @@ class DataParallel(object):
             os.environ['WORLD_SIZE'] = '1'
         local = int(os.environ.get('LOCAL_RANK', '0'))
         if torch.cuda.is_available():
+            if local >= torch.cuda.device_count():
+                raise RuntimeError('rank with LOCAL_RANK %d but only %d GPU(s) are visible' % (local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
         return DataParallel()
 
@@ -58,28 +107,143 @@ class DataParallel(object):
                 m.c = float(c)
             net.mark_params_changed()
 
-    def all_reduce_flat(self, flat):
-        """SUM all-reduce of one flat fp32 buffer (averaging happens in the optimizer)."""
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    # ---------------------------------------------------------------- data plane
+    def exchange_stream(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        return self._stream
+
+    def all_reduce_flat(self, flat, stream=None):
+        """SUM all-reduce of one flat fp32 buffer, in place (averaging happens in the optimizer).  On the device: one
+        ``pg_allreduce_sum_f32`` on ``stream`` (default: the current stream)."""
+        self.stats['collectives'] += 1
+        self.stats['bytes'] += flat.numel() * 4
+        if self.comm is not None and flat.is_cuda:
+            from . import _lib
+            if flat.dtype != torch.float32 or not flat.is_contiguous():
+                raise RuntimeError('all_reduce_flat expects a contiguous float32 buffer')
+            s = stream if stream is not None else torch.cuda.current_stream()
+            _lib.call('pg_allreduce_sum_f32', self.comm, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
+                      ctypes.c_void_p(s.cuda_stream))
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         return flat
 
-    def all_reduce_grads(self, net):
-        """SUM all-reduce of the gradients of the layers that are live at the current growth stage: the parameters
-        whose ``.grad`` the backward pass attached (a function of depth / alpha only, so every rank derives the same
-        ranges) form a few contiguous spans of the flat gradient buffer — at 4x4 that is 26 MB instead of the whole
-        73 MB buffer, at 1024x1024 everything, in one or two collectives."""
+    def all_reduce_grads(self, net, average=False):
+        """Exchange of one network's gradients.  The parameters whose ``.grad`` the backward pass attached (a function of
+        depth / alpha only, so every rank derives the same ranges) form a few contiguous spans of the flat gradient
+        buffer — at 4x4 that is 26 MB instead of the whole 73 MB.  Spans a ``GradExchange`` already sent while the
+        backward pass was still running are not sent again; the current stream then waits for the exchange stream.
+        ``average``: also scale by 1/world (for optimizers without a gradient pre-scale)."""
         if net._flat_grad is None:
             raise RuntimeError('all_reduce_grads called before any backward pass')
         flat = net._flat_grad
-        for s, e in active_grad_spans(net):
-            self.all_reduce_flat(flat[s:e])
+        ex = getattr(net, '_grad_exchange', None)
+        if ex is not None and ex.started:
+            ex.finish()
+        else:
+            for s, e in active_grad_spans(net):
+                self.all_reduce_flat(flat[s:e])
+        if average and self.world_size > 1:
+            for s, e in active_grad_spans(net):
+                flat[s:e].mul_(self.grad_scale)
         return flat
 
     def barrier(self):
         dist.barrier()
 
 
-MERGE_GAP = 1 << 16        # spans closer than 256 KB travel in one collective (the gap is zeros: inactive layers)
+class GradExchange(object):
+    """Bucketed, overlapped exchange of one network's gradients during its backward sweep.
+
+    ``begin(active_layers)`` before the sweep; the sweep calls ``ready(layers)`` whenever the weight gradients of some
+    layers have all been enqueued; ``finish()`` sends what is left and makes the current stream wait for the exchange
+    stream.  A bucket is a run of layers that are neighbours in the flat gradient buffer among the ACTIVE layers (what
+    lies between two active neighbours belongs to layers that are not live at this growth stage: zeros), so no
+    collective ever covers a gradient that is still being accumulated."""
+
+    def __init__(self, dp, net, bucket_bytes=None):
+        self.dp, self.net = dp, net
+        self.bucket_bytes = BUCKET_BYTES if bucket_bytes is None else bucket_bytes
+        self.started = False
+        self.sent_bytes = 0
+        self.buckets = 0
+
+    @staticmethod
+    def _span(net, layer):
+        base = net._flat_grad.data_ptr()
+        lo = min(layer._gw.data_ptr(), layer._gb.data_ptr())
+        hi = max(layer._gw.data_ptr() + layer._gw.numel() * 4, layer._gb.data_ptr() + layer._gb.numel() * 4)
+        return (lo - base) // 4, (hi - base) // 4
+
+    def begin(self, active_layers):
+        net = self.net
+        spans = sorted((self._span(net, m) + (id(m),)) for m in active_layers)
+        self.order = {lid: i for i, (_, _, lid) in enumerate(spans)}
+        self.spans = [(s, e) for s, e, _ in spans]
+        self.state = [0] * len(spans)            # 0 pending, 1 ready, 2 sent
+        self.ready_bytes = 0
+        self.started = True
+        self.sent_bytes = self.buckets = 0
+        self.side = None
+
+    def ready(self, layers, side_stream=None):
+        """``layers``: every gradient of theirs has been enqueued (on ``side_stream`` when the weight-gradient stream is
+        in use, else on the current stream)."""
+        if not self.started:
+            return
+        self.side = side_stream
+        for m in layers:
+            i = self.order.get(id(m))
+            if i is not None and self.state[i] == 0:
+                self.state[i] = 1
+                self.ready_bytes += (self.spans[i][1] - self.spans[i][0]) * 4
+        if self.ready_bytes >= self.bucket_bytes:
+            self._flush()
+
+    def _flush(self):
+        flat = self.net._flat_grad
+        runs, i, n = [], 0, len(self.spans)
+        while i < n:
+            if self.state[i] != 1:
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and self.state[j + 1] == 1:
+                j += 1
+            runs.append((self.spans[i][0], self.spans[j][1]))
+            for k in range(i, j + 1):
+                self.state[k] = 2
+            i = j + 1
+        self.ready_bytes = 0
+        if not runs:
+            return
+        if flat.is_cuda:
+            ex = self.dp.exchange_stream()
+            src = self.side if self.side is not None else torch.cuda.current_stream()
+            ex.wait_stream(src)                   # behind the weight-gradient launches enqueued so far
+            with torch.cuda.stream(ex):
+                for s, e in runs:
+                    self.dp.all_reduce_flat(flat[s:e], stream=ex)
+        else:
+            for s, e in runs:
+                self.dp.all_reduce_flat(flat[s:e])
+        self.buckets += len(runs)
+        self.sent_bytes += sum(e - s for s, e in runs) * 4
+
+    def finish(self):
+        """Send the remaining layers (those never reported count as ready now: the sweep is over) and join."""
+        if not self.started:
+            return
+        for i, st in enumerate(self.state):
+            if st == 0:
+                self.state[i] = 1
+        if self.net._flat_grad.is_cuda:
+            self.side = None                      # the caller's stream is already behind every gradient launch
+        self._flush()
+        if self.net._flat_grad.is_cuda:
+            torch.cuda.current_stream().wait_stream(self.dp.exchange_stream())
+        self.started = False
 
 
 def active_grad_spans(net):

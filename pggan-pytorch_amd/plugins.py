@@ -12,105 +12,120 @@ from glob import glob
 
 
 class Plugin(object):
+    """The plugin protocol ``Trainer`` dispatches on: ``trigger_interval`` = list of (period, unit) pairs, ``register(trainer)``,
+    and one method per unit it listens on."""
+
     def __init__(self, interval=None):
-        if interval is None:
-            interval = []
-        self.trigger_interval = interval
+        self.trigger_interval = [] if interval is None else interval
 
     def register(self, trainer):
         raise NotImplementedError
 
 
+_STAT_FMT = ['{val:.2f}']
+
+
+def growth_stage(cur_nimg, lod_training_nimg, lod_transition_nimg, max_depth):
+    """The progressive-growing schedule as a pure integer function of the images shown so far (behaviour of reference
+    plugins.py:58-63, bit for bit): time is cut into cycles of ``stabilise`` (lod_training_nimg) + ``fade``
+    (lod_transition_nimg) images; the stage index is the number of completed cycles plus the number of whole
+    ``stabilise`` spans already inside the current one, clamped to ``max_depth``; while a new stage is still un-clamped
+    and past its stabilise span, alpha is the position inside the remaining span over ``fade`` (one IEEE double division),
+    otherwise exactly 1.0.  Returns (depth, alpha)."""
+    cycle, inside = divmod(cur_nimg, lod_training_nimg + lod_transition_nimg)
+    spans, position = divmod(inside, lod_training_nimg)
+    stage = cycle + spans
+    depth = stage if stage < max_depth else max_depth
+    fading = spans > 0 and stage == depth
+    return depth, (position / lod_transition_nimg if fading else 1.0)
+
+
 class DepthManager(Plugin):
-    """reference plugins.py:13-81 (same constructor, same stats keys)."""
+    """Growth-stage controller (reference plugins.py:13-81: same constructor arguments, same trainer/dataset fields
+    written, same ``stats`` keys).  On a stage change it rebuilds the data iterator and the latent generator for the
+    stage's minibatch size and sets the tick length; alpha is pushed to D, G and the dataset whenever it changes."""
 
-    def __init__(self,
-                 create_dataloader_fun,
-                 create_rlg,
-                 max_depth,
-                 minibatch_default=16,
-                 minibatch_overrides={6: 14, 7: 6, 8: 3},
-                 tick_kimg_default=20,
+    def __init__(self, create_dataloader_fun, create_rlg, max_depth, minibatch_default=16,
+                 minibatch_overrides={6: 14, 7: 6, 8: 3}, tick_kimg_default=20,
                  tick_kimg_overrides={3: 10, 4: 10, 5: 5, 6: 2, 7: 2, 8: 1},
-                 lod_training_nimg=100 * 1000,
-                 lod_transition_nimg=100 * 1000,
-                 max_lod=None,
-                 depth_offset=None):
+                 lod_training_nimg=100 * 1000, lod_transition_nimg=100 * 1000, max_lod=None, depth_offset=None):
         super(DepthManager, self).__init__([(1, 'iteration')])
-        self.minibatch_default = minibatch_default
-        self.minibatch_overrides = minibatch_overrides
-        self.tick_kimg_default = tick_kimg_default
-        self.tick_kimg_overrides = tick_kimg_overrides
-        self.create_dataloader_fun = create_dataloader_fun
-        self.create_rlg = create_rlg
-        self.lod_training_nimg = lod_training_nimg
-        self.lod_transition_nimg = lod_transition_nimg
-        self.trainer = None
-        self.depth = -1
-        self.alpha = -1
+        self.create_dataloader_fun, self.create_rlg = create_dataloader_fun, create_rlg
         self.max_depth = max_depth
-        self.max_lod = max_lod
-        self.depth_offset = depth_offset
+        self.minibatch_default, self.minibatch_overrides = minibatch_default, minibatch_overrides
+        self.tick_kimg_default, self.tick_kimg_overrides = tick_kimg_default, tick_kimg_overrides
+        self.lod_training_nimg, self.lod_transition_nimg = lod_training_nimg, lod_transition_nimg
+        self.max_lod, self.depth_offset = max_lod, depth_offset      # only for the 'lod' statistic of the original paper
+        self.trainer = None
+        self.depth = self.alpha = -1                                 # "nothing applied yet"
 
-    def register(self, trainer):
-        self.trainer = trainer
-        self.trainer.stats['minibatch_size'] = self.minibatch_default
-        self.trainer.stats['alpha'] = {'log_name': 'alpha', 'log_epoch_fields': ['{val:.2f}'], 'val': self.alpha}
-        if self.max_lod is not None and self.depth_offset is not None:
-            self.trainer.stats['lod'] = {'log_name': 'lod', 'log_epoch_fields': ['{val:.2f}'], 'val': self.lod}
-        self.iteration()
+    @property
+    def _reports_lod(self):
+        return self.max_lod is not None and self.depth_offset is not None
 
     @property
     def lod(self):
-        if self.max_lod is not None and self.depth_offset is not None:
-            return self.max_lod - self.depth_offset - self.depth - self.alpha + 1
-        return -1
+        return self.max_lod - self.depth_offset - self.depth - self.alpha + 1 if self._reports_lod else -1
 
     def schedule(self, cur_nimg):
-        """(depth, alpha) as a pure function of cur_nimg.  plugins.py:58-63."""
-        full_passes, remaining_nimg = divmod(cur_nimg, self.lod_training_nimg + self.lod_transition_nimg)
-        train_passes_rem, remaining_nimg = divmod(remaining_nimg, self.lod_training_nimg)
-        depth = min(self.max_depth, full_passes + train_passes_rem)
-        alpha = remaining_nimg / self.lod_transition_nimg \
-            if train_passes_rem > 0 and full_passes + train_passes_rem == depth else 1.0
-        return depth, alpha
+        return growth_stage(cur_nimg, self.lod_training_nimg, self.lod_transition_nimg, self.max_depth)
+
+    def register(self, trainer):
+        self.trainer = trainer
+        stats = trainer.stats
+        stats['minibatch_size'] = self.minibatch_default
+        stats['alpha'] = dict(log_name='alpha', log_epoch_fields=_STAT_FMT, val=self.alpha)
+        if self._reports_lod:
+            stats['lod'] = dict(log_name='lod', log_epoch_fields=_STAT_FMT, val=self.lod)
+        self.iteration()                                             # stage 0 is applied before the first step
+
+    def _enter_stage(self, depth):
+        tr = self.trainer
+        for target in (tr.D, tr.G):
+            target.depth = depth
+        tr.dataset.model_depth = depth
+        self.depth = depth
+        batch = self.minibatch_overrides.get(depth, self.minibatch_default)
+        tr.dataiter = iter(self.create_dataloader_fun(batch))
+        tr.random_latents_generator = self.create_rlg(batch)
+        tr.tick_duration_nimg = 1000 * self.tick_kimg_overrides.get(depth, self.tick_kimg_default)
+        tr.stats['minibatch_size'] = batch
+
+    def _set_alpha(self, alpha):
+        tr = self.trainer
+        for target in (tr.D, tr.G, tr.dataset):
+            target.alpha = alpha
+        self.alpha = alpha
 
     def iteration(self, *args):
-        depth, alpha = self.schedule(self.trainer.cur_nimg)
-        dataset = self.trainer.dataset
-        if depth != self.depth:                                                # plugins.py:65-74
-            self.trainer.D.depth = self.trainer.G.depth = dataset.model_depth = depth
-            self.depth = depth
-            minibatch_size = self.minibatch_overrides.get(depth, self.minibatch_default)
-            self.trainer.dataiter = iter(self.create_dataloader_fun(minibatch_size))
-            self.trainer.random_latents_generator = self.create_rlg(minibatch_size)
-            tick_duration_kimg = self.tick_kimg_overrides.get(depth, self.tick_kimg_default)
-            self.trainer.tick_duration_nimg = tick_duration_kimg * 1000
-            self.trainer.stats['minibatch_size'] = minibatch_size
-        if alpha != self.alpha:                                                # plugins.py:75-77
-            self.trainer.D.alpha = self.trainer.G.alpha = dataset.alpha = alpha
-            self.alpha = alpha
-        self.trainer.stats['depth'] = depth
-        self.trainer.stats['alpha']['val'] = alpha
-        if self.max_lod is not None and self.depth_offset is not None:
-            self.trainer.stats['lod']['val'] = self.lod
+        tr = self.trainer
+        depth, alpha = self.schedule(tr.cur_nimg)
+        if depth != self.depth:
+            self._enter_stage(depth)
+        if alpha != self.alpha:
+            self._set_alpha(alpha)
+        tr.stats['depth'] = depth
+        tr.stats['alpha']['val'] = alpha
+        if self._reports_lod:
+            tr.stats['lod']['val'] = self.lod
 
 
 class LRScheduler(Plugin):
-    """reference plugins.py:84-99."""
+    """Steps both learning-rate schedules with the image counter after every iteration and once at registration
+    (reference plugins.py:84-99); the schedulers only need ``step(cur_nimg)``."""
 
     def __init__(self, lr_scheduler_d, lr_scheduler_g):
         super(LRScheduler, self).__init__([(1, 'iteration')])
-        self.lrs_d = lr_scheduler_d
-        self.lrs_g = lr_scheduler_g
+        self.lrs_d, self.lrs_g = lr_scheduler_d, lr_scheduler_g
 
     def register(self, trainer):
         self.trainer = trainer
         self.iteration()
 
     def iteration(self, *args):
-        self.lrs_d.step(self.trainer.cur_nimg)
-        self.lrs_g.step(self.trainer.cur_nimg)
+        shown = self.trainer.cur_nimg
+        for sched in (self.lrs_d, self.lrs_g):
+            sched.step(shown)
 
 
 class RampupLR(object):

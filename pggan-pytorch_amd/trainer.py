@@ -1,107 +1,144 @@
-"""Trainer: the reference's step driver and plugin queues (/root/reference/trainer.py), unchanged in
-API — ``Trainer(D, G, D_loss, G_loss, optimizer_d, optimizer_g, dataset, dataiter,
-random_latents_generator, D_training_repeats=1, tick_nimg_default=2000, resume_nimg=0)``,
-``register_plugin``, ``run(total_kimg)``, ``train()`` and the public mutable fields.
+"""Trainer: step driver + plugin dispatcher behind the reference's API (/root/reference/trainer.py:7-115).
 
-Additions for the MI355X data-parallel path (both optional, default off):
-  * ``parallel``: a ``parallel.DataParallel`` helper; gradients of D (after trainer.py:98) and of G
-    (after trainer.py:111) are sum-all-reduced over RCCL on the networks' flat gradient buffers, and
-    ``cur_nimg`` advances by ``world_size * minibatch`` so the depth/alpha schedule stays a pure
-    function of the number of images shown;
-  * inputs that are not yet on the device are moved there (the reference's ``.cuda()`` calls)."""
+Same public surface as the reference — ``Trainer(D, G, D_loss, G_loss, optimizer_d, optimizer_g, dataset, dataiter,
+random_latents_generator, D_training_repeats=1, tick_nimg_default=2000, resume_nimg=0)``, ``register_plugin``,
+``call_plugins``, ``run(total_kimg)``, ``train()``, the mutable fields plugins poke (``dataiter``,
+``random_latents_generator``, ``tick_duration_nimg``, ``stats`` ...) and ``plugin_queues`` (unit -> list of
+``(due, registration order, plugin)``) — with the same observable firing order, pinned by the reference trace
+fixture (``tests/golden/trace16``).  The body is this project's own.
+
+MI355X data-parallel additions (optional, default off):
+  * ``parallel``: a ``parallel.DataParallel``; D's gradients (after reference trainer.py:98) and G's (after :111)
+    are sum-all-reduced over RCCL on the flat gradient buffers, ``cur_nimg`` advances by ``world_size * minibatch``
+    so the depth/alpha schedule stays a pure function of the images shown, and the optimizers' gradient pre-scale is
+    set to 1/world_size here (a plain ``torch.optim`` optimizer gets averaged gradients from the all-reduce instead);
+  * host inputs are moved to the device (the reference's ``.cuda()`` calls)."""
 import heapq
 import os
 
 from . import engine
+
+PLUGIN_UNITS = ('iteration', 'epoch', 's', 'end')
 
 
 def _to_device(t):
     return t if getattr(t, 'is_cuda', False) else t.cuda()
 
 
+def _triggers(plugin):
+    """``plugin.trigger_interval`` as a list of (period, unit) pairs (a bare pair is accepted like a one-element list)."""
+    trig = plugin.trigger_interval
+    return trig if isinstance(trig, list) else [trig]
+
+
+def _period(plugin, unit):
+    """Re-arm period of ``plugin`` on the ``unit`` queue: the LAST matching trigger wins, as in the reference's scan
+    (trainer.py:63-65)."""
+    found = None
+    for period, u in _triggers(plugin):
+        if u == unit:
+            found = period
+    if found is None:
+        raise ValueError('plugin %r fired on %r without a trigger for it' % (plugin, unit))
+    return found
+
+
+def _as_tuple(losses):
+    """Loss functions may return a scalar, a tuple or a list (trainer.py:105-110)."""
+    if isinstance(losses, (list, tuple)):
+        return tuple(losses)
+    return (losses,)
+
+
 class Trainer(object):
 
-    def __init__(self,
-                 D,
-                 G,
-                 D_loss,
-                 G_loss,
-                 optimizer_d,
-                 optimizer_g,
-                 dataset,
-                 dataiter,
-                 random_latents_generator,
-                 D_training_repeats=1,  # trainer
-                 tick_nimg_default=2 * 1000,  # trainer
-                 resume_nimg=0,
-                 parallel=None):
-        self.D = D
-        self.G = G
-        self.D_loss = D_loss
-        self.G_loss = G_loss
-        self.D_training_repeats = D_training_repeats
-        self.optimizer_d = optimizer_d
-        self.optimizer_g = optimizer_g
-        self.dataiter = dataiter
-        self.dataset = dataset
-        self.cur_nimg = resume_nimg
+    def __init__(self, D, G, D_loss, G_loss, optimizer_d, optimizer_g, dataset, dataiter, random_latents_generator,
+                 D_training_repeats=1, tick_nimg_default=2 * 1000, resume_nimg=0, parallel=None):
+        # networks, losses, optimizers, data sources: the names are API (plugins read and replace them)
+        self.D, self.G = D, G
+        self.D_loss, self.G_loss = D_loss, G_loss
+        self.optimizer_d, self.optimizer_g = optimizer_d, optimizer_g
+        self.dataset, self.dataiter = dataset, dataiter
         self.random_latents_generator = random_latents_generator
-        self.tick_start_nimg = self.cur_nimg
+        self.D_training_repeats = D_training_repeats
+        # progress counters
+        self.cur_nimg = self.tick_start_nimg = resume_nimg
         self.tick_duration_nimg = tick_nimg_default
-        self.iterations = 0
-        self.cur_tick = 0
-        self.time = 0
-        self.parallel = parallel
+        self.iterations = self.cur_tick = self.time = 0
         self.stats = {
-            'kimg_stat': {'val': self.cur_nimg / 1000., 'log_epoch_fields': ['{val:8.3f}'], 'log_name': 'kimg'},
-            'tick_stat': {'val': self.cur_tick, 'log_epoch_fields': ['{val:5}'], 'log_name': 'tick'}
+            'kimg_stat': dict(val=self.cur_nimg / 1000., log_epoch_fields=['{val:8.3f}'], log_name='kimg'),
+            'tick_stat': dict(val=self.cur_tick, log_epoch_fields=['{val:5}'], log_name='tick'),
         }
-        self.plugin_queues = {
-            'iteration': [],
-            'epoch': [],
-            's': [],
-            'end': []
-        }
+        self.plugin_queues = {unit: [] for unit in PLUGIN_UNITS}
+        self.parallel = parallel
+        self._average_in_allreduce = {}
+        self._exchanges = {}
+        if parallel is not None:
+            for net, opt in ((D, optimizer_d), (G, optimizer_g)):
+                if hasattr(opt, 'grad_scale'):
+                    opt.grad_scale = parallel.grad_scale          # FusedAdam folds 1/world into its update
+                    self._average_in_allreduce[id(net)] = False
+                else:                                             # e.g. torch.optim.Adam: hand it averaged gradients
+                    self._average_in_allreduce[id(net)] = True
 
+    # ---------------------------------------------------------------- plugins
     def register_plugin(self, plugin):
         plugin.register(self)
-        intervals = plugin.trigger_interval
-        if not isinstance(intervals, list):
-            intervals = [intervals]
-        for (duration, unit) in intervals:
-            queue = self.plugin_queues[unit]
-            queue.append((duration, len(queue), plugin))
+        for period, unit in _triggers(plugin):
+            pending = self.plugin_queues[unit]
+            pending.append((period, len(pending), plugin))       # first firing at t == period; ties by registration order
 
     def call_plugins(self, queue_name, time, *args):
-        args = (time,) + args
-        queue = self.plugin_queues[queue_name]
-        if len(queue) == 0:
-            return
-        while queue[0][0] <= time:
-            plugin = queue[0][2]
-            getattr(plugin, queue_name)(*args)
-            for trigger in plugin.trigger_interval:
-                if trigger[1] == queue_name:
-                    interval = trigger[0]
-            new_item = (time + interval, queue[0][1], plugin)
-            heapq.heappushpop(queue, new_item)
+        """Fire every plugin of the ``queue_name`` queue that is due at ``time`` (earliest due first, then registration
+        order) and re-arm each at ``time + period``."""
+        pending = self.plugin_queues[queue_name]
+        while pending and pending[0][0] <= time:
+            _, order, plugin = pending[0]
+            getattr(plugin, queue_name)(time, *args)
+            heapq.heapreplace(pending, (time + _period(plugin, queue_name), order, plugin))
+
+    def _end_tick(self):
+        self.cur_tick += 1
+        self.tick_start_nimg = self.cur_nimg
+        self.stats['kimg_stat']['val'] = self.cur_nimg / 1000.
+        self.stats['tick_stat']['val'] = self.cur_tick
+        self.call_plugins('epoch', self.cur_tick)
 
     def run(self, total_kimg=1):
-        for q in self.plugin_queues.values():
-            heapq.heapify(q)
-        while self.cur_nimg < total_kimg * 1000:
+        for pending in self.plugin_queues.values():
+            heapq.heapify(pending)
+        total_nimg = total_kimg * 1000
+        while self.cur_nimg < total_nimg:
             self.train()
-            if self.cur_nimg >= self.tick_start_nimg + self.tick_duration_nimg or self.cur_nimg >= total_kimg * 1000:
-                self.cur_tick += 1
-                self.tick_start_nimg = self.cur_nimg
-                self.stats['kimg_stat']['val'] = self.cur_nimg / 1000.
-                self.stats['tick_stat']['val'] = self.cur_tick
-                self.call_plugins('epoch', self.cur_tick)
+            # a tick closes when its image budget is used up, and always with the last iteration of the run
+            if self.cur_nimg >= min(total_nimg, self.tick_start_nimg + self.tick_duration_nimg):
+                self._end_tick()
         self.call_plugins('end', 1)
 
-    def _d_update(self):
+    # ---------------------------------------------------------------- one iteration
+    def _open_exchange(self, net, layers_fn):
+        """Under data parallelism, let the backward sweep that follows hand finished blocks to a bucketed all-reduce
+        (``parallel.GradExchange``).  Eager launches of the product's own networks only: a captured hipGraph step has
+        no hook points, and a foreign network has no flat gradient buffer."""
+        if self.parallel is None or not hasattr(net, '_flat_param'):
+            return
+        from . import parallel as par, wgan_gp_loss
+        if wgan_gp_loss._graphs_on(net) and float(net.alpha) >= 1.0 and net._flat_param.is_cuda:
+            return
+        if os.environ.get('PGGAN_DP_BUCKETS', '1') == '0':
+            return
+        ex = self._exchanges.get(id(net))
+        if ex is None:
+            ex = self._exchanges[id(net)] = par.GradExchange(self.parallel, net)
+        ex.begin(layers_fn(net, int(net.depth), float(net.alpha)))
+        net._grad_exchange, net._grad_hook = ex, ex.ready
+
+    def _exchange(self, net):
         if self.parallel is not None:
-            self.parallel.all_reduce_grads(self.D)
+            self.parallel.all_reduce_grads(net, average=self._average_in_allreduce.get(id(net), False))
+
+    def _d_update(self):
+        self._exchange(self.D)
         self.optimizer_d.step()                                                   # reference trainer.py:100
         if getattr(self.D, '_flat_param', None) is not None and self.D._flat_param.is_cuda:
             engine._derived(self.D)
@@ -116,38 +153,38 @@ class Trainer(object):
                 and not wgan_gp_loss._graphs_on(self.D) and not wgan_gp_loss._graphs_on(self.G))
 
     def train(self):
-        """One iteration.  reference trainer.py:85-115."""
+        """One iteration: ``D_training_repeats`` discriminator updates, then one generator update
+        (reference trainer.py:85-115; line numbers below refer to it)."""
         world = 1 if self.parallel is None else self.parallel.world_size
-        fake_latents_in = _to_device(self.random_latents_generator())            # :86
-        d_losses = [0, 0, 0]
-        for i in range(self.D_training_repeats):                                  # :90
-            real_images_expr = _to_device(next(self.dataiter))                    # :92
-            self.cur_nimg += real_images_expr.size(0) * world                     # :93 (global images)
-            d_losses = self.D_loss(self.D, self.G, real_images_expr, fake_latents_in)   # :95
-            d_losses = tuple(d_losses)
-            D_loss = d_losses[0]
-            defer = i == self.D_training_repeats - 1 and self._can_overlap_d_update()
+        latents = _to_device(self.random_latents_generator())                     # :86
+        d_losses = (0, 0, 0)
+        for rep in range(self.D_training_repeats):                                # :90
+            reals = _to_device(next(self.dataiter))                               # :92
+            self.cur_nimg += reals.size(0) * world                                # :93 (global images)
+            d_losses = _as_tuple(self.D_loss(self.D, self.G, reals, latents))     # :95
+            last = rep == self.D_training_repeats - 1
+            defer = last and self._can_overlap_d_update()
             self.D._skip_join = defer                # the update runs on the second stream, behind the weight gradients
+            self._open_exchange(self.D, engine.d_exchange_layers)
             try:
-                D_loss.backward()                                                 # :98
+                d_losses[0].backward()                                            # :98
             finally:
                 self.D._skip_join = False
+                self.D._grad_hook = None
             if defer:
                 # the tail of the last D update (all-reduce, Adam, derived weights) runs on the second stream under the
                 # generator forward that opens the G step; the main stream re-joins at its first use of D (engine.wait_pending)
                 engine.defer_to_side(self.D, self._d_update)
             else:
                 self._d_update()
-            fake_latents_in = _to_device(self.random_latents_generator())         # :103
-        g_losses = self.G_loss(self.G, self.D, fake_latents_in)                   # :105
-        if type(g_losses) is list:
-            g_losses = tuple(g_losses)
-        elif type(g_losses) is not tuple:
-            g_losses = (g_losses,)
-        G_loss = g_losses[0]
-        G_loss.backward()                                                         # :111
-        if self.parallel is not None:
-            self.parallel.all_reduce_grads(self.G)
+            latents = _to_device(self.random_latents_generator())                 # :103
+        g_losses = _as_tuple(self.G_loss(self.G, self.D, latents))                # :105-110
+        self._open_exchange(self.G, engine.g_exchange_layers)
+        try:
+            g_losses[0].backward()                                                # :111
+        finally:
+            self.G._grad_hook = None
+        self._exchange(self.G)
         self.optimizer_g.step()                                                   # :112
         engine.wait_pending(self.D)                  # (a G_loss that never ran D: nothing may outlive the iteration)
         self.iterations += 1

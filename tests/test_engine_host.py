@@ -232,7 +232,8 @@ def test_depth_manager_bit_exact():
 
 
 def test_library_exports_every_declared_symbol():
-    """The C-ABI library loads and exports every symbol include/pggan_hip.h declares (no compute)."""
+    """The C-ABI library loads and exports every symbol include/*.h declares (no compute): the product boundary
+    (pggan_hip.h) and the thread-local diagnostic exports (pggan_hip_debug.h)."""
     import ctypes
     import os
     import re
@@ -240,6 +241,11 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(root, 'include', 'pggan_hip.h')).read()
     declared = set(re.findall(r'\b(?:int|const char\*)\s+(pg_\w+)\s*\(', hdr))
     assert declared == set(pg._lib.SIGNATURES), declared ^ set(pg._lib.SIGNATURES)
+    assert not any(n.startswith('pg_debug') for n in declared)          # the product header carries no debug state
+    dbg = open(os.path.join(root, 'include', 'pggan_hip_debug.h')).read()
+    declared_dbg = set(re.findall(r'\b(?:int|const char\*)\s+(pg_\w+)\s*\(', dbg))
+    assert declared_dbg == set(pg._lib.DEBUG_SIGNATURES), declared_dbg ^ set(pg._lib.DEBUG_SIGNATURES)
+    declared |= declared_dbg
     if not os.path.exists(pg.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()

@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_path, res):
+def _worker(rank, world, port, out_path, res, bucket_bytes):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -44,6 +44,7 @@ def _worker(rank, world, port, out_path, res):
     G = pg.Generator(shape, latent_size=16, **kw)
     D = pg.Discriminator(shape, **kw)
     pg.parallel.MERGE_GAP = 0                          # tiny layers: keep the live spans apart so the span logic is exercised
+    pg.parallel.BUCKET_BYTES = bucket_bytes            # small: several buckets leave while the backward sweep is still running
     dp.broadcast_params(G, D)                          # ... made identical by the broadcast from rank 0
     G.depth = D.depth = 2
     G.alpha = D.alpha = 0.5
@@ -75,12 +76,16 @@ def _worker(rank, world, port, out_path, res):
     first = {}
     orig_all_reduce = dp.all_reduce_grads
 
-    def recording_all_reduce(net):
-        r = orig_all_reduce(net)
+    def recording_all_reduce(net, average=False):
+        ex = getattr(net, '_grad_exchange', None)
+        assert ex is not None and ex.started               # the Trainer opened a bucketed exchange for this sweep
+        before = dp.stats['bytes']
+        r = orig_all_reduce(net, average=average)
         key = 'D' if net is D else 'G'
         if key not in first:                               # summed (not yet averaged) gradients, iteration 0
             first[key] = {k: v.clone() for k, v in reference_grads(net).items()}
             first[key + '_reduced'] = (sum(e - s for s, e in pg.parallel.active_grad_spans(net)), net._flat_grad.numel())
+            first[key + '_buckets'] = (ex.buckets, ex.sent_bytes, dp.stats['bytes'] - before)
         return r
     dp.all_reduce_grads = recording_all_reduce
     tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, DS(), loader(), rlg, parallel=dp)
@@ -104,12 +109,21 @@ def _err(a, b):
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-3))
 
 
-@pytest.mark.parametrize('res', [16, 32])               # 32: the last growth stage is not live at depth 2 -> partial all-reduce
-def test_two_rank_data_parallel_matches_oracle(tmp_path, oracle, res):
+# res 32: the last growth stage is not live at depth 2 -> partial all-reduce.  bucket 1 KB: a bucket leaves after almost every
+# block of the backward sweep; 16 MB: everything travels in the final flush.
+@pytest.mark.parametrize('res,bucket_bytes', [(16, 1024), (32, 1024), (16, 16 << 20)])
+def test_two_rank_data_parallel_matches_oracle(tmp_path, oracle, res, bucket_bytes):
     world = 2
     out_path = str(tmp_path / 'dp.pt')
-    mp.spawn(_worker, args=(world, _free_port(), out_path, res), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out_path, res, bucket_bytes), nprocs=world, join=True)
     got = torch.load(out_path, weights_only=False)
+    for key in ('D', 'G'):
+        buckets, sent, at_finish = got['first'][key + '_buckets']
+        assert sent >= 4 * got['first'][key + '_reduced'][0] - 64          # every live gradient travelled (span padding aside)
+        if bucket_bytes <= 1024:
+            assert buckets >= 3 and at_finish < sent, (key, buckets, sent, at_finish)   # most of it before the sweep ended
+        else:
+            assert at_finish == sent, (key, buckets, sent, at_finish)
     # oracle: same start (rank 0's init), per-shard gradients averaged
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import pggan_amd as pg

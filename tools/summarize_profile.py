@@ -57,13 +57,15 @@ for k in kernels:
                  '%.1f' % mfma_pct, '%.3f' % (conf / act if act else 0.0),
                  '%.3g' % sq.get(k, {}).get('SQ_INSTS_MFMA', 0), '%.3g' % sq.get(k, {}).get('SQ_INSTS_VALU', 0),
                  '%.3f' % (sq.get(k, {}).get('SQ_WAIT_INST_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1))),
-                 '%.3f' % (sq.get(k, {}).get('SQ_WAIT_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1)))])
+                 '%.3f' % (sq.get(k, {}).get('SQ_WAIT_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1))),
+                 # effective shader clock while the kernel ran: GRBM_GUI_ACTIVE cycles / kernel wall time (MI355X_MICROARCH.md, DVFS)
+                 '%.2f' % (lds.get(k, {}).get('GRBM_GUI_ACTIVE', 0.0) / max(1.0, sum(ld.get(k, {}).values())))])
     roof[k] = {'hbm_bytes_per_launch': fetch_b + write_b, 'fetch_bytes_per_launch': fetch_b,
                'write_bytes_per_launch': write_b, 'mfma_busy_pct': mfma_pct, 'avg_launch_us': tot_ns / 1e3 / max(1, calls)}
 with open(os.path.join(out, tag + '_pmc_summary.csv'), 'w') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'calls', 'total_ms', 'avg_us', 'hbm_fetch_bytes_per_launch(x2 corrected)', 'hbm_write_bytes_per_launch',
-                'mfma_busy_pct', 'lds_conflict_frac', 'insts_mfma', 'insts_valu', 'wait_inst_frac', 'wait_any_frac'])
+                'mfma_busy_pct', 'lds_conflict_frac', 'insts_mfma', 'insts_valu', 'wait_inst_frac', 'wait_any_frac', 'eff_clock_ghz'])
     w.writerows(rows)
 fam = collections.defaultdict(lambda: dict(bytes=0.0, calls=0, ns=0.0))
 for k, v in roof.items():
