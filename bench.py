@@ -1,36 +1,87 @@
 #!/usr/bin/env python
 """bench.py — images/sec of the PGGAN train step on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--depth D] [--no-cpu] [--no-per-depth]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--depth D] [--alpha A] [--fmap-base F] [--config {2,3,4,5}]
+                    [--no-cpu] [--no-per-depth] [--no-configs]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one Trainer.train() iteration (reference trainer.py:85-115): wgan_gp_D_loss + backward
 (3 D passes batched, G forward, gradient-penalty double backward) + Adam(D), then wgan_gp_G_loss +
-backward + Adam(G), on one synthetic minibatch already resident in HBM.  Headline workload: the
-1024x1024 growth stage (depth 8) of the default-width (fmap_base 4096) CelebA-HQ-shape network with
+backward + Adam(G), on one synthetic minibatch already resident in HBM.  Headline workload (BASELINE.json config 5):
+the 1024x1024 growth stage (depth 8) of the default-width (fmap_base 4096) CelebA-HQ-shape network with
 the reference's per-depth minibatch (3 per GPU, plugins.py:20), fp32.  Data-parallel: one process
-per GPU, minibatch per rank fixed (weak scaling), one RCCL sum-all-reduce of each network's flat
-gradient buffer per iteration.  Rank 0 prints ONE JSON line (the last line of stdout).
-Setup before the W warmup steps: --prime (default 50) untimed steps that load the code objects, grow the
-caching allocator and let the clocks settle; the count is reported as "priming_steps".
+per GPU, minibatch per rank fixed (weak scaling), RCCL sum-all-reduce of each network's flat gradient buffer
+(bucketed, overlapped with the backward sweeps) through the library's C-ABI.  ``--gpus N`` with N > 1 and no
+WORLD_SIZE in the environment launches the N ranks itself (torch.distributed.run) and fails loudly when fewer than N
+devices are visible.  Rank 0 prints ONE JSON line (the last line of stdout).
+
+Fractions in the line: ``algorithmic_frac`` = 2*MAC FLOP of the reference's convolutions per second over the nominal
+157.3 TF fp32-MFMA peak (can exceed what the matrix cores execute: Winograd F(2x2,3x3) layers issue 16/36 of it);
+``executed_mfma_frac`` = the same with Winograd launches credited 16/36 (HIP-event timed conv launches only);
+``mfma_busy_pct`` = time-weighted SQ_VALU_MFMA_BUSY_CYCLES of the conv kernels from the committed PMC pass
+(``mfma_busy_source``).  Setup before the W warmup steps: --prime (default 50) untimed steps (code objects, allocator
+growth, clock ramp), reported as "priming_steps".
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The step uses three HIP streams (main, weight gradients, gradient exchange) next to RCCL's own; with ROCm's default of 4
+# hardware queues two of them can share a queue and serialise (measured: 17.2 vs 14.6 ms per step with the library's RCCL
+# communicator alive).  Must be set before the HIP runtime is loaded.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12          # gfx950 f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 REF_MINIBATCH = {6: 14, 7: 6, 8: 3}          # reference plugins.py:19-20 (default 16)
-# per-image forward FLOPs (2*MAC, conv+linear), fmap_base 4096, alpha 1 — SURVEY.md §8a / BASELINE.md §4
-F_D = [0.0841, 0.6882, 3.1047, 6.7294, 10.3548, 13.9819, 17.6120, 21.2485, 24.8975]
+PROFILE_TAG = 'r02'                           # profiles/<tag>_roofline.json: PMC pass the traffic / MFMA-busy figures come from
+
+
+def forward_flops(G, D, depth, alpha):
+    """Per-image forward FLOPs (2*MAC of every conv + the final linear; elementwise work excluded) of G and D at a
+    growth stage, with the reference's channel counts (513, not the stored 528) and ONE live tap per output pixel for
+    the 4x4 pad-3 conv on the 1x1 latent (depth 8, fmap_base 4096 -> F_G 24.8974, F_D 24.8975 GFLOP)."""
+    C = D.num_channels
+    r = 4 * 2 ** depth
+
+    def conv(m, h, taps=None):
+        return 2.0 * h * h * m.ch_in * m.ch_out * (m.ksize * m.ksize if taps is None else taps)
+    b0 = G.block0
+    fg = conv(b0.c1, 4, taps=1) + conv(b0.c2, 4)
+    h = 4
+    for i in range(depth):
+        h *= 2
+        fg += conv(G.blocks[i].c1, h) + conv(G.blocks[i].c2, h)
+    fg += conv(G.blocks[depth - 1].toRGB if depth > 0 else b0.toRGB, r)
+    if depth > 0 and alpha < 1.0:
+        fg += conv(G.blocks[depth - 2].toRGB if depth > 1 else b0.toRGB, r // 2)
+    nb = len(D.blocks)
+    e = nb - 1 - depth
+    fd = conv(D.blocks[e].fromRGB, r)
+    if depth > 0 and alpha < 1.0:
+        fd += conv(D.blocks[e + 1].fromRGB, r // 2)
+    h = r
+    for j in range(e, nb - 1):
+        fd += conv(D.blocks[j].c1, h) + conv(D.blocks[j].c2, h)
+        h //= 2
+    last = D.blocks[nb - 1]
+    fd += conv(last.c1, 4) + 2.0 * 16 * last.c2.ch_in * last.c2.ch_out + 2.0 * D.linear.in_features
+    return fg, fd
+
+
+def step_flops(G, D, depth, alpha):
+    """Algorithmic FLOP per image of the D-step + GP (12 F_D + F_G) and of the full iteration (14 F_D + 4 F_G),
+    SURVEY.md §8d."""
+    fg, fd = forward_flops(G, D, depth, alpha)
+    return 12 * fd + fg, 14 * fd + 4 * fg
 
 
 def conv_flops(n, hout, wout, ks, pad, c_a, c_b):
@@ -143,8 +194,9 @@ class KernelTimer(object):
             t['flops'] += fl
             t['ms'] += ms
             t['launches'] += 1
-            d = fam.setdefault(family, dict(flops=0.0, ms=0.0, launches=0))
+            d = fam.setdefault(family, dict(flops=0.0, exec_flops=0.0, ms=0.0, launches=0))
             d['flops'] += fl
+            d['exec_flops'] += fl * (16.0 / 36.0 if 'wino' in family else 1.0)     # F(2x2,3x3) issues 16 of the 36 multiplies
             d['ms'] += ms
             d['launches'] += 1
         for d in fam.values():
@@ -153,24 +205,27 @@ class KernelTimer(object):
             d['launches_per_step'] = d['launches'] / nsteps
             d['avg_launch_us'] = 1e3 * d['ms'] / max(1, d['launches'])
             d['tflops'] = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+            d['exec_tflops'] = d['exec_flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
         return fam
 
 
-def make_trainer(pg, res, depth, alpha, mb, seed, dp, fmap_base=4096):
+
+def make_trainer(pg, res, depth, alpha, mb, seed, dp, fmap_base=4096, channels=3, ring=8):
     torch.manual_seed(1337)                       # same weights on every rank (train.py:21)
-    shape = (1, 3, res, res)
+    shape = (1, channels, res, res)
     G = pg.Generator(shape, fmap_base=fmap_base).cuda()
     D = pg.Discriminator(shape, fmap_base=fmap_base).cuda()
     G.depth = D.depth = depth
     G.alpha = D.alpha = alpha
-    gs = 1.0 if dp is None else dp.grad_scale
-    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99), grad_scale=gs)
-    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99), grad_scale=gs)
-    ds = pg.utils.SyntheticDataset(res, 3, seed=seed)
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))     # 1/world gradient pre-scale: set by Trainer(parallel=...)
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    ds = pg.utils.SyntheticDataset(res, channels, seed=seed, ring=ring)   # pre-generated ring: no RNG kernels in the timed steps
     ds.model_depth = depth
     pg.wgan_gp_loss.manual_seed(seed)
     tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, ds.loader(mb),
-                    pg.utils.device_latents(mb, 512, seed=seed + 7), parallel=dp)
+                    pg.utils.device_latents(mb, G.latent_size, seed=seed + 7, ring=2 * ring), parallel=dp)
+    if dp is not None:
+        dp.broadcast_params(tr.G, tr.D)
     return tr
 
 
@@ -180,51 +235,56 @@ def make_trainer(pg, res, depth, alpha, mb, seed, dp, fmap_base=4096):
 PRIME_STEPS = 50
 
 
-def timed_steps(tr, steps, warmup, dp):
+def _max_over_ranks(dt, dp):
+    if dp is None:
+        return dt
+    t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t)
+
+
+def timed_steps(tr, steps, warmup, dp, fn=None):
+    fn = tr.train if fn is None else fn
     for _ in range(warmup):
-        tr.train()
+        fn()
     if dp is not None:
         dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        tr.train()
+        fn()
     torch.cuda.synchronize()
     if dp is not None:
         dp.barrier()
-    dt = time.perf_counter() - t0
+    return _max_over_ranks(time.perf_counter() - t0, dp)
+
+
+def robust_ms(tr, dp, fn=None, prime=20, window_s=0.35, windows=3):
+    """ms per call of ``fn`` (default: a train step), robust against one-off stalls: ``prime`` untimed calls, then the
+    MEDIAN of ``windows`` timed windows of >= ``window_s`` seconds each (the call count per window is derived from a
+    short probe and agreed across ranks)."""
+    fn = tr.train if fn is None else fn
+    probe = timed_steps(tr, 3, prime, dp, fn) / 3
+    k = max(3, int(window_s / max(probe, 1e-5)) + 1)
     if dp is not None:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        t = torch.tensor([k], device='cuda', dtype=torch.int64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
-    return dt
+        k = int(t)
+    ms = sorted(1e3 * timed_steps(tr, k, 0, dp, fn) / k for _ in range(windows))
+    return ms[len(ms) // 2], k, ms
 
 
-def d_step_ms(tr, steps):
-    """per-depth 'D+GP ms' = wgan_gp_D_loss + backward + Adam(D)."""
+def d_step_fn(tr):
+    """per-depth 'D+GP ms' = wgan_gp_D_loss + backward + gradient exchange + Adam(D)."""
     real = next(tr.dataiter)
     z = tr.random_latents_generator()
+
     def one():
         c = tr.D_loss(tr.D, tr.G, real, z)[0]
         c.backward()
-        if tr.parallel is not None:                          # the D-step of Trainer.train(): gradients summed over ranks
-            tr.parallel.all_reduce_grads(tr.D)
+        tr._exchange(tr.D)
         tr.optimizer_d.step()
-    for _ in range(2):
-        one()
-    if tr.parallel is not None:
-        tr.parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if tr.parallel is not None:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
-    return 1e3 * dt / steps
+    return one
 
 
 def cpu_baseline(depth, mb):
@@ -254,6 +314,97 @@ def cpu_baseline(depth, mb):
                        'torch-CPU fp32 oracle, %d threads, %.1f s' % (depth, res, res, mb, cores, dt))
 
 
+def relaunch(n):
+    """``python bench.py --gpus N`` without a torchrun environment: start the N ranks here."""
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write('bench.py: --gpus %d requested but only %d GPU(s) are visible on this node; refusing to '
+                         'report an N=%d number measured on fewer devices\n' % (n, have, n))
+        sys.exit(2)
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def stage_entry(pg, tr, dp, n_gpus, mb, depth, alpha, extra=None):
+    """images/s, ms per step and D+GP ms of one configured trainer (median of 3 timed windows), with the algorithmic
+    fractions of the nominal fp32-MFMA peak."""
+    ms, k, all_ms = robust_ms(tr, dp)
+    dms, _, _ = robust_ms(tr, dp, fn=d_step_fn(tr), prime=3, window_s=0.25)
+    w_d, w = step_flops(tr.G, tr.D, depth, alpha)
+    e = {'depth': depth, 'res': 4 * 2 ** depth, 'alpha': alpha, 'minibatch': mb, 'images_per_sec': n_gpus * mb / (ms * 1e-3),
+         'ms_per_step': ms, 'ms_windows': all_ms, 'steps_per_window': k, 'd_step_gp_ms': dms,
+         'algorithmic_gflop_per_image': w / 1e9,
+         'algorithmic_frac': w * (mb / (ms * 1e-3)) / MFMA_F32_PEAK,
+         'd_step_gp_algorithmic_frac': w_d * (mb / (dms * 1e-3)) / MFMA_F32_PEAK}
+    if extra:
+        e.update(extra)
+    return e
+
+
+def grow_run(pg, dp, n_gpus, rank):
+    """BASELINE.json config 2: the res-32 network grown depth 0 -> 3 with alpha fade-ins, minibatch 64, through the
+    product's Trainer + DepthManager + LRScheduler (shortened lod_*_nimg so every stage and every fade occurs)."""
+    torch.manual_seed(1337)
+    shape = (1, 3, 32, 32)
+    G, D = pg.Generator(shape).cuda(), pg.Discriminator(shape).cuda()
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    seed = pg.parallel.shard_seed(1337, rank)
+    ds = pg.utils.SyntheticDataset(32, 3, seed=seed, ring=8)
+    pg.wgan_gp_loss.manual_seed(seed)
+    world = 1 if dp is None else dp.world_size
+    tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, None, None, parallel=dp)
+    if dp is not None:
+        dp.broadcast_params(G, D)
+    lod = 64 * 40 * world                                   # 40 iterations per stabilisation / fade span
+    dm = pg.DepthManager(ds.loader, lambda n: pg.utils.device_latents(n, 512, seed=seed + 7, ring=16), 3,
+                         minibatch_default=64, lod_training_nimg=lod, lod_transition_nimg=lod)
+    tr.register_plugin(dm)
+    tr.register_plugin(pg.LRScheduler(pg.RampupLR(opt_d, pg.utils.rampup), pg.RampupLR(opt_g, pg.utils.rampup)))
+    total = 7 * lod                                         # stages 0,1,2,3 + three fades
+    marks = {}
+
+    class Clock(pg.Plugin):
+        def __init__(self):
+            super(Clock, self).__init__([(1, 'iteration')])
+
+        def register(self, trainer):
+            pass
+
+        def iteration(self, *a):
+            key = (int(tr.G.depth), float(tr.G.alpha) < 1.0)
+            marks.setdefault(key, []).append(time.perf_counter())
+    tr.register_plugin(Clock())
+    for _ in range(10):                                     # untimed: code objects of the 4x4 stage
+        tr.train()
+    tr.cur_nimg = 0
+    dm.depth = dm.alpha = -1
+    dm.iteration()
+    if dp is not None:
+        dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks.clear()
+    tr.run(total / 1000.0)
+    torch.cuda.synchronize()
+    dt = _max_over_ranks(time.perf_counter() - t0, dp)
+    stages = []
+    for (d, fading), ts in sorted(marks.items()):
+        if len(ts) > 4:
+            per = (ts[-1] - ts[2]) / (len(ts) - 3)            # host clock between iteration ends (GPU runs ahead by < 1 step)
+            stages.append({'depth': d, 'fade_in': fading, 'iterations': len(ts), 'ms_per_step': 1e3 * per,
+                           'images_per_sec': n_gpus * 64 / per})
+    return {'workload': 'config 2: 32x32 network, grow depth 0->3 with alpha fade-ins, minibatch 64 per GPU, DepthManager + '
+                        'LRScheduler, %d iterations' % tr.iterations,
+            'images_per_sec': total / dt, 'seconds': dt, 'iterations': tr.iterations, 'stages': stages}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -262,9 +413,13 @@ def main():
     ap.add_argument('--prime', type=int, default=PRIME_STEPS, help='untimed setup steps before the warmup (see PRIME_STEPS)')
     ap.add_argument('--depth', type=int, default=8)
     ap.add_argument('--alpha', type=float, default=1.0)
+    ap.add_argument('--fmap-base', type=int, default=4096, help='4096: reference default; 8192: the paper\'s widths')
+    ap.add_argument('--config', type=int, default=5, choices=[2, 3, 4, 5],
+                    help='BASELINE.json config timed as the headline (default 5 = the 1024x1024 stage the metric is quoted on)')
     ap.add_argument('--minibatch', type=int, default=0, help='per-GPU minibatch (default: reference schedule)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-per-depth', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the secondary workloads (BASELINE configs 2-4, fmap_base 8192, alpha 0.5)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--graphs', action='store_true', help='replay every stage from captured hipGraphs (graphs.py); default: only the launch-bound 4x4 stage, eager two-stream launching elsewhere (measured faster)')
     ap.add_argument('--serial-kernel-timing', action='store_true', help='instrumented passes with the weight-gradient stream off '
@@ -272,48 +427,94 @@ def main():
     ap.add_argument('--kernel-table', action='store_true', help='per-layer conv timing table on stderr')
     args = ap.parse_args()
 
+    env_world = os.environ.get('WORLD_SIZE')
+    if args.gpus > 1 and env_world is None:
+        relaunch(args.gpus)
+    world = int(env_world or '1')
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
+        sys.exit(2)
+
     import pggan_amd as pg
     if os.environ.get('PGGAN_TUNE'):                       # kernel A/B aid: "key=value,..." -> pg_debug_set_tuning
         for kv in os.environ['PGGAN_TUNE'].split(','):
             pg._lib.load().pg_debug_set_tuning(*[int(v) for v in kv.split('=')])
+    if os.environ.get('PGGAN_WINO'):                       # kernel A/B aid: Winograd conv generation (pg_debug_set_wino)
+        pg._lib.load().pg_debug_set_wino(int(os.environ['PGGAN_WINO']))
     pg.wgan_gp_loss.enable_graphs(True if args.graphs else 'auto')   # 'auto': hipGraph replay only at the launch-bound 4x4 stage
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     force_dp = os.environ.get('PGGAN_FORCE_DP', '') == '1'      # one-rank RCCL group: smoke test of the DP code path
     dp = pg.parallel.DataParallel.from_env(force=force_dp) if (world > 1 or force_dp) else None
     rank = 0 if dp is None else dp.rank
     if dp is None:
         torch.cuda.set_device(0)
     n_gpus = world
-    depth = args.depth
-    res = 4 * 2 ** depth
-    mb = args.minibatch or REF_MINIBATCH.get(depth, 16)
+    rccl = None
+    if dp is not None:                                     # prove the library's RCCL communicator spans every rank
+        probe = torch.ones(1 << 16, device='cuda', dtype=torch.float32)
+        dp.all_reduce_flat(probe)
+        torch.cuda.synchronize()
+        got = float(probe[0])
+        if got != float(world) or dp.comm_ranks != world:
+            raise RuntimeError('RCCL all-reduce over %d ranks returned %r (communicator size %d)' % (world, got, dp.comm_ranks))
+        rccl = {'rccl_ranks': dp.comm_ranks, 'allreduce_probe_sum': got}
+        dp.stats.update(collectives=0, bytes=0)
 
-    tr = make_trainer(pg, 1024, depth, args.alpha, mb, pg.parallel.shard_seed(1337, rank), dp)
-    if dp is not None:
-        dp.broadcast_params(tr.G, tr.D)
+    # ---- headline workload
+    cfgs = {5: dict(net=1024, depth=8, mb=3, ch=3), 3: dict(net=128, depth=5, mb=16, ch=3), 4: dict(net=256, depth=6, mb=8, ch=1),
+            2: dict(net=32, depth=3, mb=64, ch=3)}
+    c = cfgs[args.config]
+    depth = args.depth if args.config == 5 else c['depth']
+    net_res = c['net']
+    res = 4 * 2 ** depth
+    mb = args.minibatch or (REF_MINIBATCH.get(depth, 16) if args.config == 5 else c['mb'])
+    seed = pg.parallel.shard_seed(1337, rank)
+
+    tr = make_trainer(pg, net_res, depth, args.alpha, mb, seed, dp, fmap_base=args.fmap_base, channels=c['ch'])
     for _ in range(args.prime):           # setup, untimed and reported: code-object loading, allocator growth, clock ramp
         tr.train()
+    if dp is not None:
+        dp.stats.update(collectives=0, bytes=0)
     dt = timed_steps(tr, args.steps, args.warmup, dp)
     ms_per_step = 1e3 * dt / args.steps
     value = n_gpus * mb * args.steps / dt
+    w_d, w = step_flops(tr.G, tr.D, depth, args.alpha)
 
     out = {
         'metric': 'images/sec, PGGAN full train step (D+GP step + G step + Adam) at %dx%d' % (res, res),
         'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'priming_steps': args.prime,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'PGGAN (default widths fmap_base=4096, C=3, latent 512) growth stage depth %d = %dx%d, '
-                               'alpha %.2f, minibatch %d per GPU (reference per-depth schedule), Trainer.train() with '
-                               'WGAN-GP (lambda 10) and Adam(0,0.99), fp32' % (depth, res, res, args.alpha, mb),
+        'dtype': 'f32', 'data': 'synthetic (seeded uniform [-1,1) images / normal latents, pre-generated ring of 8 device batches)',
+        'config': {'workload': 'BASELINE config %d: PGGAN %dx%d network (fmap_base=%d, C=%d, latent %d) growth stage depth %d = %dx%d, '
+                               'alpha %.2f, minibatch %d per GPU%s, Trainer.train() with WGAN-GP (lambda 10) and Adam(0,0.99), fp32'
+                               % (args.config, net_res, net_res, args.fmap_base, c['ch'], tr.G.latent_size, depth, res, res, args.alpha, mb,
+                                  ' (reference per-depth schedule)' if args.config == 5 and not args.minibatch else ''),
                    'resolution': res, 'depth': depth, 'minibatch_per_gpu': mb, 'global_batch': mb * n_gpus,
-                   'parallelism': 'dp%d' % n_gpus},
+                   'parallelism': 'dp%d' % n_gpus, 'fmap_base': args.fmap_base},
+        'step_algorithmic_gflop_per_image': w / 1e9,
+        'algorithmic_frac': w * (value / n_gpus) / MFMA_F32_PEAK,
     }
-    W = (14 * F_D[depth] + 4 * F_D[depth]) * 1e9 if depth < len(F_D) else None     # F_G ~= F_D
-    if W:
-        out['step_algorithmic_gflop_per_image'] = W / 1e9
-        out['step_mfma_frac'] = W * (value / n_gpus) / MFMA_F32_PEAK
-
     out['config']['hip_graphs'] = bool((args.graphs or depth == 0) and args.alpha >= 1.0)
+    if rccl is not None:
+        out.update(rccl)
+        steps_counted = args.steps + args.warmup
+        out['allreduce_bytes_per_step'] = dp.stats['bytes'] / steps_counted
+        out['allreduce_collectives_per_step'] = dp.stats['collectives'] / steps_counted
+        # busy time of the exchange per step (HIP events around every collective on the stream it runs on) and the step
+        # time with the collectives left out: their difference to ms_per_step is the EXPOSED exchange
+        dp.record_events, dp.events = True, []
+        esteps = 5
+        for _ in range(esteps):
+            tr.train()
+        torch.cuda.synchronize()
+        dp.record_events = False
+        out['allreduce_ms'] = sum(a.elapsed_time(b) for a, b in dp.events) / esteps
+        dp.skip_exchange = True
+        dt0 = timed_steps(tr, args.steps, 2, dp)
+        dp.skip_exchange = False
+        dp.broadcast_params(tr.G, tr.D)                        # ranks diverged while nothing was exchanged
+        out['ms_per_step_without_exchange'] = 1e3 * dt0 / args.steps
+        out['exposed_exchange_ms'] = ms_per_step - out['ms_per_step_without_exchange']
+
     if rank == 0 and not args.no_kernel_timing:
         psteps = 3
         pg.wgan_gp_loss.enable_graphs(False)               # per-launch HIP events need eager launches
@@ -333,18 +534,32 @@ def main():
                     tag, t['launches'] / psteps, t['ms'] / psteps, t['flops'] / (t['ms'] * 1e-3) / 1e12))
         dom = max(fam, key=lambda k: fam[k]['ms'])
         d = fam[dom]
-        traffic = None
-        try:                                   # HBM bytes per launch of that symbol from the committed PMC summary
-            with open(os.path.join(ROOT, 'profiles', 'r01_roofline.json')) as f:
-                traffic = json.load(f)['per_kernel'][dom]['hbm_bytes_per_launch']
+        prof, traffic, busy = None, None, None
+        src = os.path.join('profiles', PROFILE_TAG + '_roofline.json')
+        try:                                   # HBM bytes per launch / MFMA-busy of that symbol from the committed PMC pass
+            with open(os.path.join(ROOT, src)) as f:
+                prof = json.load(f)['per_kernel']
+            traffic = prof[dom]['hbm_bytes_per_launch']
         except Exception:
-            pass
+            src = None
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': MFMA_F32_PEAK / 1e12,
-                           'unit': 'TFLOP/s', 'frac': d['tflops'] * 1e12 / MFMA_F32_PEAK, 'traffic': traffic,
+                           'unit': 'TFLOP/s', 'frac': d['tflops'] * 1e12 / MFMA_F32_PEAK,
+                           'frac_is': 'ALGORITHMIC FLOP of the launches / HIP-event time / nominal peak (not MFMA utilisation)',
+                           'executed_mfma_frac': d['exec_tflops'] * 1e12 / MFMA_F32_PEAK,
+                           'traffic': traffic, 'traffic_source': src,
+                           'mfma_busy_pct': prof[dom]['mfma_busy_pct'] if prof and dom in prof else None,
                            'avg_launch_us': d['avg_launch_us'], 'launches_per_step': d['launches_per_step'],
                            'ms_per_step_in_kernel': d['ms_per_step'],
                            'algorithmic_gflop_per_step': d['flops_per_step'] / 1e9}
-        out['kernels'] = {k: {'tflops': v['tflops'], 'ms_per_step': v['ms_per_step'],
+        tot_ms = sum(v['ms'] for v in fam.values())
+        out['executed_mfma_frac'] = sum(v['exec_flops'] for v in fam.values()) / (tot_ms * 1e-3) / MFMA_F32_PEAK
+        out['executed_mfma_frac_is'] = 'MFMA FLOP issued by the HIP-event-timed conv launches (Winograd credited 16/36) / their summed time / peak'
+        if prof:
+            num = sum(v['ms'] * prof[k]['mfma_busy_pct'] for k, v in fam.items() if k in prof)
+            den = sum(v['ms'] for k, v in fam.items() if k in prof)
+            out['mfma_busy_pct'] = num / den if den else None
+            out['mfma_busy_source'] = src + ' (SQ_VALU_MFMA_BUSY_CYCLES per kernel symbol, weighted by this run\'s time per symbol)'
+        out['kernels'] = {k: {'tflops': v['tflops'], 'executed_tflops': v['exec_tflops'], 'ms_per_step': v['ms_per_step'],
                               'launches_per_step': v['launches_per_step'], 'avg_launch_us': v['avg_launch_us']}
                           for k, v in fam.items()}
     elif dp is not None and not args.no_kernel_timing:
@@ -352,34 +567,49 @@ def main():
         for _ in range(3):                                  # keep collectives matched with rank 0
             tr.train()
     pg.wgan_gp_loss.enable_graphs(True if args.graphs else 'auto')
+    del tr
+    torch.cuda.empty_cache()
 
     if not args.no_per_depth:
         per = []
-        del tr
-        torch.cuda.empty_cache()
         for d in range(0, 9):
             m = REF_MINIBATCH.get(d, 16)
-            t = make_trainer(pg, 1024, d, 1.0, m, pg.parallel.shard_seed(1337, rank), dp)
-            if dp is not None:
-                dp.broadcast_params(t.G, t.D)
-            k = 100 if d <= 1 else (40 if d <= 3 else (20 if d <= 5 else (8 if d <= 7 else 5)))
-            tt = timed_steps(t, k, 5 if d <= 3 else 3, dp)            # max over ranks; minibatch m PER RANK (weak scaling)
-            dms = d_step_ms(t, k)
-            Wd = 18 * F_D[d] * 1e9
-            per.append({'depth': d, 'res': 4 * 2 ** d, 'minibatch': m, 'images_per_sec': n_gpus * m * k / tt,
-                        'ms_per_step': 1e3 * tt / k, 'd_step_gp_ms': dms,
-                        'mfma_frac': Wd * (m * k / tt) / MFMA_F32_PEAK})
+            t = make_trainer(pg, 1024, d, 1.0, m, seed, dp, fmap_base=args.fmap_base)
+            per.append(stage_entry(pg, t, dp, n_gpus, m, d, 1.0))          # minibatch m PER RANK (weak scaling), max over ranks
             del t
             torch.cuda.empty_cache()
         out['per_depth'] = per
 
+    if not args.no_configs:
+        sec = {}
+        t = make_trainer(pg, 1024, 8, 0.5, 3, seed, dp)
+        sec['depth8_alpha0.5'] = stage_entry(pg, t, dp, n_gpus, 3, 8, 0.5, {'workload': 'config 5 network, 1024x1024 stage in the middle of its fade-in (alpha 0.5)'})
+        del t
+        torch.cuda.empty_cache()
+        t = make_trainer(pg, 1024, 8, 1.0, 3, seed, dp, fmap_base=8192)
+        sec['depth8_fmap8192'] = stage_entry(pg, t, dp, n_gpus, 3, 8, 1.0, {'workload': 'paper widths (fmap_base 8192), 1024x1024 stage, minibatch 3 per GPU'})
+        del t
+        torch.cuda.empty_cache()
+        t = make_trainer(pg, 128, 5, 1.0, 16, seed, dp)
+        sec['config3'] = stage_entry(pg, t, dp, n_gpus, 16, 5, 1.0, {'workload': 'config 3: 128x128 network at depth 5, minibatch 16 per GPU (32 global on 2 GPUs)'})
+        del t
+        torch.cuda.empty_cache()
+        t = make_trainer(pg, 256, 6, 1.0, 8, seed, dp, channels=1)
+        sec['config4'] = stage_entry(pg, t, dp, n_gpus, 8, 6, 1.0, {'workload': 'config 4: 256x256 C=1 (abslog-spectrogram shape) network at depth 6, minibatch 8 per GPU (32 global on 4 GPUs)'})
+        del t
+        torch.cuda.empty_cache()
+        sec['config2'] = grow_run(pg, dp, n_gpus, rank)
+        torch.cuda.empty_cache()
+        out['configs'] = sec
+
     if rank == 0:
-        if not args.no_cpu and n_gpus == 1:
+        if not args.no_cpu and n_gpus == 1 and args.config == 5:
             out['cpu_baseline'] = cpu_baseline(depth, mb)
         else:
             out['cpu_baseline'] = None
     if dp is not None:
         dp.barrier()
+        dp.close()
         torch.distributed.destroy_process_group()
     if rank == 0:
         # the JSON line is the LAST thing on stdout: RCCL prints its banner through C stdio, which is still buffered here

@@ -321,6 +321,17 @@ int pg_pyramid_level_u8(const uint8_t* in, uint8_t* out, int64_t planes, int H, 
 int pg_image_grid_u8(const float* img, uint8_t* grid, int n, int C, int h, int w, int up,
                      float min_in, float max_in, pg_stream_t stream);
 
+/* Sound input step: replaces SoundImageDataset.load_file dataset.py:285-300 after the file read, for a waveform on the device.
+ *   pg_stft_abslog: y [nsamp][channels] fp32 (channels > 1: mono mix-down sum/2, :287-288) ->
+ *       out[k][t] = log(1 + |STFT(y)[k][t]|), k < bins, t < frames, with librosa's stft definition (periodic Hann window,
+ *       center=True / reflect padding, hop_length; :293-296).  n_fft: power of two <= 2048.  librosa is not in this image:
+ *       parity unpinned (oracle/sound_steps.py restates the published algorithm).
+ *   pg_minmax_f32 + pg_stretch_to_u8: np.uint8(adjust_dynamic_range(s, (s.min(), s.max()), (0, max_out))) dataset.py:299. */
+int pg_stft_abslog(const float* y, int64_t nsamp, int channels, float* out, int n_fft, int hop_length,
+                   int bins, int frames, pg_stream_t stream);
+int pg_minmax_f32(const float* x, int64_t n, float* lohi, pg_stream_t stream);
+int pg_stretch_to_u8(const float* x, uint8_t* out, int64_t n, const float* lohi, float max_out, pg_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Gradient exchange of the data-parallel step: RCCL over xGMI (SURVEY.md §8b "the all-reduce itself is a C-ABI call
  * taking ncclComm_t, buffer, count, stream", §8e).  The reference is single-GPU and has no collective; the exchange

@@ -121,10 +121,57 @@ def pgconv(x, p, name, pad, slope, pixelnorm):
     h = x * p[name + '.c']                                                        # :33
     h = F.conv2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], 1, pad)      # :34
     if slope is not None:
-        h = F.leaky_relu(h, slope) if slope != 0.0 else F.relu(h)                 # :35-36
+        h = _activation(h, slope)                                                 # :35-36
     if pixelnorm:
         h = h * torch.rsqrt(torch.mean(h * h, 1, keepdim=True) + EPS)             # :37-40
     return h
+
+
+_FORCED = None          # adjudication aid, see ``forced_signs``
+
+
+def _activation(h, slope):
+    """LeakyReLU / ReLU of the reference (network.py:26-29,35-36).  Under ``forced_signs`` the branch of every element is taken
+    from a given sign pattern instead of from ``h`` itself."""
+    if _FORCED is None:
+        return F.leaky_relu(h, slope) if slope != 0.0 else F.relu(h)
+    m = _FORCED['masks'].pop(0)
+    pos = m.to(h.device) > 0
+    _FORCED['flips'] += int((pos != (h > 0)).sum())
+    _FORCED['elements'] += h.numel()
+    return h * torch.where(pos, torch.ones((), dtype=h.dtype), torch.full((), float(slope), dtype=h.dtype))
+
+
+class forced_signs(object):
+    """Adjudication aid (tests/test_fp64_adjudicator.py): evaluate the networks on the LINEAR PIECE selected by a given list of
+    activation sign patterns (one tensor per activation call, in call order, NCHW) instead of the piece the evaluation itself
+    would select.  The networks are piecewise linear in their LeakyReLU branches, so two fp32 evaluations that disagree on a
+    single branch differ by O(1e-4..1e-3) in their gradients; conditioning an fp64 evaluation on the other party's branches
+    gives the exact gradient OF THAT PIECE, against which pure arithmetic error can be measured.  ``.flips`` counts the branches
+    that differ from the ones the evaluation would have chosen itself."""
+
+    def __init__(self, masks):
+        self.state = dict(masks=list(masks), flips=0, elements=0)
+
+    def __enter__(self):
+        global _FORCED
+        _FORCED = self.state
+        return self
+
+    def __exit__(self, *exc):
+        global _FORCED
+        _FORCED = None
+        if exc[0] is None and self.state['masks']:
+            raise RuntimeError('%d sign patterns were not consumed' % len(self.state['masks']))
+        return False
+
+    @property
+    def flips(self):
+        return self.state['flips']
+
+    @property
+    def elements(self):
+        return self.state['elements']
 
 
 def generator_forward(p, cfg, z, depth, alpha):
@@ -212,10 +259,12 @@ def _leafify(p, names=None):
     return q
 
 
-def gradient_penalty(dp, cfg, real, fake, mix, depth, alpha, iwass_lambda, iwass_target):
-    """reference wgan_gp_loss.py:13-33.  ``mix`` [N,1] is the U[0,1) draw of :15-17 (weights *fake*)."""
+def gradient_penalty(dp, cfg, real, fake, mix, depth, alpha, iwass_lambda, iwass_target, mixed=None):
+    """reference wgan_gp_loss.py:13-33.  ``mix`` [N,1] is the U[0,1) draw of :15-17 (weights *fake*).
+    (``mixed`` given: adjudication aid — the interpolated samples are taken as they are instead of being re-derived.)"""
     n = real.size(0)
-    mixed = (real.reshape(n, -1) * (1 - mix) + fake.reshape(n, -1) * mix).reshape(real.shape)  # :8-10,19
+    if mixed is None:
+        mixed = (real.reshape(n, -1) * (1 - mix) + fake.reshape(n, -1) * mix).reshape(real.shape)  # :8-10,19
     mixed = mixed.detach().requires_grad_(True)
     scores = discriminator_forward(dp, cfg, mixed, depth, alpha)                   # :20
     g = torch.autograd.grad(scores, mixed, torch.ones_like(scores),
@@ -225,7 +274,7 @@ def gradient_penalty(dp, cfg, real, fake, mix, depth, alpha, iwass_lambda, iwass
 
 
 def d_loss_and_grads(dparams, gparams, cfg, real, latents, mix, depth, alpha,
-                     iwass_lambda=10.0, iwass_epsilon=0.001, iwass_target=1.0):
+                     iwass_lambda=10.0, iwass_epsilon=0.001, iwass_target=1.0, fake=None, mixed=None):
     """``wgan_gp_D_loss`` + ``D_cost.backward()``  (wgan_gp_loss.py:36-65, trainer.py:95-98).
 
     Returns dict(D_cost, D_real_loss[N,1], D_fake_loss[N,1], gp[N], fake, grads{name: tensor}).
@@ -234,11 +283,15 @@ def d_loss_and_grads(dparams, gparams, cfg, real, latents, mix, depth, alpha,
     dp = _leafify(dparams)
     d_real = discriminator_forward(dp, cfg, real, depth, alpha)                   # :47
     d_real_loss = -d_real + d_real ** 2 * iwass_epsilon                           # :48
-    with torch.no_grad():
-        fake = generator_forward(gparams, cfg, latents, depth, alpha)             # :51-52 (no graph)
+    if fake is None:
+        with torch.no_grad():
+            fake = generator_forward(gparams, cfg, latents, depth, alpha)         # :51-52 (no graph)
+    # (``fake`` / ``mixed`` given: adjudication aid of tests/test_fp64_adjudicator.py — the D step as a function of FIXED images, so
+    #  that an fp64 evaluation differs from an fp32 one only by D's own arithmetic and not by G's forward rounding, which the
+    #  discontinuous LeakyReLU' amplifies)
     d_fake = discriminator_forward(dp, cfg, fake, depth, alpha)                   # :54
     d_fake_loss = d_fake                                                          # :55
-    gp = gradient_penalty(dp, cfg, real, fake, mix, depth, alpha, iwass_lambda, iwass_target)  # :58
+    gp = gradient_penalty(dp, cfg, real, fake, mix, depth, alpha, iwass_lambda, iwass_target, mixed=mixed)  # :58
     d_cost = (d_fake_loss + d_real_loss + gp).mean()                              # :62 ([N,1]+[N] -> [N,N])
     names = tensor_names(dp)
     gr = torch.autograd.grad(d_cost, [dp[k] for k in names], allow_unused=True)
@@ -259,6 +312,23 @@ def g_loss_and_grads(gparams, dparams, cfg, latents, depth, alpha):
     gr = torch.autograd.grad(g_cost, [gp_[k] for k in names], allow_unused=True)
     grads = OrderedDict((k, g) for k, g in zip(names, gr) if g is not None)
     return dict(G_cost=g_cost.detach(), fake=g_new.detach(), grads=grads)
+
+
+def d_input_gradient(dparams, cfg, x, depth, alpha):
+    """Adjudication aid: gradient of wgan_gp_G_loss's ``(-D(x)).mean()`` (wgan_gp_loss.py:72-73) with respect to the images x."""
+    x = x.detach().clone().requires_grad_(True)
+    cost = (-discriminator_forward(dparams, cfg, x, depth, alpha)).mean()
+    return torch.autograd.grad(cost, x)[0]
+
+
+def g_grads_given_output_gradient(gparams, cfg, latents, depth, alpha, grad_out):
+    """Adjudication aid: G's parameter gradients for a GIVEN d(cost)/d(G output) (the vector-Jacobian product of
+    generator_forward), i.e. trainer.py:111 with the discriminator half of the chain held fixed."""
+    gp_ = _leafify(gparams)
+    out = generator_forward(gp_, cfg, latents, depth, alpha)
+    names = tensor_names(gp_)
+    gr = torch.autograd.grad(out, [gp_[k] for k in names], grad_outputs=grad_out.to(out.dtype), allow_unused=True)
+    return OrderedDict((k, g) for k, g in zip(names, gr) if g is not None)
 
 
 # ----------------------------------------------------------------------------------------

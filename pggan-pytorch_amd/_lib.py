@@ -70,6 +70,9 @@ SIGNATURES = {
     'pg_image_grid_u8': [P, P, I, I, I, I, I, F, F, P],
     'pg_pyramid_level_u8': [P, P, L, I, I, I, F, F, P],
     'pg_zero': [P, L, P],
+    'pg_stft_abslog': [P, L, I, P, I, I, I, I, P],
+    'pg_minmax_f32': [P, L, P, P],
+    'pg_stretch_to_u8': [P, P, L, P, F, P],
     # gradient exchange (RCCL bound at run time inside the library)
     'pg_rccl_version': [P],
     'pg_comm_unique_id': [P],

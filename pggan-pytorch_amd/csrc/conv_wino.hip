@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "pggan_hip.h"
 #include "bufload.h"
 
@@ -34,6 +35,7 @@ struct WinoP {
     float* yup; const float* upmask; float up_mul;
     int mask_bytes, y_bytes;                   // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES, pggan_hip.h)
     unsigned char* ysigns;                     // PG_FLAG_SIGNS_OUT
+    int dma_mode;                              // second generation: where the next chunk's LDS-DMA is issued (0 after the patch reads, 1 after the transform, 2 spread over the MFMA groups)
 #ifdef PG_WINO_TRACE
     unsigned long long* trace;                 // [workgroup][wave][chunk][8] s_memtime stamps (tools/exp/wino_trace.py)
 #endif
@@ -48,6 +50,16 @@ struct WinoP {
 
 template <int VEC> struct WRow { static constexpr int value = VEC == 4 ? 24 : 12; };   // LDS row stride (floats), conflict-free b128 / b64
 constexpr int XMAX = 400;                      // halo pixels per workgroup: 18x18 (8x8 tiles) .. 4 x 10x10 (8x8 images)
+
+// Winograd-domain weights are stored in 8-channel packs: U[Cin/8][16 positions][Cout][8] — the slice a workgroup stages per
+// 8-channel K chunk (16 positions x its couts x 8 channels) is then 16 contiguous pieces of couts*32 bytes, i.e. whole 128-byte
+// cache lines that are consumed completely while they are hot, instead of 32 bytes out of every Cin*4-byte row of a
+// [16][Cout][Cin] array (every line fetched from L2 four times, 2-4 us apart).  Measured on the second-generation kernel:
+// 128.6 -> 112.0 us on n9 @64 128->256 with 16-channel packs (tools/sweep_wino.py).
+__host__ __device__ __forceinline__ size_t wino_u_index(size_t xi, size_t co, size_t ci, size_t Cout)
+{
+    return (((ci >> 3) * 16 + xi) * Cout + co) * 8 + (ci & 7);
+}
 
 __device__ __forceinline__ float4 sign_factors(unsigned char b, float slope)
 {
@@ -73,13 +85,100 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
             t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
             t[3][b] = g[2][b];
         }
+        const size_t co = i / Cin, ci = i - co * Cin;
+        float* ub = u + wino_u_index(0, co, ci, Cout);
+        const size_t xs = (size_t)Cout * 8;               // stride between Winograd positions inside a pack
 #pragma unroll
         for (int a = 0; a < 4; ++a) {                     // U = t G^T
-            u[(size_t)(4 * a + 0) * n + i] = t[a][0];
-            u[(size_t)(4 * a + 1) * n + i] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
-            u[(size_t)(4 * a + 2) * n + i] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
-            u[(size_t)(4 * a + 3) * n + i] = t[a][2];
+            ub[(size_t)(4 * a + 0) * xs] = t[a][0];
+            ub[(size_t)(4 * a + 1) * xs] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
+            ub[(size_t)(4 * a + 2) * xs] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
+            ub[(size_t)(4 * a + 3) * xs] = t[a][2];
         }
+    }
+}
+
+// Output transform Y = A^T M A of one lane's (tile, 4 couts) products (lane-local: the lane holds all 16 Winograd positions),
+// then the fused epilogue on the 2x2 outputs of the tile.  cb: first of the lane's 4 couts, ni: image, (oy0, ox0): first output pixel.
+__device__ __forceinline__ void wino_epilogue(const WinoP& p, const f32x4 (&acc)[16], int cb, int ni, int oy0, int ox0)
+{
+    // ---- output transform Y = A^T M A (lane-local), then the fused epilogue on the 2x2 outputs
+    f32x4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = acc[0 + j] + acc[4 + j] + acc[8 + j];
+        s[1][j] = acc[4 + j] - acc[8 + j] - acc[12 + j];
+    }
+    f32x4 yq[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        yq[a][0] = s[a][0] + s[a][1] + s[a][2];
+        yq[a][1] = s[a][1] - s[a][2] - s[a][3];
+    }
+    if (cb >= p.Cout || ni >= p.N) return;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + cb);
+    float4 ov[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = yq[q >> 1][q & 1];
+        const size_t off = (((size_t)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1)) * p.Cout + cb;
+        float4 o = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
+        if (p.mask) {
+            float4 f;
+            if (p.mask_bytes) f = sign_factors(reinterpret_cast<const unsigned char*>(p.mask)[off >> 2], p.mask_slope);
+            else {
+                const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
+                f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
+                                mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
+            }
+            o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+        } else {
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+            o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
+            o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+        }
+        ov[q] = o;
+        if (p.yup) {                                         // pool adjoint: four masked copies of every output
+            const float k = p.up_mul * 0.25f;
+            const size_t W2 = (size_t)2 * p.W;
+            const size_t ubase = (((size_t)ni * 2 * p.H + 2 * (oy0 + (q >> 1))) * W2 + 2 * (ox0 + (q & 1))) * p.Cout + cb;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const size_t uo = ubase + ((size_t)(dd >> 1) * W2 + (dd & 1)) * p.Cout;
+                float4 w4 = make_float4(o.x * k, o.y * k, o.z * k, o.w * k);
+                if (p.upmask) {
+                    float4 f;
+                    if (p.mask_bytes) f = sign_factors(reinterpret_cast<const unsigned char*>(p.upmask)[uo >> 2], p.mask_slope);
+                    else {
+                        const float4 mk = *reinterpret_cast<const float4*>(p.upmask + uo);
+                        f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
+                                        mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
+                    }
+                    w4.x *= f.x; w4.y *= f.y; w4.z *= f.z; w4.w *= f.w;
+                }
+                *reinterpret_cast<float4*>(p.yup + uo) = w4;
+            }
+        } else if (p.y_bytes) {                                  // only the sign is kept (the pooled output follows)
+            reinterpret_cast<unsigned char*>(p.y)[off >> 2] =
+                (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+        } else if (!(p.ypool && p.pool_only)) {
+            *reinterpret_cast<float4*>(p.y + off) = o;
+        }
+        if (p.ysigns)
+            p.ysigns[off >> 2] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+    }
+    if (p.ypool) {                                           // the 2x2 outputs of a tile ARE one pooled pixel
+        float4 v;
+        v.x = ((ov[0].x + ov[1].x) + (ov[2].x + ov[3].x)) * 0.25f; v.y = ((ov[0].y + ov[1].y) + (ov[2].y + ov[3].y)) * 0.25f;
+        v.z = ((ov[0].z + ov[1].z) + (ov[2].z + ov[3].z)) * 0.25f; v.w = ((ov[0].w + ov[1].w) + (ov[2].w + ov[3].w)) * 0.25f;
+        const size_t poff = (((size_t)ni * (p.H >> 1) + (oy0 >> 1)) * (p.W >> 1) + (ox0 >> 1)) * p.Cout + cb;
+        if (p.pool_other) {
+            const float4 q = *reinterpret_cast<const float4*>(p.pool_other + poff);
+            v.x = fmaf(v.x, p.pool_a, p.pool_b * q.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * q.y);
+            v.z = fmaf(v.z, p.pool_a, p.pool_b * q.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * q.w);
+        } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
+        *reinterpret_cast<float4*>(p.ypool + poff) = v;
     }
 }
 
@@ -155,8 +254,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         const int r = idx / VEC, v = idx - r * VEC;          // r = xi*16 + co
         const int xi = r >> 4, co = co0 + (r & 15);
         udst[i] = r * KCP + 4 * v;
-        usrc[i] = co < p.Cout ? 4u * (unsigned)((xi * p.Cout + co) * p.Cin + 4 * v) : PG_OOB;
+        usrc[i] = co < p.Cout ? 4u * (unsigned)((((v >> 1) * 16 + xi) * p.Cout + co) * 8 + 4 * (v & 1)) : PG_OOB;   // packs k0/8 (+1): wino_u_index
     }
+    const unsigned upack = 4u * 16u * 8u * (unsigned)p.Cout;                                      // bytes of one 8-channel pack
 
     f32x4 acc[16];
 #pragma unroll
@@ -165,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
     float4 xreg[XPT], ureg[UPT];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < UPT; ++i) ureg[i] = pg_buf_load4(ru, usrc[i], 4u * (unsigned)k0);
+        for (int i = 0; i < UPT; ++i) ureg[i] = pg_buf_load4(ru, usrc[i], (unsigned)(k0 >> 3) * upack);
 #pragma unroll
         for (int i = 0; i < XPT; ++i) xreg[i] = pg_buf_load4(rx, xsrc[i], 4u * (unsigned)k0);
     };
@@ -235,87 +335,197 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
         PG_STAMP(6);
     }
 
-    // ---- output transform Y = A^T M A (lane-local), then the fused epilogue on the 2x2 outputs
-    f32x4 s[2][4];
+    wino_epilogue(p, acc, co0 + 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
+#ifdef PG_WINO_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.trace && lane == 0 && blockIdx.x < 1024) p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + 1) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Second-generation Winograd conv: input-transform reuse + LDS-DMA staging (round-2 rebuild).
+//
+// What the phase trace of conv_wino_kernel<4> showed (tools/exp/wino_trace.py, n9 @64 128->256, cycles per 16-channel chunk
+// and wave, two workgroups per CU): LDS store of the staged registers 1200 (ds_write_b128 moves 79 B/clk/CU), barrier 800,
+// fetch issue 520, patch reads + input transform 1000, 64 MFMAs 3100 (2048 if the pipe were free), barrier 300: the matrix
+// pipe is busy 58 % even on the best layers because 3900 of 7000 cycles per chunk are staging / transform work that every
+// 16-cout workgroup repeats for the same input region.
+//
+// This kernel:
+//   * one workgroup owns 64 tiles x 16*NCB couts (NCB = 2: the transformed input V is computed ONCE per 32 couts, half the
+//     patch reads / transforms / input staging per MFMA; 32-channel layers have all their couts in one workgroup, so their
+//     input region is fetched once instead of once per 16 couts);
+//   * K chunks of 8 channels, staged global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs (that is
+//     what makes 128 accumulator registers + two waves per SIMD fit), no ds_write pass, out-of-image pixels zero-filled by
+//     the buffer bounds check; double-buffered, ONE barrier per chunk;
+//   * the LDS image is "quad-planar": plane q holds channels 4q..4q+3 of every pixel (resp. every (xi, cout) row of U)
+//     as consecutive 16-byte slots — the layout LDS-DMA can write (wave-uniform base + lane * 16) — and region rows are
+//     shifted by one slot on every second tile row, so that the 16 tiles a wave reads with one ds_read_b64 (2 tile rows x 8
+//     tiles, 2 pixels apart) cover the 256-byte bank row exactly once: conflict-free patch and fragment reads.
+template <int NCB>
+__global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 waves per SIMD: <= 256 VGPRs + AGPRs
+{
+    constexpr int KC = 8;
+    constexpr int XS = 4;                                    // DMA instructions per thread and chunk for the input region (<= 1024 slots)
+    constexpr int US = 2 * NCB;                              // ... for the U chunk: 2 planes x 16 xi x 16*NCB rows / 256
+    constexpr int XSLOTS = XS * 256, USLOTS = US * 256;
+    constexpr int BUF = (XSLOTS + USLOTS) * 4;               // floats per buffer
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __align__(16) float lds[];
+    const int TTW = 1 << p.lgTW, TTH = 1 << p.lgTH;
+    const int WT = 2 * TTW + 2, HT = 2 * TTH + 2, WTP = WT + 1;
+    const int npixp = p.TN * HT * WTP;                       // slots of one input plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+#ifdef PG_WINO_TRACE
+    if (p.trace && lane == 0 && blockIdx.x < 1024) p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + 0) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
+    int b = (int)pg_xcd_remap(blockIdx.x, gridDim.x);
+    int cob;
+    if (p.cout_minor) { cob = b % p.ncob; b /= p.ncob; }
+    else { const int ntb = (int)gridDim.x / p.ncob; cob = b / ntb; b -= cob * ntb; }
+    const int bw = b % p.blocksW; b /= p.blocksW;
+    const int bh = b % p.blocksH; b /= p.blocksH;
+    const int n0 = b * p.TN;
+    const int ty0 = bh << p.lgTH, tx0 = bw << p.lgTW;
+    const int co0 = cob * 16 * NCB;
+    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
+
+    const int t = wave * 16 + li;
+    const int ttx = t & (TTW - 1), tty = (t >> p.lgTW) & (TTH - 1), ttn = t >> (p.lgTW + p.lgTH);
+    // byte offset of patch element (a, c) inside a buffer: plane (kk >> 1), slot of pixel (2 tty + a, 2 ttx + c), half (kk & 1)
+    int prow[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[0][j] = acc[0 + j] + acc[4 + j] + acc[8 + j];
-        s[1][j] = acc[4 + j] - acc[8 + j] - acc[12 + j];
+    for (int a = 0; a < 4; ++a) {
+        const int y = 2 * tty + a;
+        prow[a] = ((kk >> 1) * npixp + (ttn * HT + y) * WTP + 2 * ttx + ((y >> 1) & 1)) * 16 + (kk & 1) * 8;
     }
-    f32x4 yq[2][2];
+    const int ubyte = XSLOTS * 16 + ((kk >> 1) * 256 * NCB + li) * 16 + (kk & 1) * 8;     // + (xi * 16 * NCB + cb * 16) * 16
+
+    const size_t img = (size_t)xH * xW * p.Cin;
+    const int nimg = min(p.TN, p.N - n0);
+    // DMA descriptors: instruction i of wave w fills slots [(i*4 + w)*64, +64); lane l supplies slot (i*4 + w)*64 + l
+    unsigned xsrc[XS], usrc[US];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        yq[a][0] = s[a][0] + s[a][1] + s[a][2];
-        yq[a][1] = s[a][1] - s[a][2] - s[a][3];
+    for (int i = 0; i < XS; ++i) {
+        const int sl = (i * 4 + wave) * 64 + lane;
+        const int q = sl >= npixp ? 1 : 0, pi = sl - q * npixp;
+        const int row = (int)__umulhi((unsigned)pi, p.mWT), xs = pi - row * WTP;        // mWT: magic reciprocal of WTP here
+        const int tn = (int)__umulhi((unsigned)row, p.mHT), y = row - tn * HT;
+        const int x = xs - ((y >> 1) & 1);
+        int ih = 2 * ty0 + y - 1, iw = 2 * tx0 + x - 1;
+        const bool ok = pi < npixp && sl < 2 * npixp && (unsigned)x < (unsigned)WT && n0 + tn < p.N &&
+                        (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        if (p.ups) { ih >>= 1; iw >>= 1; }
+        xsrc[i] = ok ? 4u * (unsigned)(((tn * xH + ih) * xW + iw) * p.Cin + 4 * q) : PG_OOB;
     }
-    const int cb = co0 + 4 * kk;
-    const int ni = n0 + ttn;
-    if (cb >= p.Cout || ni >= p.N) return;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + cb);
-    const int oy0 = 2 * (ty0 + tty), ox0 = 2 * (tx0 + ttx);
-    float4 ov[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 v = yq[q >> 1][q & 1];
-        const size_t off = (((size_t)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1)) * p.Cout + cb;
-        float4 o = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
-        if (p.mask) {
-            float4 f;
-            if (p.mask_bytes) f = sign_factors(reinterpret_cast<const unsigned char*>(p.mask)[off >> 2], p.mask_slope);
-            else {
-                const float4 mk = *reinterpret_cast<const float4*>(p.mask + off);
-                f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
-                                mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
-            }
-            o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
-        } else {
-            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
-            o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
-            o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+    for (int i = 0; i < US; ++i) {
+        const int sl = (i * 4 + wave) * 64 + lane;
+        const int q = sl / (256 * NCB), r = sl - q * 256 * NCB;                          // r = xi * 16*NCB + co
+        const int xi = r / (16 * NCB), co = co0 + r - xi * 16 * NCB;
+        usrc[i] = co < p.Cout ? 4u * (unsigned)((xi * p.Cout + co) * 8 + 4 * q) : PG_OOB;        // inside the 8-channel pack k0/8 (wino_u_index)
+    }
+    const unsigned upack = 4u * 16u * 8u * (unsigned)p.Cout;
+    // LDS-DMA through inline asm: hipcc orders every later LDS read behind an LDS-DMA it can see (s_waitcnt vmcnt(0) before the
+    // next ds_read), which would drain the prefetch of the NEXT chunk before the MFMAs of this one; the copies are ordered by hand
+    // instead (the vmcnt(0) + barrier at the top of every chunk).  M0 = LDS byte address of the wave's 1 KiB destination.
+    auto rsrc_words = [](const void* base, unsigned bytes) {        // the raw buffer descriptor pg_make_rsrc builds, as four SGPR words
+        const unsigned long long a = (unsigned long long)base;
+        return pg_u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+    };
+    const pg_u32x4 rxs = rsrc_words(p.x + (size_t)n0 * img, (unsigned)(nimg * img * 4));
+    const pg_u32x4 rus = rsrc_words(p.u, (unsigned)((size_t)16 * p.Cout * p.Cin * 4));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto dma16 = [&](const pg_u32x4& rs, unsigned voff, unsigned soff, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(dst) : "memory");
+    };
+    // pieces [first, last) of the next chunk's copy (US pieces of U, then the input-region pieces)
+    auto dma = [&](int k0, int buf, int first, int last) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * BUF * 4u + (unsigned)wave * 1024u);
+        const unsigned soff = 4u * (unsigned)k0, usoff = (unsigned)(k0 >> 3) * upack;
+#pragma unroll
+        for (int i = 0; i < US; ++i)
+            if (i >= first && i < last) dma16(rus, usrc[i], usoff, base + XSLOTS * 16 + i * 4096);
+#pragma unroll
+        for (int i = 0; i < XS; ++i)
+            if (US + i >= first && US + i < last && (i * 4) * 64 < 2 * npixp) dma16(rxs, xsrc[i], soff, base + i * 4096);   // (workgroup-uniform)
+    };
+    constexpr int NP = US + XS;
+
+    f32x4 acc[NCB][16];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    dma(0, 0, 0, NP);
+    int buf = 0;
+    for (int k0 = 0; k0 < p.Cin; k0 += KC, buf ^= 1) {
+        PG_STAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of the chunk has landed ...
+        PG_STAMP(1);
+        __syncthreads();
+        PG_STAMP(2);                                      // ... everyone's has, and nobody still reads the other buffer
+        // explicit LDS address space: a volatile access through a generic pointer would become a flat load (vmcnt + lgkmcnt)
+        typedef __attribute__((address_space(3))) const char* lds_cptr;
+        typedef __attribute__((address_space(3))) const volatile v2* lds_v2ptr;
+        const lds_cptr xb = (lds_cptr)lds + buf * BUF * 4;
+        v2 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[a][c] = *(lds_v2ptr)(xb + prow[a] + c * 16);   // volatile: keep ds_read_b64 (a merged ds_read2_b64 is half rate)
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = k0 + KC < p.Cin;
+        if (more && p.dma_mode == 0) dma(k0 + KC, buf ^ 1, 0, NP);   // in flight under the transform and the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+        PG_STAMP(3);
+        // V = B^T d B, in place
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const v2 t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
+            d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
         }
-        ov[q] = o;
-        if (p.yup) {                                         // pool adjoint: four masked copies of every output
-            const float k = p.up_mul * 0.25f;
-            const size_t W2 = (size_t)2 * p.W;
-            const size_t ubase = (((size_t)ni * 2 * p.H + 2 * (oy0 + (q >> 1))) * W2 + 2 * (ox0 + (q & 1))) * p.Cout + cb;
 #pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                const size_t uo = ubase + ((size_t)(dd >> 1) * W2 + (dd & 1)) * p.Cout;
-                float4 w4 = make_float4(o.x * k, o.y * k, o.z * k, o.w * k);
-                if (p.upmask) {
-                    float4 f;
-                    if (p.mask_bytes) f = sign_factors(reinterpret_cast<const unsigned char*>(p.upmask)[uo >> 2], p.mask_slope);
-                    else {
-                        const float4 mk = *reinterpret_cast<const float4*>(p.upmask + uo);
-                        f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
-                                        mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
-                    }
-                    w4.x *= f.x; w4.y *= f.y; w4.z *= f.z; w4.w *= f.w;
-                }
-                *reinterpret_cast<float4*>(p.yup + uo) = w4;
-            }
-        } else if (p.y_bytes) {                                  // only the sign is kept (the pooled output follows)
-            reinterpret_cast<unsigned char*>(p.y)[off >> 2] =
-                (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
-        } else if (!(p.ypool && p.pool_only)) {
-            *reinterpret_cast<float4*>(p.y + off) = o;
+        for (int a = 0; a < 4; ++a) {
+            const v2 t0 = d[a][0] - d[a][2], t1 = d[a][1] + d[a][2], t2 = d[a][2] - d[a][1], t3 = d[a][1] - d[a][3];
+            d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
         }
-        if (p.ysigns)
-            p.ysigns[off >> 2] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && p.dma_mode == 1) dma(k0 + KC, buf ^ 1, 0, NP);
+        __builtin_amdgcn_sched_barrier(0);
+        PG_STAMP(4);
+        const lds_cptr ub = xb + ubyte;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                         // one row of Winograd positions at a time: 4 x NCB accumulators interleaved
+            v2 af[NCB][4];
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[c][j] = *(lds_v2ptr)(ub + (((g * 4 + j) * NCB + c) * 16) * 16);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c)
+                        acc[c][4 * g + j] = MFMA16(af[c][j][s2], d[g][j][s2], acc[c][4 * g + j]);
+            if (more && p.dma_mode == 2 && g < 2) {            // half of the pieces behind each of the first two MFMA groups
+                __builtin_amdgcn_sched_barrier(0);
+                dma(k0 + KC, buf ^ 1, g == 0 ? 0 : (NP + 1) / 2, g == 0 ? (NP + 1) / 2 : NP);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        PG_STAMP(5);
+        PG_STAMP(6);
     }
-    if (p.ypool) {                                           // the 2x2 outputs of a tile ARE one pooled pixel
-        float4 v;
-        v.x = ((ov[0].x + ov[1].x) + (ov[2].x + ov[3].x)) * 0.25f; v.y = ((ov[0].y + ov[1].y) + (ov[2].y + ov[3].y)) * 0.25f;
-        v.z = ((ov[0].z + ov[1].z) + (ov[2].z + ov[3].z)) * 0.25f; v.w = ((ov[0].w + ov[1].w) + (ov[2].w + ov[3].w)) * 0.25f;
-        const size_t poff = (((size_t)ni * (p.H >> 1) + (oy0 >> 1)) * (p.W >> 1) + (ox0 >> 1)) * p.Cout + cb;
-        if (p.pool_other) {
-            const float4 q = *reinterpret_cast<const float4*>(p.pool_other + poff);
-            v.x = fmaf(v.x, p.pool_a, p.pool_b * q.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * q.y);
-            v.z = fmaf(v.z, p.pool_a, p.pool_b * q.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * q.w);
-        } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
-        *reinterpret_cast<float4*>(p.ypool + poff) = v;
-    }
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+        wino_epilogue(p, acc[c], co0 + 16 * c + 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
 #ifdef PG_WINO_TRACE
     __builtin_amdgcn_sched_barrier(0);
     if (p.trace && lane == 0 && blockIdx.x < 1024) p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + 1) * 8 + 7] = __builtin_amdgcn_s_memtime();
@@ -352,12 +562,15 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
         t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
         t[3][b] = g[2][b];
     }
+    const size_t co = i / d.cin[l], ci = i - co * d.cin[l];
+    float* ub = u + wino_u_index(0, co, ci, d.cout[l]);
+    const size_t xs = (size_t)d.cout[l] * 8;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        u[(size_t)(4 * a + 0) * n + i] = t[a][0];
-        u[(size_t)(4 * a + 1) * n + i] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
-        u[(size_t)(4 * a + 2) * n + i] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
-        u[(size_t)(4 * a + 3) * n + i] = t[a][2];
+        ub[(size_t)(4 * a + 0) * xs] = t[a][0];
+        ub[(size_t)(4 * a + 1) * xs] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
+        ub[(size_t)(4 * a + 2) * xs] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
+        ub[(size_t)(4 * a + 3) * xs] = t[a][2];
     }
 }
 
@@ -368,7 +581,8 @@ thread_local char g_wino_last[64] = "";
 #ifdef PG_WINO_TRACE
 thread_local unsigned long long* g_wino_trace = nullptr;
 #endif
-thread_local int g_wino_vec = 4;               // K-chunk = 4*vec channels (pg_debug_set_wino)
+thread_local int g_wino_vec = 0;               // 2 / 4: first-generation kernel with K chunks of 4*vec channels; 0: second-generation kernel,
+                                               // built-in choice of couts per workgroup; 11 / 12: second generation, 16 / 32 couts (pg_debug_set_wino)
 
 }  // namespace
 
@@ -376,11 +590,17 @@ extern "C" const char* pg_debug_last_wino_kernel(void) { return g_wino_last; }
 #ifdef PG_WINO_TRACE
 extern "C" int pg_debug_wino_trace(void* buf) { g_wino_trace = (unsigned long long*)buf; return 0; }
 #endif
-extern "C" int pg_debug_set_wino(int vec) { if (vec != 2 && vec != 4) return PG_E_ARG; g_wino_vec = vec; return 0; }
+extern "C" int pg_debug_set_wino(int vec)
+{
+    if (vec != 0 && vec != 2 && vec != 4 && vec != 11 && vec != 12) return PG_E_ARG;
+    g_wino_vec = vec;
+    return 0;
+}
 
 extern "C" int pg_wino_transform_weights(const float* w, float* u, int Cout, int Cin, pg_stream_t stream)
 {
     if (!w || !u || Cout <= 0 || Cin <= 0) return PG_E_ARG;
+    if (Cin & 7) return PG_E_ALIGN;                         // 8-channel packs
     size_t g = ((size_t)Cout * Cin + 255) / 256; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, u, Cout, Cin);
     return (int)hipGetLastError();
@@ -397,6 +617,7 @@ extern "C" int pg_wino_transform_weights_batched(const float* wbase, float* ubas
         for (int l = 0; l < d.n; ++l) {
             const int i = l0 + l;
             if (cout[i] <= 0 || cin[i] <= 0 || woff[i] < 0 || uoff[i] < 0) return PG_E_ARG;
+            if (cin[i] & 7) return PG_E_ALIGN;
             d.first_block[l] = total;
             d.woff[l] = woff[i]; d.uoff[l] = uoff[i]; d.cout[l] = cout[i]; d.cin[l] = cin[i];
             total += (int)(((size_t)cout[i] * cin[i] + 255) / 256);
@@ -451,10 +672,35 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
     }
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     const int vec = g_wino_vec;
+    const int ntb = ((N + TN - 1) / TN) * p.blocksH * p.blocksW;                 // tile blocks of 64 tiles
+    if (vec >= 10 || vec == 0) {
+        // second-generation kernel (LDS-DMA, 8-channel chunks, 16*NCB couts per workgroup); two cout blocks per workgroup
+        // when that still leaves at least two workgroups per CU
+        int ncb = vec >= 10 ? vec - 10 : ((Cin >= 512 && (long long)ntb * ((Cout + 31) / 32) >= 768) ? 2 : 1);   // measured: tools/sweep_wino.py
+        if (ncb != 1 && ncb != 2) return PG_E_ARG;
+        static const int dma_mode = getenv("PG_WINO_DMA") ? atoi(getenv("PG_WINO_DMA")) : 0;     // tuning aid (tools/sweep_wino.py)
+        p.dma_mode = dma_mode;
+        const int WTP = WT + 1;
+        if (2 * TN * HT * WTP > 1024) return PG_E_UNSUP;
+        p.mWT = (unsigned)((1ull << 32) / (unsigned)WTP) + 1u;
+        p.ncob = (Cout + 16 * ncb - 1) / (16 * ncb);
+        p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20);
+        const size_t smem2 = (size_t)2 * (1024 + 512 * ncb) * 16;
+        dim3 grid2((unsigned)(ntb * p.ncob));
+        snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d>", ncb);
+        const void* fn = ncb == 2 ? reinterpret_cast<const void*>(conv_wino2_kernel<2>) : reinterpret_cast<const void*>(conv_wino2_kernel<1>);
+        if (smem2 > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (ncb == 2) hipLaunchKernelGGL(conv_wino2_kernel<2>, grid2, dim3(256), smem2, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(conv_wino2_kernel<1>, grid2, dim3(256), smem2, (hipStream_t)stream, p);
+        return (int)hipGetLastError();
+    }
     const size_t smem = ((size_t)16 * 16 * (vec == 4 ? 24 : 12) + (size_t)TN * HT * WT * (vec == 4 ? 20 : 12)) * sizeof(float);
     p.ncob = (Cout + 15) / 16;
     p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20);      // measured: tools/sweep_wino.py
-    dim3 grid((unsigned)(((N + TN - 1) / TN) * p.blocksH * p.blocksW * p.ncob));
+    dim3 grid((unsigned)(ntb * p.ncob));
     snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino_kernel<%d>", vec);
     if (vec == 4) {
         if (smem > 48 * 1024) {

@@ -57,8 +57,15 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
     return (y, sb) if signs_out else y
 
 
+def wino_unpack(u):
+    """Device layout of the Winograd-domain weights (8-channel packs, [Cin/8][16][Cout][8], csrc/conv_wino.hip::wino_u_index)
+    -> plain [16, Cout, Cin] (tests / diagnostics)."""
+    _, cout, cin = u.shape
+    return u.reshape(cin // 8, 16, cout, 8).permute(1, 2, 0, 3).reshape(16, cout, cin)
+
+
 def wino_transform_weights(w, u=None):
-    """w packed [3,3,Cout,Cin] -> Winograd-domain weights u [16,Cout,Cin]."""
+    """w packed [3,3,Cout,Cin] -> Winograd-domain weights u, nominal shape [16,Cout,Cin], stored in 8-channel packs (``wino_unpack``)."""
     ks, _, cout, cin = w.shape
     assert ks == 3
     if u is None:
@@ -435,6 +442,26 @@ def real_prepare_u8(x_u8, alpha, range_in=(0, 255), range_out=(-1, 1)):
     out = torch.empty((N, C, H, W), device=x_u8.device, dtype=torch.float32)
     _lib.call('pg_real_prepare_u8', x_u8.data_ptr(), _p(out), N * C, H, W, float(alpha), float(range_in[0]),
               float(range_in[1]), float(range_out[0]), float(range_out[1]), _stream())
+    return out
+
+
+def spectrogram_u8(signal, n_fft, hop_length, max_out=255.0):
+    """fp32 device waveform [nsamp] or [nsamp, channels] -> uint8 'abslog' spectrogram image [1, n_fft/2, n_fft/2]
+    (SoundImageDataset.load_file, dataset.py:285-300)."""
+    require_gpu()
+    if not signal.is_cuda or signal.dtype != torch.float32 or not signal.is_contiguous() or signal.dim() not in (1, 2):
+        raise ValueError('expected a contiguous float32 device tensor [nsamp] or [nsamp, channels]')
+    nsamp = signal.shape[0]
+    ch = 1 if signal.dim() == 1 else signal.shape[1]
+    side = n_fft // 2
+    if 1 + nsamp // hop_length < side:
+        raise ValueError('%d samples give %d frames, the %dx%d image needs %d' % (nsamp, 1 + nsamp // hop_length, side, side, side))
+    mag = torch.empty((side, side), device=signal.device, dtype=torch.float32)
+    _lib.call('pg_stft_abslog', _p(signal), nsamp, ch, _p(mag), n_fft, hop_length, side, side, _stream())
+    lohi = torch.empty(2, device=signal.device, dtype=torch.float32)
+    _lib.call('pg_minmax_f32', _p(mag), mag.numel(), _p(lohi), _stream())
+    out = torch.empty((1, side, side), device=signal.device, dtype=torch.uint8)
+    _lib.call('pg_stretch_to_u8', _p(mag), out.data_ptr(), mag.numel(), _p(lohi), float(max_out), _stream())
     return out
 
 

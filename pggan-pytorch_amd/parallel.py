@@ -40,6 +40,9 @@ class DataParallel(object):
         self.comm_ranks = 0
         self._stream = None
         self.stats = dict(collectives=0, bytes=0)
+        self.record_events = False            # bench.py: HIP events around every collective on the stream it runs on
+        self.events = []
+        self.skip_exchange = False            # bench.py only: time the step with the collectives left out (exposed-exchange estimate)
         if torch.cuda.is_available() and os.environ.get('PGGAN_DP_TORCH_ALLREDUCE', '0') != '1':
             self._init_comm()
 
@@ -118,6 +121,22 @@ class DataParallel(object):
         ``pg_allreduce_sum_f32`` on ``stream`` (default: the current stream)."""
         self.stats['collectives'] += 1
         self.stats['bytes'] += flat.numel() * 4
+        if self.skip_exchange:
+            return flat
+        if self.record_events and flat.is_cuda:
+            s = stream if stream is not None else torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            self.record_events = False
+            try:
+                self.all_reduce_flat(flat, stream=stream)
+                self.stats['collectives'] -= 1
+                self.stats['bytes'] -= flat.numel() * 4
+            finally:
+                self.record_events = True
+            e1.record(s)
+            self.events.append((e0, e1))
+            return flat
         if self.comm is not None and flat.is_cuda:
             from . import _lib
             if flat.dtype != torch.float32 or not flat.is_contiguous():

@@ -35,13 +35,16 @@ def rampup(cur_nimg, lr_rampup_kimg=40):
 class SyntheticDataset(object):
     """Seeded synthetic images in [-1,1) with the DepthDataset protocol the DepthManager drives
     (``model_depth``, ``alpha``, ``shape``; reference dataset.py:31-70).  Batches are generated on the
-    device, so the benchmark measures the train step and not a host data loader."""
+    device, so the benchmark measures the train step and not a host data loader.
+    ``ring`` > 0: a loader pre-generates that many batches and cycles through them, so that no RNG kernel runs inside
+    the timed train steps (the reference's DataLoader workers produce batches off the step's critical path too)."""
 
-    def __init__(self, resolution, num_channels=3, seed=1337, device='cuda'):
+    def __init__(self, resolution, num_channels=3, seed=1337, device='cuda', ring=0):
         self.shape = (1, num_channels, resolution, resolution)
         self.model_depth = 0
         self.alpha = 1.0
         self.device = device
+        self.ring = int(ring)
         self._gen = torch.Generator(device=device)
         self._gen.manual_seed(int(seed))
 
@@ -51,6 +54,12 @@ class SyntheticDataset(object):
         return x.mul_(2).sub_(1)
 
     def loader(self, minibatch_size):
+        if self.ring > 0:
+            batches = [self.batch(minibatch_size) for _ in range(self.ring)]
+            i = 0
+            while True:
+                yield batches[i]
+                i = (i + 1) % len(batches)
         while True:
             yield self.batch(minibatch_size)
 
@@ -58,11 +67,24 @@ class SyntheticDataset(object):
         pass
 
 
-def device_latents(minibatch_size, latent_size, seed=1337, device='cuda'):
-    """Device-side replacement of ``random_latents`` for benchmarks (no H2D copy per iteration)."""
+def device_latents(minibatch_size, latent_size, seed=1337, device='cuda', ring=0):
+    """Device-side replacement of ``random_latents`` for benchmarks (no H2D copy per iteration).  ``ring`` > 0:
+    cycle through that many pre-generated draws (no RNG kernel inside the timed steps)."""
     gen = torch.Generator(device=device)
     gen.manual_seed(int(seed))
-    return lambda: torch.randn((minibatch_size, latent_size), device=device, dtype=torch.float32, generator=gen)
+
+    def draw():
+        return torch.randn((minibatch_size, latent_size), device=device, dtype=torch.float32, generator=gen)
+    if ring <= 0:
+        return draw
+    draws = [draw() for _ in range(ring)]
+    state = [0]
+
+    def cycle():
+        z = draws[state[0]]
+        state[0] = (state[0] + 1) % len(draws)
+        return z
+    return cycle
 
 
 def prepare_real_batch(batch_u8, alpha, range_in=(0, 255), range_out=(-1, 1)):

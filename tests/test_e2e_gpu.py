@@ -22,7 +22,9 @@ GRAD_TOL = 2e-3      # per-tensor gradient, rel. max-norm — small, well-condit
 # fp32 CPU path deviates from an fp64 evaluation by the same mechanism (tools/diag_grad_noise.py:
 # 2e-3 max-norm at 128x128).  Gradients are therefore compared in relative L2 norm per tensor, with a
 # loose max-norm guard, and in global relative L2 norm.
-GRAD_L2_TOL, GRAD_MAX_TOL, GRAD_GLOBAL_L2_TOL = 1e-2, 6e-2, 4e-3
+# (the claim is tested, not assumed: tests/test_fp64_adjudicator.py bounds |HIP - fp64| by 3 |fp32 oracle - fp64|; measured worst
+# values on MI355X: per-tensor rel-max 1.8e-2 (thin1024 depth 8), global rel-L2 1.7e-3)
+GRAD_L2_TOL, GRAD_MAX_TOL, GRAD_GLOBAL_L2_TOL = 1e-2, 2e-2, 2e-3
 DEV = 'cuda'
 
 
@@ -176,7 +178,8 @@ def test_trainer_trace_golden():
 
 @pytest.mark.parametrize('res,depth,alpha,n,fmap_base,C', [(128, 5, 1.0, 2, 4096, 3), (128, 4, 0.5, 3, 4096, 3),
                                                            (1024, 8, 1.0, 1, 4096, 3), (256, 6, 0.25, 2, 8192, 3),
-                                                           (256, 6, 1.0, 2, 4096, 1), (1024, 7, 0.5, 1, 4096, 3)])
+                                                           (256, 6, 1.0, 2, 4096, 1), (1024, 7, 0.5, 1, 4096, 3),
+                                                           (1024, 8, 1.0, 3, 4096, 3)])   # config 5's real minibatch: stddev couples the 3 samples
 def test_against_oracle_at_baseline_widths(oracle, res, depth, alpha, n, fmap_base, C):
     """HIP vs CPU oracle on seeded inputs at BASELINE.json widths (default 4096 and the paper's 8192), incl. the
     one-channel 256^2 spectrogram shape of config 4 and a fade-in stage of the 1024^2 net."""
@@ -537,4 +540,85 @@ def test_deferred_d_update_matches_inline(monkeypatch):
             if torch.is_tensor(v):
                 # Adam with beta1 = 0 is sign-like: a weight-gradient element within atomic round-off of zero may flip
                 assert float((v - b[k]).abs().max()) <= 2 * 0.001 * 3 + 1e-6, k
-                assert rel_err(v.cpu(), b[k].cpu()) < 2e-2, k
+                assert _l2(v, b[k].cpu()) < 3e-2, k      # (a flipped element moves by 2*lr per step: bounded above, L2 here)
+
+
+def test_config2_grow_run_against_oracle(oracle):
+    """BASELINE.json config 2 as written: the 32x32 network (default 512-channel widths) grown depth 0 -> 3 with alpha
+    fade-ins at minibatch 64, through Trainer + DepthManager + LRScheduler + FusedAdam, against the oracle's
+    ``train_iteration`` driven by the oracle's own schedule (lod spans shortened to 2 iterations so that every stage and
+    every fade occurs: 14 iterations, 192 stacked images per D pass)."""
+    N, LOD, ITERS, RAMP = 64, 128, 14, 0.256
+    torch.manual_seed(77)
+    shape = (1, 3, 32, 32)
+    G, D = pg.Generator(shape), pg.Discriminator(shape)
+    gp, dp = G.reference_state_dict(), D.reference_state_dict()
+    G.to(DEV)
+    D.to(DEV)
+    cfg = oracle.NetCfg(32, 3)
+    sched = [oracle.depth_schedule(it * N, 3, LOD, LOD, minibatch_default=N) for it in range(ITERS)]
+    assert sorted(set(d for d, _, _, _ in sched)) == [0, 1, 2, 3] and sum(1 for _, a, _, _ in sched if a < 1.0) == 6
+    batches = [oracle.synthetic_batch(300 + it, N, 3, 4 * 2 ** sched[it][0], 512) for it in range(ITERS)]
+    state = dict(it=0, z=0)
+
+    class Data(object):
+        model_depth, alpha = 0, 1.0
+
+    def make_loader(mb):
+        assert mb == N
+
+        def gen():
+            while True:
+                yield batches[state['it']][0]
+        return gen()
+
+    def make_rlg(mb):
+        def f():
+            b = batches[state['it']]
+            state['z'] += 1
+            return b[1] if state['z'] % 2 == 1 else b[2]
+        return f
+
+    def d_loss(Dm, Gm, real, z):
+        pg.wgan_gp_loss.set_mixing_factors(batches[state['it']][3])
+        return pg.wgan_gp_D_loss(Dm, Gm, real, z)
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    ramp = lambda nimg: pg.utils.rampup(nimg, RAMP)
+    tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, Data(), None, None)
+    tr.register_plugin(pg.DepthManager(make_loader, make_rlg, 3, minibatch_default=N, lod_training_nimg=LOD, lod_transition_nimg=LOD))
+    tr.register_plugin(pg.LRScheduler(pg.RampupLR(opt_d, ramp), pg.RampupLR(opt_g, ramp)))
+    losses = []
+
+    class Rec(pg.Plugin):
+        def __init__(self):
+            super(Rec, self).__init__([(1, 'iteration')])
+
+        def register(self, trainer):
+            pass
+
+        def iteration(self, i, g_cost, d_cost, d_real, d_fake):
+            losses.append((float(g_cost), float(d_cost)))
+    # Rec is registered last: it fires after DepthManager / LRScheduler have prepared the NEXT iteration
+    tr.register_plugin(Rec())
+    for q in tr.plugin_queues.values():
+        heapq.heapify(q)
+    og, od = oracle.AdamState(), oracle.AdamState()
+    for it in range(ITERS):
+        depth, alpha, mb, _ = sched[it]
+        assert (tr.cur_nimg, int(G.depth), repr(float(G.alpha)), tr.stats['minibatch_size']) == (it * N, depth, repr(alpha), mb)
+        state['it'], state['z'] = it, 0
+        tr.train()
+        real, z_d, z_g, mix = batches[it]
+        lr = 0.001 * oracle.rampup(it * N, RAMP)
+        d, g = oracle.train_iteration(gp, dp, cfg, og, od, real, z_d, z_g, mix, depth, alpha, lr, lr)
+        gc, dc = losses[it]
+        tol = 5e-4 if it == 0 else 3e-3          # later iterations inherit sign-like Adam(beta1=0) steps on round-off-sized gradients
+        assert abs(dc - float(d['D_cost'])) < tol * max(1.0, abs(float(d['D_cost']))), (it, dc, float(d['D_cost']))
+        assert abs(gc - float(g['G_cost'])) < tol * max(1.0, abs(float(g['G_cost']))), (it, gc, float(g['G_cost']))
+    for name, ref, net in (('G', gp, G), ('D', dp, D)):
+        mine = net.reference_state_dict()
+        for k, v in ref.items():
+            if torch.is_tensor(v):
+                assert float((mine[k].cpu() - v).abs().max()) < 2 * 0.001 * ITERS + 1e-4, (name, k)
+                assert _l2(mine[k].cpu(), v) < 2e-2, (name, k, _l2(mine[k].cpu(), v))

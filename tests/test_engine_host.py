@@ -262,3 +262,19 @@ def test_no_cpu_fallback():
         G(torch.zeros(2, 16))
     with pytest.raises(RuntimeError):
         pg.wgan_gp_D_loss(D, G, torch.zeros(2, 3, 4, 4), torch.zeros(2, 16))
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """``python bench.py --gpus N`` launches the N ranks itself and must not silently measure fewer devices."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    want = torch.cuda.device_count() + 1 if torch.cuda.is_available() else 2
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(max(2, want))], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'GPU(s) are visible' in r.stderr, (r.returncode, r.stderr[-300:])
+    env['WORLD_SIZE'] = '4'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE' in r.stderr

@@ -1,0 +1,157 @@
+"""fp64 adjudication of the gradient tolerances (VERDICT r1 "weak" 1).
+
+The wide / high-resolution gradient comparisons against the fp32 CPU oracle use relative-L2 bounds of 1e-2 per tensor.  The
+reason is tested here instead of asserted.  With LeakyReLU, D and G are piecewise linear maps of their inputs (G up to
+PixelNorm), so every gradient is piecewise CONSTANT: it changes discontinuously when a pre-activation crosses zero.  Two
+correct fp32 evaluations round the >1e7 pre-activations of a pass differently (order of the sums, Winograd), a handful of
+values within ~1e-7 of zero land on different sides, and ONE such flip in a 4x4 .. 32x32 layer moves every gradient that flows
+through it by 1e-4 .. 2e-3 (measured in round 2 with the torch-CPU emulation of the launch schedule as well as on the MI355X:
+the fp32 oracle agreed with an fp64 run to 8e-7 on the input gradient of D where the schedule was 2.3e-3 off — with 3 flipped
+branches out of 1.2e7; on another seed the roles were reversed).  A comparison of complete fp32 pipelines therefore measures the
+luck of those draws, not the arithmetic.
+
+What CAN be pinned exactly: on the linear piece its own forward pass selected, the HIP path must compute that piece's
+gradient.  So the oracle is evaluated in float64 (and in float32) with every LeakyReLU branch FORCED to the HIP pass's sign
+patterns (``oracle.forced_signs``), on the HIP pass's own fake / interpolated images, and
+
+    || HIP - fp64(piece) ||   <=   3 || fp32 oracle(piece) - fp64(piece) ||  +  FLOOR || fp64 ||     for all tensors together
+    || HIP - fp64(piece) ||   <=   3 || fp32 oracle(piece) - fp64(piece) ||  +  TENSOR_FLOOR || tensor ||  +  FLOOR || all ||   per tensor
+
+The number of branches on which the HIP pass and an unforced fp64 pass disagree is printed with the per-tensor table
+(pytest -s); DESIGN.md §6 quotes both."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import fixture_params, load_fixture
+from helpers import build_nets, load_fixture_params, reference_grads
+
+import pggan_amd as pg
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+FACTOR, FLOOR, TENSOR_FLOOR = 3.0, 2e-5, 1e-4
+
+
+def _double(params):
+    return {k: (v.double() if torch.is_tensor(v) else float(v)) for k, v in params.items()}
+
+
+def _nchw(t):
+    if t.dtype == torch.uint8:
+        t = pg.ops.signbytes_to_mask(t)
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+def _d_signs(ctx, a, b, ch_last):
+    """Sign patterns of images [a, b) of a batched D pass in the oracle's call order (network.py:225-240): entry block
+    fromRGB, c1, c2, (fade-in: the next block's fromRGB), then c1, c2 of every further block."""
+    out = []
+    for k, rec in enumerate(ctx['recs']):
+        if k == 0:
+            out.append(_nchw(rec['inp'][a:b]))
+        a1 = _nchw(rec['a1'][a:b])
+        out.append(a1)
+        a2 = rec['a2'][a:b]
+        out.append(_nchw(a2) if a2.dim() == 4 and a2.shape[1] == a2.shape[2] and a2.shape[1] > 1 else
+                   (pg.ops.signbytes_to_mask(a2) if a2.dtype == torch.uint8 else a2).reshape(b - a, -1, 1, 1).cpu())
+        if k == 0 and 'pf' in rec:
+            out.append(_nchw(rec['pf'][a:b]))
+    return out
+
+
+def _g_signs(gctx):
+    """Sign patterns of a G pass (network.py:118-139): block0.c1, block0.c2, then c1, c2 of every block (toRGB has no
+    activation).  The saved tensors are the PixelNorm outputs: same signs as the LeakyReLU inputs."""
+    out = [_nchw(gctx['y1']), _nchw(gctx['y2'])]
+    for rec in gctx['recs']:
+        out += [_nchw(rec['a1']), _nchw(rec['a2'])]
+    return out
+
+
+def _adjudicate(mine, ref32, ref64, what):
+    rows, tot_hip, tot_ref, tot = [], 0.0, 0.0, 0.0
+    for k, r64 in ref64.items():
+        r64 = r64.double().reshape(-1)
+        a = mine[k].detach().cpu().double().reshape(-1)
+        r32 = ref32[k].double().reshape(-1)
+        e_hip, e_ref, scale = float((a - r64).norm()), float((r32 - r64).norm()), float(r64.norm())
+        rows.append((k, scale, e_hip, e_ref))
+        tot_hip += e_hip ** 2
+        tot_ref += e_ref ** 2
+        tot += scale ** 2
+    tot_hip, tot_ref, tot = tot_hip ** 0.5, tot_ref ** 0.5, tot ** 0.5
+    print('%s: all tensors |fp64| %.3e   |HIP-fp64|/|fp64| %.2e   |fp32 oracle-fp64|/|fp64| %.2e' % (what, tot, tot_hip / tot, tot_ref / tot))
+    for k, scale, e_hip, e_ref in rows:
+        print('    %-28s |fp64| %.3e   HIP %.2e   fp32 oracle %.2e   (relative to the tensor)' % (k, scale, e_hip / scale, e_ref / scale))
+    assert tot_hip <= FACTOR * tot_ref + FLOOR * tot, (what, tot_hip / tot, tot_ref / tot)
+    for k, scale, e_hip, e_ref in rows:
+        assert e_hip <= FACTOR * e_ref + TENSOR_FLOOR * scale + FLOOR * tot, (what, k, e_hip / scale, e_ref / scale)
+
+
+def _run(oracle, G, D, gp, dp, cfg, real, z_d, z_g, mix, depth, alpha, what):
+    eng = pg.engine
+    G.depth = D.depth = depth
+    G.alpha = D.alpha = alpha
+    n = real.shape[0]
+    gp64, dp64 = _double(gp), _double(dp)
+    # ---- D step (wgan_gp_D_loss + backward), on the fake / interpolated images and the activation branches of the HIP pass
+    d_cost, _, _, state = eng.d_loss_forward(D, G, real.to(DEV), z_d.to(DEV), mix.to(DEV), 10.0, 0.001, 1.0)
+    ctx = state['ctx']
+    fake, mixed = ctx['x'][n:2 * n].cpu(), ctx['x'][2 * n:].cpu()
+    signs = _d_signs(ctx, 0, n, True) + _d_signs(ctx, n, 2 * n, True) + _d_signs(ctx, 2 * n, 3 * n, True)
+    eng.d_loss_backward(state)
+    mine_d = reference_grads(D)
+    with oracle.forced_signs(signs):
+        r32 = oracle.d_loss_and_grads(dp, gp, cfg, real, z_d, mix, depth, alpha, fake=fake, mixed=mixed)
+    with oracle.forced_signs(signs) as fs:
+        r64 = oracle.d_loss_and_grads(dp64, gp64, cfg, real.double(), z_d.double(), mix.double(), depth, alpha,
+                                      fake=fake.double(), mixed=mixed.double())
+    print('%s D step: %d of %d LeakyReLU branches of the HIP pass differ from those of the fp64 pass' % (what, fs.flips, fs.elements))
+    assert fs.flips <= max(20, fs.elements // 100000)                 # the pieces differ on a handful of branches, not systematically
+    assert abs(float(d_cost) - float(r64['D_cost'])) <= 3 * abs(float(r32['D_cost']) - float(r64['D_cost'])) + 2e-6 * max(1.0, abs(float(r64['D_cost'])))
+    _adjudicate(mine_d, r32['grads'], r64['grads'], what + ' D step')
+    # ---- G step (wgan_gp_G_loss + backward) on the branches of the HIP pass (G's and D's)
+    g_cost, gstate = eng.g_loss_forward(G, D, z_g.to(DEV))
+    signs = _g_signs(gstate['gctx']) + _d_signs(gstate['dctx'], 0, n, True)
+    eng.g_loss_backward(gstate)
+    mine_g = reference_grads(G)
+    with oracle.forced_signs(signs):
+        g32 = oracle.g_loss_and_grads(gp, dp, cfg, z_g, depth, alpha)
+    with oracle.forced_signs(signs) as fs:
+        g64 = oracle.g_loss_and_grads(gp64, dp64, cfg, z_g.double(), depth, alpha)
+    print('%s G step: %d of %d LeakyReLU branches of the HIP pass differ from those of the fp64 pass' % (what, fs.flips, fs.elements))
+    assert fs.flips <= max(20, fs.elements // 100000)
+    assert abs(float(g_cost) - float(g64['G_cost'])) <= 3 * abs(float(g32['G_cost']) - float(g64['G_cost'])) + 2e-6 * max(1.0, abs(float(g64['G_cost'])))
+    _adjudicate(mine_g, g32['grads'], g64['grads'], what + ' G step')
+
+
+@pytest.mark.parametrize('tag', ['d8_a100', 'd7_a050'])
+def test_thin1024_against_fp64(oracle, tag):
+    """The reference-generated 1024x1024 fixture network (narrow widths): depth 8 and a depth-7 fade-in stage."""
+    meta, data = load_fixture('thin1024')
+    case = [c for c in meta['cases'] if c['tag'] == tag][0]
+    G, D = build_nets(meta, DEV)
+    load_fixture_params(G, data, 'G')
+    load_fixture_params(D, data, 'D')
+    c = meta['cfg']
+    cfg = oracle.NetCfg(c['resolution'], c['num_channels'], fmap_base=c['fmap_base'], fmap_decay=c['fmap_decay'],
+                        fmap_max=c['fmap_max'], latent_size=c['latent_size'])
+    gp, dp = fixture_params(data, 'G'), fixture_params(data, 'D')
+    real, z_d, z_g, mix = oracle.synthetic_batch(case['seed'], case['n'], c['num_channels'], 4 * 2 ** case['depth'], c['latent_size'])
+    _run(oracle, G, D, gp, dp, cfg, real, z_d, z_g, mix, case['depth'], case['alpha'], 'thin1024 ' + tag)
+
+
+@pytest.mark.parametrize('res,depth,alpha,n,C', [(128, 5, 1.0, 2, 3), (256, 6, 1.0, 2, 1), (128, 4, 0.5, 3, 3)])
+def test_baseline_widths_against_fp64(oracle, res, depth, alpha, n, C):
+    """Default widths (fmap_base 4096): the 128x128 network (config 3, fully grown and in a fade-in) and the one-channel
+    256x256 network (config 4)."""
+    torch.manual_seed(1337)
+    shape = (1, C, res, res)
+    G, D = pg.Generator(shape), pg.Discriminator(shape)
+    gp, dp = G.reference_state_dict(), D.reference_state_dict()
+    G.to(DEV)
+    D.to(DEV)
+    cfg = oracle.NetCfg(res, C)
+    real, z_d, z_g, mix = oracle.synthetic_batch(42 + depth, n, C, 4 * 2 ** depth, 512)
+    _run(oracle, G, D, gp, dp, cfg, real, z_d, z_g, mix, depth, alpha, 'res %d depth %d alpha %.2f' % (res, depth, alpha))

@@ -9,6 +9,9 @@ import torch
 import pggan_amd as pg
 ops, lib = pg.ops, pg._lib.load()
 N, H, ci, co = [int(v) for v in sys.argv[1:5]]
+gen = int(sys.argv[5]) if len(sys.argv) > 5 else 4          # pg_debug_set_wino: 4 first generation, 11 / 12 second
+lib.pg_debug_set_wino(gen)
+KC = 16 if gen == 4 else 8
 x = torch.randn(N, H, H, ci, device='cuda'); w = torch.randn(3, 3, co, ci, device='cuda') * 0.05; b = torch.randn(co, device='cuda')
 u = ops.wino_transform_weights(w)
 y = torch.empty(N, H, H, co, device='cuda')
@@ -21,12 +24,13 @@ ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2, out=y)
 torch.cuda.synchronize()
 lib.pg_debug_wino_trace(None)
 t = tr.cpu().numpy().reshape(1024, 4, 8, 8).astype(np.float64)
-nch = min(8, ci // 16)
+nch = min(8, ci // KC)
 ok = t[:, :, 0, 7] > 0
 print('workgroups traced', int(ok[:, 0].sum()), 'chunks', nch)
 t0 = t[:, :, 0, 7]                       # kernel entry of the wave
 tend = t[:, :, 1, 7]
-names = ['lds store', 'barrier1', 'fetch issue', 'patch reads + transform', 'mfma issue', 'barrier2']
+names = ['lds store', 'barrier1', 'fetch issue', 'patch reads + transform', 'mfma issue', 'barrier2'] if gen == 4 else \
+    ['wait dma', 'barrier', 'patch reads + dma issue', 'transform', 'frag reads + mfma issue', '-']
 tot = (tend - t0)[ok]
 print('wave lifetime: mean %.0f  min %.0f  max %.0f cycles' % (tot.mean(), tot.min(), tot.max()))
 print('prologue (entry -> first chunk top): mean %.0f' % ((t[:, :, 0, 0] - t0)[ok].mean()))

@@ -18,15 +18,15 @@ for (N, H, ci, co) in SHAPES:
     u = ops.wino_transform_weights(w)
     fl = 2.0 * N * H * H * ci * co * 9
     y0 = ops.conv2d(x, w, b, N, H, H, 3, 1, 0.5, 0.2)
-    y1 = ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2)
-    err = float((y1 - y0).abs().max() / y0.abs().max())
-    ym0 = ops.conv2d(x, w, None, N, H, H, 3, 1, 0.5, mask=m); ym1 = ops.conv2d_wino(x, u, None, N, H, H, 0.5, mask=m)
-    errm = float((ym1 - ym0).abs().max() / ym0.abs().max())
+    ym0 = ops.conv2d(x, w, None, N, H, H, 3, 1, 0.5, mask=m)
     t0 = run(lambda: ops.conv2d(x, w, b, N, H, H, 3, 1, 0.5, 0.2, out=y0))
+    res = []
+    for v in (4, 11, 12, 0):                 # first generation (16-channel chunks); second generation with 16 / 32 couts per workgroup; built-in choice
+        lib.pg_debug_set_wino(v)
+        y1 = ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2)
+        ym1 = ops.conv2d_wino(x, u, None, N, H, H, 0.5, mask=m)
+        e = max(float((y1 - y0).abs().max() / y0.abs().max()), float((ym1 - ym0).abs().max() / ym0.abs().max()))
+        t = run(lambda: ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2, out=y1))
+        res.append('%s %.1fus %.0fTF (%.2fx) err %.0e' % ({4: 'gen1', 11: 'gen2/16', 12: 'gen2/32', 0: 'auto'}[v], t * 1e6, fl / t / 1e12, t0 / t, e))
     lib.pg_debug_set_wino(4)
-    t1 = run(lambda: ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2, out=y1))
-    lib.pg_debug_set_wino(2)
-    t2 = run(lambda: ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2, out=y1))
-    lib.pg_debug_set_wino(4)
-    print('conv n%d @%d %d->%d: direct %.1fus %.0fTF   wino %.1fus %.0fTF (%.2fx)  wino-kc8 %.1fus (%.2fx)   rel err %.1e / masked %.1e' % (
-        N, H, ci, co, t0 * 1e6, fl / t0 / 1e12, t1 * 1e6, fl / t1 / 1e12, t0 / t1, t2 * 1e6, t0 / t2, err, errm), flush=True)
+    print('conv n%d @%d %d->%d: direct %.1fus %.0fTF | %s' % (N, H, ci, co, t0 * 1e6, fl / t0 / 1e12, ' | '.join(res)), flush=True)
