@@ -368,9 +368,15 @@ def grow_run(pg, dp, n_gpus, rank):
     tr.register_plugin(dm)
     tr.register_plugin(pg.LRScheduler(pg.RampupLR(opt_d, pg.utils.rampup), pg.RampupLR(opt_g, pg.utils.rampup)))
     total = 7 * lod                                         # stages 0,1,2,3 + three fades
-    marks = {}
+    stages = []                                             # [depth, fading, iterations, t_start, t_end], closed with a device sync
+
+    def key_now():
+        return (int(tr.G.depth), float(tr.G.alpha) < 1.0)
 
     class Clock(pg.Plugin):
+        """Registered last: runs after DepthManager has prepared the NEXT iteration; a stage closes (device synchronised, so the
+        host clock is the GPU's) when the (depth, fading) pair of the next iteration differs from the current stage's."""
+
         def __init__(self):
             super(Clock, self).__init__([(1, 'iteration')])
 
@@ -378,9 +384,14 @@ def grow_run(pg, dp, n_gpus, rank):
             pass
 
         def iteration(self, *a):
-            key = (int(tr.G.depth), float(tr.G.alpha) < 1.0)
-            marks.setdefault(key, []).append(time.perf_counter())
+            stages[-1][2] += 1
+            if key_now() != (stages[-1][0], stages[-1][1]):
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                stages[-1][4] = now
+                stages.append([key_now()[0], key_now()[1], 0, now, None])
     tr.register_plugin(Clock())
+    stages.append([0, False, 0, None, None])
     for _ in range(10):                                     # untimed: code objects of the 4x4 stage
         tr.train()
     tr.cur_nimg = 0
@@ -390,16 +401,15 @@ def grow_run(pg, dp, n_gpus, rank):
         dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    marks.clear()
+    del stages[:]
+    stages.append([key_now()[0], key_now()[1], 0, t0, None])
     tr.run(total / 1000.0)
     torch.cuda.synchronize()
-    dt = _max_over_ranks(time.perf_counter() - t0, dp)
-    stages = []
-    for (d, fading), ts in sorted(marks.items()):
-        if len(ts) > 4:
-            per = (ts[-1] - ts[2]) / (len(ts) - 3)            # host clock between iteration ends (GPU runs ahead by < 1 step)
-            stages.append({'depth': d, 'fade_in': fading, 'iterations': len(ts), 'ms_per_step': 1e3 * per,
-                           'images_per_sec': n_gpus * 64 / per})
+    t1 = time.perf_counter()
+    stages[-1][4] = t1
+    dt = _max_over_ranks(t1 - t0, dp)
+    stages = [{'depth': d, 'fade_in': f, 'iterations': n, 'ms_per_step': 1e3 * (e - b) / n, 'images_per_sec': n_gpus * 64 * n / (e - b)}
+              for d, f, n, b, e in stages if n > 0]
     return {'workload': 'config 2: 32x32 network, grow depth 0->3 with alpha fade-ins, minibatch 64 per GPU, DepthManager + '
                         'LRScheduler, %d iterations' % tr.iterations,
             'images_per_sec': total / dt, 'seconds': dt, 'iterations': tr.iterations, 'stages': stages}

@@ -133,7 +133,8 @@ int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, const unsigned
 
 /* Winograd F(2x2,3x3) path for the wide 3x3 layers (pad 1; Cin % 16 == 0; H, W powers of two >= 8): 2.25x fewer MFMAs
  * than the direct implicit GEMM, same fp32 sums re-associated (transform coefficients +-1, 1/2; ~1e-6 relative).
- *   pg_wino_transform_weights: u[16][Cout][Cin] = G g G^T of w[3][3][Cout][Cin]   (once per weight version)
+ *   pg_wino_transform_weights: u = G g G^T of w[3][3][Cout][Cin] (once per weight version), 16*Cout*Cin floats stored in
+ *   8-channel packs u[Cin/8][16][Cout][8] (the slice a workgroup stages per K chunk is then whole 128-byte lines); Cin % 8 == 0
  *   pg_conv2d_wino_nhwc: the conv of pg_conv2d_nhwc (KS 3, pad 1) on the transformed weights, with the optional fused
  *   epilogues of pg_conv2d_pool_nhwc (ypool/pool_other/pool_a/pool_b/pool_only) and pg_conv2d_unpool_nhwc
  *   (yup/upmask/up_mul); pass NULL for the ones not wanted.  Returns PG_E_UNSUP for shapes it does not take.      */

@@ -500,7 +500,18 @@ struct WgP {
     int atomic;                 // 0: this workgroup is the only writer of its dW block -> plain +=
     // pool adjoint fused into the gz gather (pg_conv2d_wgrad_unpooled_nhwc): gz[n][h][w][c] = gmul * g[n][h/2][w/2][c] * lrelu'(gbytes[n][h][w][c])
     const unsigned char* gbytes; float gmul, gslope;
+#ifdef PG_WINO_TRACE
+    unsigned long long* trace;  // [workgroup][wave][tile < 8][8] s_memtime stamps (tools/exp/wgrad_trace.py)
+#endif
 };
+
+#ifdef PG_WINO_TRACE
+#define PG_WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (p.trace && lane == 0 && blockIdx.x < 1024 && (tile - t_begin) < 8) \
+    p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + (tile - t_begin)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+thread_local unsigned long long* g_wgrad_trace = nullptr;
+#else
+#define PG_WSTAMP(i) do { } while (0)
+#endif
 
 // row stride == 16 (mod 32): the two 32-lane groups of ds_read_b32 hit disjoint banks
 template <int B> struct PixStride { static constexpr int value = (B % 32 == 16) ? B : B + 16; };
@@ -946,11 +957,12 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
         *reinterpret_cast<float4*>(wl + 4 * e) = *reinterpret_cast<const float4*>(p.w + 4 * e);
     __syncthreads();
 
-    f32x4 acc[G];
+    f32x4 acc[G], acc2[G];
     int xoff[G];                                 // LDS offset of this lane's pixel in group g (tap 0,0)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int gg = wave * G + g;
         xoff[g] = ((gg / GPR) * WT + (gg % GPR) * PXG + 4 * qp + j) * S;
     }
@@ -964,15 +976,20 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvP p)
             float4 bq[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) bq[g] = *reinterpret_cast<const float4*>(xt + xoff[g] + toff + 4 * c4);
+            // two accumulation chains per group (even / odd channel of the quad) and the groups interleaved: consecutive MFMAs
+            // never share an accumulator (a dependent v_mfma_f32_4x4x1 cannot issue back to back)
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, bq[g].x, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, bq[g].y, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, bq[g].z, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, bq[g].w, acc[g], 0, 0, 0);
-            }
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, bq[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc2[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, bq[g].y, acc2[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, bq[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc2[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, bq[g].w, acc2[g], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] += acc2[g];
     // D register r of this lane = out[pixel][cout 4*qo + r]
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + 4 * qo);
@@ -1598,14 +1615,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
 
     const int npix = p.TN * HT * WT;
     const int xH = p.ups ? (p.Hin >> 1) : p.Hin, xW = p.ups ? (p.Win >> 1) : p.Win;
+    // Per-thread load descriptors, computed ONCE: byte offsets relative to the tile origin (the per-tile part of every address
+    // is a wave-uniform scalar) and, for the halo pixels of x, which tile edge they sit on.  The phase trace of round 2
+    // (tools/exp/wgrad_trace.py) showed the per-tile address arithmetic of the previous version (integer divisions of the tile
+    // index, per-load multiplies and range checks) costing 1400 of the 3700 cycles a tile took.
     int zq[ZPT], zc[ZPT];
-    int xq[XPT], xc[XPT], xdst[XPT];
+    int xdst[XPT];
+    unsigned zrel[ZPT], brel[ZPT];
+    int xrel[XPT], xedge[XPT];                                   // xedge: bit 0 top, 1 bottom, 2 left, 3 right halo; -1 = unused slot
+    const int zH = p.gbytes ? (p.Hout >> 1) : p.Hout, zW = p.gbytes ? (p.Wout >> 1) : p.Wout;
 #pragma unroll
     for (int i = 0; i < ZPT; ++i) {
         const int idx = tid + 256 * i;
         const int q = idx / ZV, v = idx - q * ZV;
         zq[i] = idx < BPX * ZV ? q : -1;
         zc[i] = 4 * v;
+        const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
+        const int zh = p.gbytes ? (th >> 1) : th, zw = p.gbytes ? (tw >> 1) : tw;
+        zrel[i] = zq[i] >= 0 ? 4u * (unsigned)(((tn * zH + zh) * zW + zw) * CO + 4 * v) : PG_OOB;
+        brel[i] = (unsigned)(((tn * p.Hout + th) * p.Wout + tw) * (CO / 4) + v);
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
@@ -1613,9 +1641,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
         const int q = idx / XV, v = idx - q * XV;
         const int r2 = (int)__umulhi((unsigned)q, p.mWT), tw = q - r2 * WT;
         const int tn = (int)__umulhi((unsigned)r2, p.mHT), th = r2 - tn * HT;
-        xq[i] = q < npix ? ((tn << 20) | (th << 10) | tw) : -1;
-        xc[i] = 4 * v;
         xdst[i] = q * SX + 4 * v;
+        int ih = th - p.pad, iw = tw - p.pad;
+        if (p.ups) { ih >>= 1; iw >>= 1; }                       // nearest-x2 upsample fused into the gather (tile origins are even)
+        xrel[i] = 4 * (((tn * xH + ih) * xW + iw) * CI + 4 * v);
+        xedge[i] = q < npix ? ((th < p.pad ? 1 : 0) | (th >= TH + p.pad ? 2 : 0) | (tw < p.pad ? 4 : 0) | (tw >= TW + p.pad ? 8 : 0)) : -1;
     }
     int tapoff[TAPS];
 #pragma unroll
@@ -1625,47 +1655,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
     unsigned char zb[ZPT];                   // sign bytes of the prefetched gz values (pool adjoint in the gather)
 #pragma unroll
     for (int i = 0; i < ZPT; ++i) zb[i] = 0;
-    auto fetch = [&](int tile) {
+    const size_t zimg = (size_t)zH * zW * CO, ximg = (size_t)xH * xW * CI;
+    int f_tw = 0, f_th = 0, f_n = 0;         // tile coordinates of the NEXT fetch (tiles are fetched in order: no divisions per tile)
+    auto fetch_seek = [&](int tile) {
         int t = tile;
-        const int tw_i = t % p.tilesW; t /= p.tilesW;
-        const int th_i = t % p.tilesH; t /= p.tilesH;
-        const int n0 = t * p.TN;
-        const int oh0 = th_i << p.lgTH, ow0 = tw_i << p.lgTW;
-        // raw buffers over the TN images of this tile (bufload.h): PG_OOB = zero fill, no branch per load
+        f_tw = t % p.tilesW; t /= p.tilesW;
+        f_th = t % p.tilesH; f_n = t / p.tilesH;
+    };
+    auto fetch = [&]() {
+        const int n0 = f_n * p.TN;
+        const int oh0 = f_th << p.lgTH, ow0 = f_tw << p.lgTW;
+        // raw buffers over the TN images of this tile (bufload.h): PG_OOB / beyond-the-records = zero fill, no branch per load
         const int nimg = min(p.TN, p.N - n0);
-        const size_t zimg = p.gbytes ? (size_t)(p.Hout >> 1) * (p.Wout >> 1) * CO : (size_t)p.Hout * p.Wout * CO;
         const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(p.gz + (size_t)n0 * zimg, (unsigned)((size_t)nimg * zimg * 4));
-        const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n0 * xH * xW * CI, (unsigned)((size_t)nimg * xH * xW * CI * 4));
+        const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n0 * ximg, (unsigned)((size_t)nimg * ximg * 4));
+        const unsigned zorg = 4u * (unsigned)((((p.gbytes ? oh0 >> 1 : oh0) * zW) + (p.gbytes ? ow0 >> 1 : ow0)) * CO);
+        const int xorg = 4 * ((((p.ups ? oh0 >> 1 : oh0) * xW) + (p.ups ? ow0 >> 1 : ow0)) * CI);
+        // tile edges that coincide with the image border: their halo pixels are outside the image
+        const int border = (oh0 == 0 ? 1 : 0) | (oh0 + TH >= p.Hout ? 2 : 0) | (ow0 == 0 ? 4 : 0) | (ow0 + TW >= p.Wout ? 8 : 0);
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) {
-            const int q = zq[i];
-            const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
-            const bool ok = q >= 0 && tn < nimg;
-            if (p.gbytes) {                          // gz = pool adjoint of the coarse gradient, evaluated in the gather
-                const int hh = oh0 + th, ww = ow0 + tw;
-                zreg[i] = pg_buf_load4(rz, ok ? 4u * (unsigned)(((tn * (p.Hout >> 1) + (hh >> 1)) * (p.Wout >> 1) + (ww >> 1)) * CO + zc[i]) : PG_OOB, 0);
+            zreg[i] = pg_buf_load4(rz, zrel[i], zorg);
+            if (p.gbytes) {
                 // the byte is applied when the prefetched value is stored to LDS (next iteration): a multiply here would
                 // wait for the load and serialise the register prefetch
-                zb[i] = ok ? p.gbytes[(size_t)n0 * p.Hout * p.Wout * (CO / 4) + (unsigned)(((tn * p.Hout + hh) * p.Wout + ww) * (CO / 4) + (zc[i] >> 2))] : (unsigned char)0;
-            } else
-            zreg[i] = pg_buf_load4(rz, ok ? 4u * (unsigned)(((tn * p.Hout + oh0 + th) * p.Wout + ow0 + tw) * CO + zc[i]) : PG_OOB, 0);
+                const bool ok = zq[i] >= 0 && (zq[i] >> (p.lgTW + p.lgTH)) < nimg;
+                zb[i] = ok ? p.gbytes[((size_t)n0 * p.Hout + oh0) * p.Wout * (CO / 4) + (size_t)ow0 * (CO / 4) + brel[i]] : (unsigned char)0;
+            }
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            const int tw = xq[i] & 1023, th = (xq[i] >> 10) & 1023, tn = xq[i] >> 20;
-            int ih = oh0 + th - p.pad, iw = ow0 + tw - p.pad;
-            const bool ok = xq[i] >= 0 && tn < nimg && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
-            if (p.ups) { ih >>= 1; iw >>= 1; }                           // nearest-x2 upsample fused into the gather
-            xreg[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)(((tn * xH + ih) * xW + iw) * CI + xc[i]) : PG_OOB, 0);
+            const bool ok = xedge[i] >= 0 && (xedge[i] & border) == 0;
+            xreg[i] = pg_buf_load4(rx, ok ? (unsigned)(xrel[i] + xorg) : PG_OOB, 0);
         }
+        if (++f_tw == p.tilesW) { f_tw = 0; if (++f_th == p.tilesH) { f_th = 0; ++f_n; } }
     };
 
     const int t_begin = (int)pg_xcd_remap(blockIdx.x, gridDim.x) * p.tiles_per_block;   // neighbouring tile ranges on one XCD
     const int t_end = min(t_begin + p.tiles_per_block, p.ntiles);
     constexpr int NSTEPS = BPX / PPM, T = NSTEPS / 4;            // k-steps per tile / per wave
 
-    if (t_begin < t_end) fetch(t_begin);
+    fetch_seek(t_begin);
+    if (t_begin < t_end) fetch();
     for (int tile = t_begin; tile < t_end; ++tile) {
+        PG_WSTAMP(0);
 #pragma unroll
         for (int i = 0; i < ZPT; ++i)
             if (zq[i] >= 0) {
@@ -1678,9 +1711,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
             }
 #pragma unroll
         for (int i = 0; i < XPT; ++i)
-            if (xq[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
+            if (xedge[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
+        PG_WSTAMP(1);
         __syncthreads();
-        if (tile + 1 < t_end) fetch(tile + 1);
+        PG_WSTAMP(2);
+        if (tile + 1 < t_end) fetch();
+        PG_WSTAMP(3);
 
         auto load_frags = [&](int step, float (&af)[GQ], float (&bf)[TAPS]) {
             const int q = PPM * step + slot;
@@ -1712,7 +1748,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
             mfmas(a[1], b[1]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        PG_WSTAMP(4);
         __syncthreads();
+        PG_WSTAMP(5);
     }
 
     // ---- sum the pixel slots (lanes 4*NB apart), then the 4 waves through LDS, then ONE commit per workgroup
@@ -1781,6 +1819,9 @@ int launch_wgrad_thin(WgP& p, hipStream_t s)
     chunks = (g.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
     p.atomic = chunks > 1 ? 1 : 0;
     snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_wgrad_thin_kernel<%d, %d, %d>", p.Cout, p.Cin, BPX);
+#ifdef PG_WINO_TRACE
+    p.trace = g_wgrad_trace;
+#endif
 #define THIN(CO_, CI_) { auto kern = conv_wgrad_thin_kernel<CO_, CI_, BPX>; if (int rc = set_smem(kern, smem)) return rc; \
                          hipLaunchKernelGGL(kern, dim3(chunks), dim3(256), smem, s, p); }
     if (p.Cout == 8 && p.Cin == 8) THIN(8, 8)
@@ -2066,6 +2107,9 @@ extern "C" int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, con
 }
 
 extern "C" const char* pg_debug_last_conv_kernel(void) { return g_last_kernel; }
+#ifdef PG_WINO_TRACE
+extern "C" int pg_debug_wgrad_trace(void* buf) { g_wgrad_trace = (unsigned long long*)buf; return 0; }
+#endif
 
 extern "C" int pg_debug_set_tuning(int key, int value)
 {

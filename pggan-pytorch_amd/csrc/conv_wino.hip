@@ -35,7 +35,6 @@ struct WinoP {
     float* yup; const float* upmask; float up_mul;
     int mask_bytes, y_bytes;                   // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES, pggan_hip.h)
     unsigned char* ysigns;                     // PG_FLAG_SIGNS_OUT
-    int dma_mode;                              // second generation: where the next chunk's LDS-DMA is issued (0 after the patch reads, 1 after the transform, 2 spread over the MFMA groups)
 #ifdef PG_WINO_TRACE
     unsigned long long* trace;                 // [workgroup][wave][chunk][8] s_memtime stamps (tools/exp/wino_trace.py)
 #endif
@@ -363,14 +362,17 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
 //     as consecutive 16-byte slots — the layout LDS-DMA can write (wave-uniform base + lane * 16) — and region rows are
 //     shifted by one slot on every second tile row, so that the 16 tiles a wave reads with one ds_read_b64 (2 tile rows x 8
 //     tiles, 2 pixels apart) cover the 256-byte bank row exactly once: conflict-free patch and fragment reads.
-template <int NCB>
+//   * XK = 2: the input region is staged 16 channels at a time (every second chunk), i.e. 64 contiguous bytes per pixel instead
+//     of 32: every 128-byte line of the activations then comes from L2 twice instead of four times.
+template <int NCB, int XK>
 __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 waves per SIMD: <= 256 VGPRs + AGPRs
 {
     constexpr int KC = 8;
-    constexpr int XS = 4;                                    // DMA instructions per thread and chunk for the input region (<= 1024 slots)
-    constexpr int US = 2 * NCB;                              // ... for the U chunk: 2 planes x 16 xi x 16*NCB rows / 256
+    constexpr int XPL = 2 * XK;                              // channel-quad planes of the staged input region
+    constexpr int XS = XK == 1 ? 4 : 7;                      // DMA instructions per thread for one input region (<= 1024 / 1792 slots)
+    constexpr int US = 2 * NCB;                              // ... for a U chunk: 2 planes x 16 xi x 16*NCB rows / 256
     constexpr int XSLOTS = XS * 256, USLOTS = US * 256;
-    constexpr int BUF = (XSLOTS + USLOTS) * 4;               // floats per buffer
+    constexpr int XBYTES = XSLOTS * 16, UBYTES = USLOTS * 16; // LDS: [X 0][X 1][U 0][U 1]
     typedef float v2 __attribute__((ext_vector_type(2)));
     extern __shared__ __align__(16) float lds[];
     const int TTW = 1 << p.lgTW, TTH = 1 << p.lgTH;
@@ -399,9 +401,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int y = 2 * tty + a;
-        prow[a] = ((kk >> 1) * npixp + (ttn * HT + y) * WTP + 2 * ttx + ((y >> 1) & 1)) * 16 + (kk & 1) * 8;
+        prow[a] = ((kk >> 1) * npixp + (ttn * HT + y) * WTP + 2 * ttx + ((y >> 1) & 1)) * 16 + (kk & 1) * 8;    // + plane pair of the chunk
     }
-    const int ubyte = XSLOTS * 16 + ((kk >> 1) * 256 * NCB + li) * 16 + (kk & 1) * 8;     // + (xi * 16 * NCB + cb * 16) * 16
+    const int ubyte = 2 * XBYTES + ((kk >> 1) * 256 * NCB + li) * 16 + (kk & 1) * 8;      // + buffer, + (xi * 16 * NCB + cb * 16) * 16
 
     const size_t img = (size_t)xH * xW * p.Cin;
     const int nimg = min(p.TN, p.N - n0);
@@ -410,12 +412,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
 #pragma unroll
     for (int i = 0; i < XS; ++i) {
         const int sl = (i * 4 + wave) * 64 + lane;
-        const int q = sl >= npixp ? 1 : 0, pi = sl - q * npixp;
+        int q = 0;
+#pragma unroll
+        for (int j = 1; j < XPL; ++j) q += sl >= j * npixp ? 1 : 0;
+        const int pi = sl - q * npixp;
         const int row = (int)__umulhi((unsigned)pi, p.mWT), xs = pi - row * WTP;        // mWT: magic reciprocal of WTP here
         const int tn = (int)__umulhi((unsigned)row, p.mHT), y = row - tn * HT;
         const int x = xs - ((y >> 1) & 1);
         int ih = 2 * ty0 + y - 1, iw = 2 * tx0 + x - 1;
-        const bool ok = pi < npixp && sl < 2 * npixp && (unsigned)x < (unsigned)WT && n0 + tn < p.N &&
+        const bool ok = pi < npixp && (unsigned)x < (unsigned)WT && n0 + tn < p.N &&
                         (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         if (p.ups) { ih >>= 1; iw >>= 1; }
         xsrc[i] = ok ? 4u * (unsigned)(((tn * xH + ih) * xW + iw) * p.Cin + 4 * q) : PG_OOB;
@@ -443,18 +448,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(dst) : "memory");
     };
-    // pieces [first, last) of the next chunk's copy (US pieces of U, then the input-region pieces)
-    auto dma = [&](int k0, int buf, int first, int last) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * BUF * 4u + (unsigned)wave * 1024u);
-        const unsigned soff = 4u * (unsigned)k0, usoff = (unsigned)(k0 >> 3) * upack;
+    const unsigned wbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    auto dma_u = [&](int k0) {                                // U chunk k0 .. k0+7 -> U buffer (k0 / 8) & 1
+        const unsigned dst = wbase + 2 * XBYTES + (unsigned)((k0 >> 3) & 1) * UBYTES, usoff = (unsigned)(k0 >> 3) * upack;
 #pragma unroll
-        for (int i = 0; i < US; ++i)
-            if (i >= first && i < last) dma16(rus, usrc[i], usoff, base + XSLOTS * 16 + i * 4096);
+        for (int i = 0; i < US; ++i) dma16(rus, usrc[i], usoff, dst + i * 4096);
+    };
+    auto dma_x = [&](int k0) {                                // input channels k0 .. k0 + 8 XK - 1 -> X buffer (k0 / (8 XK)) & 1
+        const unsigned dst = wbase + (unsigned)((k0 / (KC * XK)) & 1) * XBYTES, soff = 4u * (unsigned)k0;
 #pragma unroll
         for (int i = 0; i < XS; ++i)
-            if (US + i >= first && US + i < last && (i * 4) * 64 < 2 * npixp) dma16(rxs, xsrc[i], soff, base + i * 4096);   // (workgroup-uniform)
+            if ((i * 4) * 64 < XPL * npixp) dma16(rxs, xsrc[i], soff, dst + i * 4096);     // (workgroup-uniform: skips unused instructions)
     };
-    constexpr int NP = US + XS;
 
     f32x4 acc[NCB][16];
 #pragma unroll
@@ -462,9 +467,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    dma(0, 0, 0, NP);
-    int buf = 0;
-    for (int k0 = 0; k0 < p.Cin; k0 += KC, buf ^= 1) {
+    dma_u(0);
+    dma_x(0);
+    for (int k0 = 0; k0 < p.Cin; k0 += KC) {
         PG_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of the chunk has landed ...
         PG_STAMP(1);
@@ -473,15 +478,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
         // explicit LDS address space: a volatile access through a generic pointer would become a flat load (vmcnt + lgkmcnt)
         typedef __attribute__((address_space(3))) const char* lds_cptr;
         typedef __attribute__((address_space(3))) const volatile v2* lds_v2ptr;
-        const lds_cptr xb = (lds_cptr)lds + buf * BUF * 4;
+        const int sub = (k0 >> 3) % XK;                           // which 8-channel half of the staged region this chunk uses
+        const lds_cptr xb = (lds_cptr)lds + ((k0 / (KC * XK)) & 1) * XBYTES + sub * 2 * npixp * 16;
         v2 d[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) d[a][c] = *(lds_v2ptr)(xb + prow[a] + c * 16);   // volatile: keep ds_read_b64 (a merged ds_read2_b64 is half rate)
         __builtin_amdgcn_sched_barrier(0);
-        const bool more = k0 + KC < p.Cin;
-        if (more && p.dma_mode == 0) dma(k0 + KC, buf ^ 1, 0, NP);   // in flight under the transform and the MFMAs below
+        if (k0 + KC < p.Cin) dma_u(k0 + KC);                  // in flight under the transform and the MFMAs below
+        if (sub == 0 && k0 + KC * XK < p.Cin) dma_x(k0 + KC * XK);
         __builtin_amdgcn_sched_barrier(0);
         PG_STAMP(3);
         // V = B^T d B, in place
@@ -495,11 +501,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
             const v2 t0 = d[a][0] - d[a][2], t1 = d[a][1] + d[a][2], t2 = d[a][2] - d[a][1], t3 = d[a][1] - d[a][3];
             d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more && p.dma_mode == 1) dma(k0 + KC, buf ^ 1, 0, NP);
-        __builtin_amdgcn_sched_barrier(0);
         PG_STAMP(4);
-        const lds_cptr ub = xb + ubyte;
+        const lds_cptr ub = (lds_cptr)lds + ubyte + ((k0 >> 3) & 1) * UBYTES;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                         // one row of Winograd positions at a time: 4 x NCB accumulators interleaved
             v2 af[NCB][4];
@@ -514,11 +517,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
 #pragma unroll
                     for (int c = 0; c < NCB; ++c)
                         acc[c][4 * g + j] = MFMA16(af[c][j][s2], d[g][j][s2], acc[c][4 * g + j]);
-            if (more && p.dma_mode == 2 && g < 2) {            // half of the pieces behind each of the first two MFMA groups
-                __builtin_amdgcn_sched_barrier(0);
-                dma(k0 + KC, buf ^ 1, g == 0 ? 0 : (NP + 1) / 2, g == 0 ? (NP + 1) / 2 : NP);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         PG_STAMP(5);
         PG_STAMP(6);
@@ -678,23 +676,29 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
         // when that still leaves at least two workgroups per CU
         int ncb = vec >= 10 ? vec - 10 : ((Cin >= 512 && (long long)ntb * ((Cout + 31) / 32) >= 768) ? 2 : 1);   // measured: tools/sweep_wino.py
         if (ncb != 1 && ncb != 2) return PG_E_ARG;
-        static const int dma_mode = getenv("PG_WINO_DMA") ? atoi(getenv("PG_WINO_DMA")) : 0;     // tuning aid (tools/sweep_wino.py)
-        p.dma_mode = dma_mode;
+        // Staging the input region 16 channels at a time (XK = 2: every activation line comes from L2 twice instead of four times)
+        // costs a third workgroup per CU (74 KB of LDS) and measured SLOWER on every layer of the 1024^2 step but 512->512 @16
+        // (n9 @256 32->64: 137 -> 170 us, step 13.8 -> 14.6 ms): PG_WINO_XK=2 keeps it reachable for sweeps.  Issuing the copies
+        // after the transform or spread over the MFMA groups instead of right after the patch reads: equal / 1 % slower.
+        static const int xk_env = getenv("PG_WINO_XK") ? atoi(getenv("PG_WINO_XK")) : 1;
         const int WTP = WT + 1;
-        if (2 * TN * HT * WTP > 1024) return PG_E_UNSUP;
+        int xk = (xk_env == 2 && ncb == 1 && 4 * TN * HT * WTP <= 1792) ? 2 : 1;
+        if (2 * xk * TN * HT * WTP > (xk == 1 ? 1024 : 1792)) return PG_E_UNSUP;
         p.mWT = (unsigned)((1ull << 32) / (unsigned)WTP) + 1u;
         p.ncob = (Cout + 16 * ncb - 1) / (16 * ncb);
         p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20);
-        const size_t smem2 = (size_t)2 * (1024 + 512 * ncb) * 16;
+        const size_t smem2 = (size_t)2 * ((xk == 1 ? 1024 : 1792) + 512 * ncb) * 16;
         dim3 grid2((unsigned)(ntb * p.ncob));
-        snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d>", ncb);
-        const void* fn = ncb == 2 ? reinterpret_cast<const void*>(conv_wino2_kernel<2>) : reinterpret_cast<const void*>(conv_wino2_kernel<1>);
+        snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d>", ncb, xk);
+        const void* fn = ncb == 2 ? reinterpret_cast<const void*>(conv_wino2_kernel<2, 1>)
+                       : xk == 2 ? reinterpret_cast<const void*>(conv_wino2_kernel<1, 2>) : reinterpret_cast<const void*>(conv_wino2_kernel<1, 1>);
         if (smem2 > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
             if (e != hipSuccess) return (int)e;
         }
-        if (ncb == 2) hipLaunchKernelGGL(conv_wino2_kernel<2>, grid2, dim3(256), smem2, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(conv_wino2_kernel<1>, grid2, dim3(256), smem2, (hipStream_t)stream, p);
+        if (ncb == 2) hipLaunchKernelGGL((conv_wino2_kernel<2, 1>), grid2, dim3(256), smem2, (hipStream_t)stream, p);
+        else if (xk == 2) hipLaunchKernelGGL((conv_wino2_kernel<1, 2>), grid2, dim3(256), smem2, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_wino2_kernel<1, 1>), grid2, dim3(256), smem2, (hipStream_t)stream, p);
         return (int)hipGetLastError();
     }
     const size_t smem = ((size_t)16 * 16 * (vec == 4 ? 24 : 12) + (size_t)TN * HT * WT * (vec == 4 ? 20 : 12)) * sizeof(float);

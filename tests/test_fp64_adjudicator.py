@@ -30,7 +30,7 @@ import pggan_amd as pg
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
-FACTOR, FLOOR, TENSOR_FLOOR = 3.0, 2e-5, 1e-4
+FACTOR, FLOOR, TENSOR_FLOOR = 3.0, 1e-6, 2e-6     # measured on MI355X (round 2): HIP <= 3 x oracle + 1.3e-7 on every tensor
 
 
 def _double(params):

@@ -1,0 +1,36 @@
+"""Cycle-level phase breakdown of conv_wgrad_thin_kernel (s_memtime stamps per wave and tile, first 8 tiles of the first 1024
+workgroups).  Build: tools/exp/build_trace.sh; run on the GPU box:
+    PGGAN_HIP_LIB=ab/libpggan_trace.so python tools/exp/wgrad_trace.py N H Cin Cout"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import pggan_amd as pg
+ops, lib = pg.ops, pg._lib.load()
+N, H, ci, co = [int(v) for v in sys.argv[1:5]]
+x = torch.randn(N, H, H, ci, device='cuda'); gz = torch.randn(N, H, H, co, device='cuda')
+dw = torch.zeros(3, 3, co, ci, device='cuda'); db = torch.zeros(co, device='cuda')
+for _ in range(3):
+    ops.conv2d_wgrad(x, gz, dw, db, N, H, H, 3, 1, 0.5)
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(10):
+    ops.conv2d_wgrad(x, gz, dw, db, N, H, H, 3, 1, 0.5)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 10
+print('%s  %.1f us  %.2f TB/s algorithmic' % (lib.pg_debug_last_conv_kernel().decode(), dt * 1e6, 4.0 * N * H * H * (ci + co) / dt / 1e12))
+tr = torch.zeros(1024 * 4 * 8 * 8, dtype=torch.int64, device='cuda')
+lib.pg_debug_wgrad_trace.argtypes = [ctypes.c_void_p]
+lib.pg_debug_wgrad_trace(tr.data_ptr())
+ops.conv2d_wgrad(x, gz, dw, db, N, H, H, 3, 1, 0.5)
+torch.cuda.synchronize()
+lib.pg_debug_wgrad_trace(None)
+t = tr.cpu().numpy().reshape(1024, 4, 8, 8).astype(np.float64)
+ok = t[:, :, 0, 0] > 0
+names = ['lds store (waits for the prefetch)', 'barrier', 'fetch issue', 'fragment reads + mfma', 'barrier']
+for c in range(8):
+    seg = [(t[:, :, c, i + 1] - t[:, :, c, i])[ok].mean() for i in range(5)]
+    nxt = (t[:, :, c + 1, 0] - t[:, :, c, 5])[ok].mean() if c < 7 else float('nan')
+    print('tile %d: ' % c + '  '.join('%s %.0f' % (n, v) for n, v in zip(names, seg)) + '   total %.0f (to next %.0f)' % (sum(seg), nxt))

@@ -6,9 +6,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu --no-per-depth --prime 10 --steps 10 --warmup 3"
+BENCH="python $R/bench.py --no-cpu --no-per-depth --no-configs --prime 10 --steps 10 --warmup 3"
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $BENCH > $OUT/bench_kt.log 2>&1
-PMCB="python $R/bench.py --no-cpu --no-per-depth --no-kernel-timing --prime 0 --steps 2 --warmup 1"
+PMCB="python $R/bench.py --no-cpu --no-per-depth --no-kernel-timing --no-configs --prime 0 --steps 2 --warmup 1"
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $PMCB > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $PMCB > $OUT/pmc_write.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq -o p --output-format csv -- $PMCB > $OUT/pmc_sq.log 2>&1
@@ -16,5 +16,6 @@ timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 # keep only the small summaries (the raw traces are large)
 python $R/tools/summarize_profile.py $OUT $TAG > $OUT/summary.log 2>&1
 python $R/tools/stream_overlap.py "$OUT/kt/**/kt_kernel_trace.csv" > $OUT/${TAG}_stream_overlap.txt 2>&1
-rm -f $OUT/*/p_kernel_trace.csv $OUT/kt/kt_kernel_trace.csv
+rm -f $OUT/*/p_kernel_trace.csv $OUT/kt/kt_kernel_trace.csv $OUT/*/p_counter_collection.csv $OUT/*/*_agent_info.csv
+find $OUT -name '*.csv' -size +2M -delete      # gpurun merges at most 64 MiB back
 ls -la $OUT $OUT/* | head -40
