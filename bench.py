@@ -33,10 +33,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# The step uses three HIP streams (main, weight gradients, gradient exchange) next to RCCL's own; with ROCm's default of 4
-# hardware queues two of them can share a queue and serialise (measured: 17.2 vs 14.6 ms per step with the library's RCCL
-# communicator alive).  Must be set before the HIP runtime is loaded.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# Data-parallel runs only: with the library's RCCL communicator alive the step uses three HIP streams (main, weight gradients,
+# gradient exchange) next to RCCL's own; under ROCm's default of 4 hardware queues two of them share a queue and serialise
+# (measured with a one-rank communicator: 184 vs 218 img/s; the control-plane backend makes no difference).  Single-GPU runs
+# keep the default: 8 queues slow the hipGraph replay of the 4x4 stage down (3.8 vs 2.3 ms per step).  Must be set before the
+# HIP runtime is loaded.
+if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('PGGAN_FORCE_DP', '') == '1':
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 
@@ -238,7 +241,7 @@ PRIME_STEPS = 50
 def _max_over_ranks(dt, dp):
     if dp is None:
         return dt
-    t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+    t = torch.tensor([dt], device='cuda' if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     return float(t)
 
@@ -267,7 +270,7 @@ def robust_ms(tr, dp, fn=None, prime=20, window_s=0.35, windows=3):
     probe = timed_steps(tr, 3, prime, dp, fn) / 3
     k = max(3, int(window_s / max(probe, 1e-5)) + 1)
     if dp is not None:
-        t = torch.tensor([k], device='cuda', dtype=torch.int64)
+        t = torch.tensor([k], device='cuda' if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.int64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         k = int(t)
     ms = sorted(1e3 * timed_steps(tr, k, 0, dp, fn) / k for _ in range(windows))

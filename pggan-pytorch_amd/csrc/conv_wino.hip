@@ -72,11 +72,15 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 {
     const size_t n = (size_t)Cout * Cin;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        // thread i -> (pack, cout, channel of the pack): consecutive threads WRITE consecutive floats of every Winograd position
+        // (the reads are 32-byte pieces; with i -> (cout, cin) the sixteen stores of a wave were 8 x 32-byte pieces each)
+        const size_t pk = i / ((size_t)8 * Cout), rr = i - pk * 8 * Cout;
+        const size_t co = rr >> 3, ci = 8 * pk + (rr & 7), src = co * Cin + ci;
         float g[3][3], t[4][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = w[(size_t)(a * 3 + b) * n + i];
+            for (int b = 0; b < 3; ++b) g[a][b] = w[(size_t)(a * 3 + b) * n + src];
 #pragma unroll
         for (int b = 0; b < 3; ++b) {                     // t = G g
             t[0][b] = g[0][b];
@@ -84,7 +88,6 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
             t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
             t[3][b] = g[2][b];
         }
-        const size_t co = i / Cin, ci = i - co * Cin;
         float* ub = u + wino_u_index(0, co, ci, Cout);
         const size_t xs = (size_t)Cout * 8;               // stride between Winograd positions inside a pack
 #pragma unroll
@@ -548,11 +551,13 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
     const size_t n = (size_t)d.cout[l] * d.cin[l];
     const size_t i = (size_t)(blockIdx.x - d.first_block[l]) * 256 + threadIdx.x;
     if (i >= n) return;
+    const size_t pk = i / ((size_t)8 * d.cout[l]), rr = i - pk * 8 * d.cout[l];      // see wino_weights_kernel
+    const size_t co = rr >> 3, ci = 8 * pk + (rr & 7), src = co * d.cin[l] + ci;
     float g[3][3], t[4][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) g[a][b] = w[(size_t)(a * 3 + b) * n + i];
+        for (int b = 0; b < 3; ++b) g[a][b] = w[(size_t)(a * 3 + b) * n + src];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         t[0][b] = g[0][b];
@@ -560,7 +565,6 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
         t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
         t[3][b] = g[2][b];
     }
-    const size_t co = i / d.cin[l], ci = i - co * d.cin[l];
     float* ub = u + wino_u_index(0, co, ci, d.cout[l]);
     const size_t xs = (size_t)d.cout[l] * 8;
 #pragma unroll

@@ -31,7 +31,9 @@ class DataParallel(object):
     def __init__(self, backend=None, device=None):
         if not dist.is_initialized():
             if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+                backend = os.environ.get('PGGAN_DP_CONTROL') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            if backend == 'gloo' and os.environ.get('MASTER_ADDR', '') in ('127.0.0.1', 'localhost'):
+                os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')       # single node: do not depend on the hostname resolving
             dist.init_process_group(backend=backend)
         self.rank = dist.get_rank()
         self.world_size = dist.get_world_size()

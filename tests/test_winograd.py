@@ -82,7 +82,21 @@ def test_engine_with_winograd_gpu(monkeypatch, depth, alpha, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', [(2, 32, 64, 64, 0), (3, 16, 128, 96, 0), (1, 8, 32, 48, 0), (9, 8, 512, 512, 0), (2, 64, 32, 64, 1),
                                   (3, 16, 528, 512, 0), (5, 8, 64, 36, 0), (1, 128, 32, 32, 1), (2, 8, 16, 32, 0)])
-def test_conv2d_wino_kernel(case):
+@pytest.mark.parametrize('gen', [0, 11, 12, 4])
+def test_conv2d_wino_kernel(case, gen):
+    """Every Winograd conv kernel against the torch restatement of the conv contract: gen 0 = the built-in choice (second
+    generation), 11 / 12 = second generation with 16 / 32 couts per workgroup, 4 = the round-1 kernel (pg_debug_set_wino)."""
+    lib = pg._lib.load()
+    assert lib.pg_debug_set_wino(gen) == 0
+    try:
+        _wino_kernel_case(case)
+        want = 'conv_wino_kernel<4>' if gen == 4 else 'conv_wino2_kernel<'
+        assert lib.pg_debug_last_wino_kernel().decode().startswith(want)
+    finally:
+        lib.pg_debug_set_wino(0)
+
+
+def _wino_kernel_case(case):
     N, H, ci, co, ups = case
     ops = pg.ops
     hin = H // 2 if ups else H
@@ -104,6 +118,18 @@ def test_conv2d_wino_kernel(case):
         assert rel_err(yp, E.conv2d_pool(x, w, None, N, H, H, 3, 1, 0.37, a=4.0)[1]) < tol
         yu = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.37, mask_slope=0.2, unpool=True, upmask=dev(um), up_mul=0.7)
         assert rel_err(yu, E.conv2d_unpool(x, w, N, H, H, 3, 1, 0.37, upmask=um, mul=0.7, mask_slope=0.2)) < tol
+        # sign-byte forms: mask given as bytes, full-resolution output kept as bytes next to the pooled one, byte copy of the output
+        mb = E.signbytes_of(m)
+        y = ops.conv2d_wino(dev(x), u, None, N, H, H, 0.37, mask=dev(mb), mask_slope=0.2)
+        assert rel_err(y, E.conv2d(x, w, None, N, H, H, 3, 1, 0.37, mask=m, mask_slope=0.2)) < tol
+        yb, yp = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.37, 0.2, pool=True, y_bytes=True)
+        ry, ryp = E.conv2d_pool(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2)
+        assert yb.dtype == torch.uint8 and rel_err(yp, ryp) < tol
+        agree = (yb.cpu() == E.signbytes_of(ry)).float().mean()
+        assert float(agree) > 0.9999                       # (an output within round-off of zero may land on either side)
+        y, ys = ops.conv2d_wino(dev(x), u, dev(b), N, H, H, 0.37, 0.2, signs_out=True)
+        assert rel_err(y, E.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2)) < tol
+        assert bool((ys.cpu() == E.signbytes_of(y.cpu())).all())               # the byte copy is the sign of the very value stored
 
 
 @pytest.mark.gpu
@@ -166,3 +192,71 @@ def test_engine_with_lazy_pool_adjoint_gpu(monkeypatch, alpha):
     monkeypatch.setattr(pg.ops, 'conv2d_unpooled', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
     _engine_vs_oracle('cuda', monkeypatch, 128, 5, alpha, 2, kw=dict(fmap_base=512, fmap_max=64))
     assert (len(calls) > 0) == (alpha == 1.0)         # with the fade-in active the top boundary keeps the materialised form
+
+
+@pytest.mark.gpu
+def test_torch_adam_keeps_derived_weights_fresh(monkeypatch):
+    """with torch's own Adam (or any update that does not go through FusedAdam.mark_params_changed) the
+    Winograd-domain / backward-data weight copies must still be refreshed — every engine entry point syncs the parameter
+    versions.  Three Trainer iterations with torch.optim.Adam at a large learning rate on a Winograd-eligible network against the
+    oracle's Adam: stale copies would put iteration 2's losses off by O(lr)."""
+    monkeypatch.setattr(pg.engine, 'WINO_MIN_WORKGROUPS', 0)
+    torch.manual_seed(33)
+    res, depth, n, lr = 32, 3, 4, 0.01
+    kw = dict(fmap_base=256, fmap_max=64)
+    G = pg.Generator((1, 3, res, res), latent_size=64, **kw)
+    D = pg.Discriminator((1, 3, res, res), **kw)
+    gp, dp = G.reference_state_dict(), D.reference_state_dict()
+    G.cuda(); D.cuda()
+    G.depth = D.depth = depth
+    cfg = oracle.NetCfg(res, 3, latent_size=64, **kw)
+    opt_d = torch.optim.Adam(D.parameters(), lr, betas=(0.0, 0.99))
+    opt_g = torch.optim.Adam(G.parameters(), lr, betas=(0.0, 0.99))
+    batches = [oracle.synthetic_batch(700 + it, n, 3, res, 64) for it in range(3)]
+    state = dict(it=0, z=0)
+
+    def loader():
+        while True:
+            yield batches[state['it']][0]
+
+    def rlg():
+        b = batches[state['it']]
+        state['z'] += 1
+        return b[1] if state['z'] % 2 == 1 else b[2]
+
+    def d_loss(Dm, Gm, real, z):
+        pg.wgan_gp_loss.set_mixing_factors(batches[state['it']][3])
+        return pg.wgan_gp_D_loss(Dm, Gm, real, z)
+    tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, None, loader(), rlg)
+    losses = []
+
+    class Rec(pg.Plugin):
+        def __init__(self):
+            super(Rec, self).__init__([(1, 'iteration')])
+
+        def register(self, trainer):
+            pass
+
+        def iteration(self, i, g_cost, d_cost, d_real, d_fake):
+            losses.append((float(g_cost), float(d_cost)))
+    tr.register_plugin(Rec())
+    og, od = oracle.AdamState(), oracle.AdamState()
+    used = [m for m in list(D._layers()) + list(G._layers()) if getattr(m, '_wu', None) is not None]
+    for it in range(3):
+        state['it'], state['z'] = it, 0
+        tr.train()
+        real, z_d, z_g, mix = batches[it]
+        d, g = oracle.train_iteration(gp, dp, cfg, og, od, real, z_d, z_g, mix, depth, 1.0, lr, lr)
+        gc, dc = losses[it]
+        tol = 5e-4 if it == 0 else 2e-2       # Adam(beta1 = 0) at lr 0.01 is sign-like: round-off-sized gradients move weights by +-lr
+        assert abs(dc - float(d['D_cost'])) < tol * max(1.0, abs(float(d['D_cost']))), (it, dc, float(d['D_cost']))
+        assert abs(gc - float(g['G_cost'])) < tol * max(1.0, abs(float(g['G_cost']))), (it, gc, float(g['G_cost']))
+        # the sharp form: outputs computed now (derived copies as the engine finds them) == outputs after forcing a re-derivation
+        zt, xt = z_g.cuda(), real.cuda()
+        y1, s1 = G(zt).clone(), D(xt).clone()
+        G.mark_params_changed()
+        D.mark_params_changed()
+        # (split-K layers accumulate with atomics: bit-equality is not guaranteed; stale copies would differ by O(lr) = 1e-2)
+        assert rel_err(G(zt), y1) < 1e-5 and rel_err(D(xt), s1) < 1e-5, 'derived weight copies were stale after torch.optim.Adam.step()'
+    used = [m for m in list(D._layers()) + list(G._layers()) if getattr(m, '_wu', None) is not None]
+    assert used, 'no layer took the Winograd path'

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu --no-per-depth --no-configs --prime 10 --steps 10 --warmup 3"
+BENCH="python $R/bench.py --no-cpu --no-per-depth --no-configs --no-kernel-timing --prime 10 --steps 10 --warmup 3"      # (no instrumented passes after the timed loop: the trace ends with the timed steps)
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $BENCH > $OUT/bench_kt.log 2>&1
 PMCB="python $R/bench.py --no-cpu --no-per-depth --no-kernel-timing --no-configs --prime 0 --steps 2 --warmup 1"
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $PMCB > $OUT/pmc_fetch.log 2>&1
