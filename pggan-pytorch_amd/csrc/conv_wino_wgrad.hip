@@ -28,7 +28,18 @@ struct WWP {
     int N, H, W, Cin, Cout, ups;
     float scale;
     int blocksW, blocksH, nregions, regions_per_block;     // region = one image x 4 x 8 tiles (8 x 16 pixels)
+#ifdef PG_WINO_TRACE
+    unsigned long long* trace;                             // [workgroup][wave][region < 8][8] s_memtime stamps (tools/exp/wgrad_trace.py)
+#endif
 };
+
+#ifdef PG_WINO_TRACE
+#define PG_RSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (p.trace && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 1024 && (region - r_begin) < 8) \
+    p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + (region - r_begin)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+thread_local unsigned long long* g_ww_trace = nullptr;
+#else
+#define PG_RSTAMP(i) do { } while (0)
+#endif
 
 constexpr int RTW = 8, RTH = 4;                // tiles per region: 8 wide x 4 high = 32 tiles = 16 x 8 pixels
 constexpr int PW = 2 * RTW, PH = 2 * RTH;      // 16 x 8 output pixels
@@ -104,6 +115,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     const int r_end = min(r_begin + p.regions_per_block, p.nregions);
     if (r_begin < r_end) fetch(r_begin);
     for (int region = r_begin; region < r_end; ++region) {
+        PG_RSTAMP(0);
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) {
             const int idx = tid + 256 * i;
@@ -114,8 +126,11 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
             const int idx = tid + 256 * i;
             if (idx / VX < HH_ * HW_) *reinterpret_cast<float4*>(xt + (idx / VX) * SX + 4 * (idx % VX)) = xreg[i];
         }
+        PG_RSTAMP(1);
         __syncthreads();
+        PG_RSTAMP(2);
         if (region + 1 < r_end) fetch(region + 1);
+        PG_RSTAMP(3);
         // 32 tiles = 8 k-steps of 4 tiles; lane (li, kk): tile 4*step + kk, A channel co = wave_co*16 + li, B channel ci = wave_ci*16 + li
 #pragma unroll 2
         for (int step = wk; step < 8; step += KSPL) {
@@ -154,7 +169,9 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) acc[xi] = MFMA16(z[xi], d[xi >> 2][xi & 3], acc[xi]);
         }
+        PG_RSTAMP(4);
         __syncthreads();
+        PG_RSTAMP(5);
     }
     // dg = G^T M G, lane-local: acc[xi][r] is M[xi] for cout co0 + wave_co*16 + 4*kk + r, cin ci0 + wave_ci*16 + li
     float g[4][9];
@@ -228,6 +245,9 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 }  // namespace
 
 extern "C" const char* pg_debug_last_wino_wgrad_kernel(void) { return g_ww_last; }
+#ifdef PG_WINO_TRACE
+extern "C" int pg_debug_wino_wgrad_trace(void* buf) { g_ww_trace = (unsigned long long*)buf; return 0; }
+#endif
 
 extern "C" int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float* dw, float* db,
                                          int N, int H, int W, int Cin, int Cout, int ups, float scale, pg_stream_t stream)
@@ -243,10 +263,17 @@ extern "C" int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float*
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups; p.scale = scale;
     p.blocksW = W / PW; p.blocksH = H / PH;
     p.nregions = N * p.blocksW * p.blocksH;
+#ifdef PG_WINO_TRACE
+    p.trace = g_ww_trace;
+#endif
     const int nco = Cout <= 16 ? 1 : 2, nci = Cin <= 16 ? 1 : 2;
     const int gy = (Cout + 16 * nco - 1) / (16 * nco), gz_ = (Cin + 16 * nci - 1) / (16 * nci);
     // ~512 workgroups: best of a 256/384/512/1024 sweep (tools/sweep_wino_wgrad.py); more workgroups pay for
-    // themselves in the per-workgroup G^T M G commit (9216 atomics each), fewer leave CUs idle.
+    // themselves in the per-workgroup G^T M G commit (9216 atomics each), fewer leave CUs idle.  Round 2 measured the commit by
+    // leaving it out: 5 % of the launch on n9 @64 128->256 (141 -> 134 us) but 35 % on n3 @128 64->64 (39 -> 25 us), where 128
+    // workgroups add to the same 36 K addresses; the phase trace (tools/exp/wgrad_trace.py ... wino) puts a region at 14.1 k
+    // cycles, 11.7 k of them the 8 k-steps (20 ds_read_b32 + ~50 VALU + 16 MFMAs each: 1460 cycles per step at two waves per
+    // SIMD, 512 of MFMA issue), 2.4 k staging: the kernel is bound by its compute phase and its commit, not by staging.
     static const int target = [] { const char* t = getenv("PG_WW_TARGET"); return t ? atoi(t) : 512; }();
     int chunks = (target + gy * gz_ - 1) / (gy * gz_);
     if (chunks > p.nregions) chunks = p.nregions;
