@@ -637,7 +637,8 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
                                    float scale, float slope, float mask_slope, pg_stream_t stream)
 {
     if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
-    if ((Cin & 15) || (Cout & 3)) return PG_E_ALIGN;
+    if ((Cin & 7) || (Cout & 3)) return PG_E_ALIGN;         // 8-channel packs of U, four couts per lane
+    if ((Cin & 15) && (g_wino_vec == 2 || g_wino_vec == 4)) return PG_E_UNSUP;   // first generation: 16-channel chunks
     if (!pow2(H) || !pow2(W) || H < 8 || W < 8) return PG_E_UNSUP;
     if ((long long)N * H * W * Cin >= (1ll << 31) || (long long)N * H * W * Cout >= (1ll << 29) || (long long)16 * Cout * Cin >= (1ll << 31))
         return PG_E_UNSUP;

@@ -35,12 +35,15 @@ def _check_dev(t, what):
     return t.contiguous()
 
 
-# Winograd F(2x2,3x3) (csrc/conv_wino.hip) replaces the direct implicit GEMM where it measured faster: wide 3x3
-# layers (>= 32 channels on both sides) with enough 64-tile workgroups to fill the chip (tools/sweep_wino.py).
+# Winograd F(2x2,3x3) (csrc/conv_wino.hip) replaces the direct implicit GEMM where it measured faster (tools/sweep_wino.py):
+# 3x3 layers with a full 16-cout MFMA tile and enough 64-tile workgroups to fill the chip.  With the second-generation kernel
+# (8-channel chunks) that includes the 16-channel layers of the 512^2 stage (1.3-1.55x the direct kernel) and 8->16 at 1024^2
+# (1.16x); 16->8 and 8->8 (half of the cout tile empty) stay on the block-MFMA kernels (0.7-1.0x).
 import os as _os
 USE_WINOGRAD = _os.environ.get('PGGAN_WINOGRAD', '1') != '0'
 WINO_MIN_WORKGROUPS = int(_os.environ.get('PGGAN_WINO_MIN_WG', '256'))
-WINO_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_MIN_C', '32'))
+WINO_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_MIN_C', '8'))
+WINO_MIN_COUT = int(_os.environ.get('PGGAN_WINO_MIN_COUT', '16'))
 USE_WINOGRAD_WGRAD = USE_WINOGRAD and _os.environ.get('PGGAN_WINOGRAD_WGRAD', '1') != '0'
 WINO_WGRAD_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_WGRAD_MIN_C', '16'))
 # The c2 output of a DBlock is pooled at once (network.py:229,238); at full resolution only its SIGN is ever used again
@@ -101,7 +104,7 @@ def _wino(layer, N, H, cout, transposed=False):
     if not USE_WINOGRAD or getattr(layer, '_wu', None) is None or H < 8:
         return None
     cin = layer.conv.weight.shape[2] if transposed else layer.conv.weight.shape[3]     # input channels of THIS direction
-    if cin < WINO_MIN_CHANNELS:
+    if cin < WINO_MIN_CHANNELS or cout < WINO_MIN_COUT:
         return None
     if -(-(N * (H // 2) * (H // 2)) // 64) * -(-cout // 16) < WINO_MIN_WORKGROUPS:
         return None

@@ -239,8 +239,8 @@ class _FlatParamsMixin(object):
                 m._wt = self._flat_wt[ow:ow + w.numel()].view(ks, ks, ci, co)
         # Winograd-domain copies (forward and backward-data) of the wide 3x3 layers: 16/9 of their weights each
         wl = [m for m in self._layers() if m.kind == 'conv' and m.ksize == 3 and m.pad == 1 and
-              m.conv.weight.shape[2] % 16 == 0 and m.conv.weight.shape[3] % 16 == 0 and
-              max(m.conv.weight.shape[2], m.conv.weight.shape[3]) >= 32]     # each direction needs >= 32 INPUT channels
+              m.conv.weight.shape[2] % 8 == 0 and m.conv.weight.shape[3] % 8 == 0 and
+              max(m.conv.weight.shape[2], m.conv.weight.shape[3]) >= 16]     # a direction needs >= 16 OUTPUT channels (engine._wino)
         total = sum(16 * m.conv.weight.shape[2] * m.conv.weight.shape[3] for m in wl)
         self._flat_wu = torch.zeros(max(total, 4), dtype=torch.float32, device=flat.device)
         self._flat_wtu = torch.zeros(max(total, 4), dtype=torch.float32, device=flat.device)

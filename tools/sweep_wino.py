@@ -6,7 +6,11 @@ import torch
 import pggan_amd as pg
 ops, lib = pg.ops, pg._lib.load()
 SHAPES = [(9, 16, 512, 512), (3, 16, 512, 512), (9, 32, 256, 512), (3, 32, 256, 256), (9, 64, 128, 256), (3, 64, 128, 128), (9, 128, 64, 128), (3, 128, 64, 64),
-          (9, 256, 32, 64), (3, 256, 32, 32), (9, 512, 32, 16), (9, 8, 512, 512), (3, 8, 512, 512), (16, 16, 512, 512), (48, 16, 512, 512), (16, 32, 512, 512)]
+          (9, 256, 32, 64), (3, 256, 32, 32), (9, 512, 32, 16), (9, 8, 512, 512), (3, 8, 512, 512), (16, 16, 512, 512), (48, 16, 512, 512), (16, 32, 512, 512),
+          (9, 512, 16, 16), (3, 512, 16, 16), (9, 512, 16, 32), (3, 512, 16, 32), (9, 1024, 16, 16),
+          (9, 1024, 8, 16), (3, 1024, 8, 16), (9, 1024, 16, 8), (3, 1024, 16, 8), (9, 1024, 8, 8), (3, 1024, 8, 8)]
+if len(sys.argv) > 1 and sys.argv[1] == 'thin':
+    SHAPES = SHAPES[-11:]
 def run(f, reps=10):
     for _ in range(2): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -23,7 +27,10 @@ for (N, H, ci, co) in SHAPES:
     res = []
     for v in (4, 11, 12, 0):                 # first generation (16-channel chunks); second generation with 16 / 32 couts per workgroup; built-in choice
         lib.pg_debug_set_wino(v)
-        y1 = ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2)
+        try:
+            y1 = ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2)
+        except RuntimeError:
+            res.append('%s unsupported' % {4: 'gen1', 11: 'gen2/16', 12: 'gen2/32', 0: 'auto'}[v]); continue
         ym1 = ops.conv2d_wino(x, u, None, N, H, H, 0.5, mask=m)
         e = max(float((y1 - y0).abs().max() / y0.abs().max()), float((ym1 - ym0).abs().max() / ym0.abs().max()))
         t = run(lambda: ops.conv2d_wino(x, u, b, N, H, H, 0.5, 0.2, out=y1))
