@@ -131,7 +131,7 @@ int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, const unsigned
                                   float* dw, float* db, int N, int Hin, int Win, int Cin, int Cout,
                                   float scale, pg_stream_t stream);
 
-/* Winograd F(2x2,3x3) path for the wide 3x3 layers (pad 1; Cin % 16 == 0; H, W powers of two >= 8): 2.25x fewer MFMAs
+/* Winograd F(2x2,3x3) path for the 3x3 layers (pad 1; Cin % 8 == 0; H, W powers of two >= 8): 2.25x fewer MFMAs
  * than the direct implicit GEMM, same fp32 sums re-associated (transform coefficients +-1, 1/2; ~1e-6 relative).
  *   pg_wino_transform_weights: u = G g G^T of w[3][3][Cout][Cin] (once per weight version), 16*Cout*Cin floats stored in
  *   8-channel packs u[Cin/8][16][Cout][8] (the slice a workgroup stages per K chunk is then whole 128-byte lines); Cin % 8 == 0
@@ -146,6 +146,12 @@ int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const
                         float* yup, const float* upmask, float up_mul,
                         int N, int H, int W, int Cin, int Cout, int ups,
                         float scale, float slope, float mask_slope, pg_stream_t stream);
+/* pg_conv2d_pixelnorm_nhwc on the transformed weights (PGConv2d with pixelnorm=True, network.py:32-52, KS 3, pad 1): conv ->
+ * bias -> LeakyReLU -> PixelNorm in the Winograd epilogue, r[N*H*W] = rsqrt(mean_c y^2 + eps) kept for the backward pass.
+ * A workgroup must hold every cout of its pixels: Cout <= 32 (PG_E_UNSUP otherwise; wider layers normalise in a second pass). */
+int pg_conv2d_wino_pixelnorm_nhwc(const float* x, const float* u, const float* bias, float* y, float* r,
+                                  int N, int H, int W, int Cin, int Cout, int ups,
+                                  float scale, float slope, float eps, pg_stream_t stream);
 
 /* Winograd weight gradient of the same layers: dW[kh][kw][co][ci] += scale * sum gz*x (3x3, pad 1), db[co] += sum gz, computed as
  * G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G  -- 16 MFMAs per 4 output tiles instead of 36.  H, W powers of two with

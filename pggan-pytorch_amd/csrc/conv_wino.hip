@@ -35,6 +35,7 @@ struct WinoP {
     float* yup; const float* upmask; float up_mul;
     int mask_bytes, y_bytes;                   // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES, pggan_hip.h)
     unsigned char* ysigns;                     // PG_FLAG_SIGNS_OUT
+    float* pn_r; float pn_eps;                 // PixelNorm epilogue (pg_conv2d_wino_pixelnorm_nhwc): r[pixel] = rsqrt(mean_c y^2 + eps)
 #ifdef PG_WINO_TRACE
     unsigned long long* trace;                 // [workgroup][wave][chunk][8] s_memtime stamps (tools/exp/wino_trace.py)
 #endif
@@ -181,6 +182,61 @@ __device__ __forceinline__ void wino_epilogue(const WinoP& p, const f32x4 (&acc)
             v.z = fmaf(v.z, p.pool_a, p.pool_b * q.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * q.w);
         } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
         *reinterpret_cast<float4*>(p.ypool + poff) = v;
+    }
+}
+
+
+// conv -> bias -> LeakyReLU -> PixelNorm (network.py:44-52 after :32-41) for a workgroup that holds ALL couts of its tiles (Cout <=
+// 16 NCB): the lane's 4 couts per block are squared and summed lane-locally, the four lanes of a tile (li + 16 kk) fold with two
+// xor-shuffles.  Every lane takes part in the shuffles; lanes without a live (cout, image) contribute zeros and store nothing.
+template <int NCB>
+__device__ __forceinline__ void wino_epilogue_pixelnorm(const WinoP& p, const f32x4 (&acc)[NCB][16], int cb0, int ni, int oy0, int ox0)
+{
+    float4 o[NCB][4];
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int cb = cb0 + 16 * c;
+        const bool live = cb < p.Cout;
+        f32x4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = acc[c][0 + j] + acc[c][4 + j] + acc[c][8 + j];
+            s[1][j] = acc[c][4 + j] - acc[c][8 + j] - acc[c][12 + j];
+        }
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + cb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = q >> 1;
+            const f32x4 v = (q & 1) ? s[a][1] - s[a][2] - s[a][3] : s[a][0] + s[a][1] + s[a][2];
+            float4 t = make_float4(v[0] * p.scale + bv.x, v[1] * p.scale + bv.y, v[2] * p.scale + bv.z, v[3] * p.scale + bv.w);
+            t.x = t.x > 0.f ? t.x : t.x * p.slope; t.y = t.y > 0.f ? t.y : t.y * p.slope;
+            t.z = t.z > 0.f ? t.z : t.z * p.slope; t.w = t.w > 0.f ? t.w : t.w * p.slope;
+            if (!live) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            o[c][q] = t;
+            ss[q] += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ss[q] += __shfl_xor(ss[q], 16, 64);
+        ss[q] += __shfl_xor(ss[q], 32, 64);
+    }
+    if (ni >= p.N) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float rr = rsqrtf(ss[q] / (float)p.Cout + p.pn_eps);
+        const size_t pix = ((size_t)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int cb = cb0 + 16 * c;
+            if (cb < p.Cout) {
+                const float4 t = o[c][q];
+                *reinterpret_cast<float4*>(p.y + pix * p.Cout + cb) = make_float4(t.x * rr, t.y * rr, t.z * rr, t.w * rr);
+            }
+        }
+        if (cb0 == 0) p.pn_r[pix] = rr;
     }
 }
 
@@ -367,12 +423,15 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
 //     tiles, 2 pixels apart) cover the 256-byte bank row exactly once: conflict-free patch and fragment reads.
 //   * XK = 2: the input region is staged 16 channels at a time (every second chunk), i.e. 64 contiguous bytes per pixel instead
 //     of 32: every 128-byte line of the activations then comes from L2 twice instead of four times.
-template <int NCB, int XK>
+//   * XS: DMA instructions per thread for one input region = 256-slot (4 KB) units of an X buffer.  The usual region (one image,
+//     8 x 8 tiles: 18 x 19 slots x 2 planes = 684) fits XS = 3: 2 x (12 + 8) KB = 40 KB of LDS per workgroup, FOUR workgroups per
+//     CU (124 VGPRs allow four waves per SIMD) instead of three with XS = 4.
+template <int NCB, int XK, int XS>
 __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 waves per SIMD: <= 256 VGPRs + AGPRs
 {
     constexpr int KC = 8;
     constexpr int XPL = 2 * XK;                              // channel-quad planes of the staged input region
-    constexpr int XS = XK == 1 ? 4 : 7;                      // DMA instructions per thread for one input region (<= 1024 / 1792 slots)
+    static_assert(XK == 1 ? (XS == 3 || XS == 4) : XS == 7, "input region: <= 768 / 1024 slots (XK = 1), 1792 (XK = 2)");
     constexpr int US = 2 * NCB;                              // ... for a U chunk: 2 planes x 16 xi x 16*NCB rows / 256
     constexpr int XSLOTS = XS * 256, USLOTS = US * 256;
     constexpr int XBYTES = XSLOTS * 16, UBYTES = USLOTS * 16; // LDS: [X 0][X 1][U 0][U 1]
@@ -524,9 +583,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
         PG_STAMP(5);
         PG_STAMP(6);
     }
+    if (p.pn_r) {                                             // (workgroup-uniform; the host launches ncob == 1 then)
+        wino_epilogue_pixelnorm<NCB>(p, acc, 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
+    } else {
 #pragma unroll
-    for (int c = 0; c < NCB; ++c)
-        wino_epilogue(p, acc[c], co0 + 16 * c + 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
+        for (int c = 0; c < NCB; ++c)
+            wino_epilogue(p, acc[c], co0 + 16 * c + 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
+    }
 #ifdef PG_WINO_TRACE
     __builtin_amdgcn_sched_barrier(0);
     if (p.trace && lane == 0 && blockIdx.x < 1024) p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + 1) * 8 + 7] = __builtin_amdgcn_s_memtime();
@@ -630,11 +693,12 @@ extern "C" int pg_wino_transform_weights_batched(const float* wbase, float* ubas
     return (int)hipGetLastError();
 }
 
-extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const float* mask, float* y,
-                                   float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
-                                   float* yup, const float* upmask, float up_mul,
-                                   int N, int H, int W, int Cin, int Cout, int ups,
-                                   float scale, float slope, float mask_slope, pg_stream_t stream)
+namespace {
+int wino_conv(const float* x, const float* u, const float* bias, const float* mask, float* y,
+              float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
+              float* yup, const float* upmask, float up_mul,
+              int N, int H, int W, int Cin, int Cout, int ups,
+              float scale, float slope, float mask_slope, float* pn_r, float pn_eps, pg_stream_t stream)
 {
     if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
     if ((Cin & 7) || (Cout & 3)) return PG_E_ALIGN;         // 8-channel packs of U, four couts per lane
@@ -661,6 +725,8 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
     p.scale = scale; p.slope = slope; p.mask_slope = mask_slope;
     p.ypool = ypool; p.pool_other = pool_other; p.pool_a = pool_a; p.pool_b = pool_b; p.pool_only = pool_only;
     p.yup = yup; p.upmask = upmask; p.up_mul = up_mul;
+    p.pn_r = pn_r; p.pn_eps = pn_eps;
+    if (pn_r && (Cout > 32 || mask || ypool || yup || flags != ups || (g_wino_vec != 0 && g_wino_vec < 10))) return PG_E_UNSUP;
     const int tilesW = W >> 1, tilesH = H >> 1;
     int TTW = tilesW < 8 ? tilesW : 8;
     int TTH = 64 / TTW; if (TTH > tilesH) TTH = tilesH;
@@ -681,29 +747,31 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
         // when that still leaves at least two workgroups per CU
         int ncb = vec >= 10 ? vec - 10 : ((Cin >= 512 && (long long)ntb * ((Cout + 31) / 32) >= 768) ? 2 : 1);   // measured: tools/sweep_wino.py
         if (ncb != 1 && ncb != 2) return PG_E_ARG;
+        if (pn_r) ncb = Cout > 16 ? 2 : 1;                    // PixelNorm epilogue: all couts of a pixel in one workgroup
         // Staging the input region 16 channels at a time (XK = 2: every activation line comes from L2 twice instead of four times)
         // costs a third workgroup per CU (74 KB of LDS) and measured SLOWER on every layer of the 1024^2 step but 512->512 @16
         // (n9 @256 32->64: 137 -> 170 us, step 13.8 -> 14.6 ms): PG_WINO_XK=2 keeps it reachable for sweeps.  Issuing the copies
         // after the transform or spread over the MFMA groups instead of right after the patch reads: equal / 1 % slower.
         static const int xk_env = getenv("PG_WINO_XK") ? atoi(getenv("PG_WINO_XK")) : 1;
+        static const int xs_env = getenv("PG_WINO_XS") ? atoi(getenv("PG_WINO_XS")) : 3;     // 4: always 16 KB X buffers (sweeps)
         const int WTP = WT + 1;
-        int xk = (xk_env == 2 && ncb == 1 && 4 * TN * HT * WTP <= 1792) ? 2 : 1;
-        if (2 * xk * TN * HT * WTP > (xk == 1 ? 1024 : 1792)) return PG_E_UNSUP;
+        const int xk = (xk_env == 2 && ncb == 1 && 4 * TN * HT * WTP <= 1792) ? 2 : 1;
+        const int xslots = 2 * xk * TN * HT * WTP;
+        if (xslots > (xk == 1 ? 1024 : 1792)) return PG_E_UNSUP;
+        const int xs = xk == 2 ? 7 : (xslots <= 768 && xs_env == 3) ? 3 : 4;
         p.mWT = (unsigned)((1ull << 32) / (unsigned)WTP) + 1u;
         p.ncob = (Cout + 16 * ncb - 1) / (16 * ncb);
         p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20);
-        const size_t smem2 = (size_t)2 * ((xk == 1 ? 1024 : 1792) + 512 * ncb) * 16;
+        const size_t smem2 = (size_t)2 * (xs * 256 + 512 * ncb) * 16;
         dim3 grid2((unsigned)(ntb * p.ncob));
-        snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d>", ncb, xk);
-        const void* fn = ncb == 2 ? reinterpret_cast<const void*>(conv_wino2_kernel<2, 1>)
-                       : xk == 2 ? reinterpret_cast<const void*>(conv_wino2_kernel<1, 2>) : reinterpret_cast<const void*>(conv_wino2_kernel<1, 1>);
+        snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d>", ncb, xk, xs);
+        void (*fn)(WinoP) = ncb == 2 ? (xs == 3 ? conv_wino2_kernel<2, 1, 3> : conv_wino2_kernel<2, 1, 4>)
+                          : xk == 2 ? conv_wino2_kernel<1, 2, 7> : (xs == 3 ? conv_wino2_kernel<1, 1, 3> : conv_wino2_kernel<1, 1, 4>);
         if (smem2 > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
             if (e != hipSuccess) return (int)e;
         }
-        if (ncb == 2) hipLaunchKernelGGL((conv_wino2_kernel<2, 1>), grid2, dim3(256), smem2, (hipStream_t)stream, p);
-        else if (xk == 2) hipLaunchKernelGGL((conv_wino2_kernel<1, 2>), grid2, dim3(256), smem2, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((conv_wino2_kernel<1, 1>), grid2, dim3(256), smem2, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(fn, grid2, dim3(256), smem2, (hipStream_t)stream, p);
         return (int)hipGetLastError();
     }
     const size_t smem = ((size_t)16 * 16 * (vec == 4 ? 24 : 12) + (size_t)TN * HT * WT * (vec == 4 ? 20 : 12)) * sizeof(float);
@@ -721,4 +789,24 @@ extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* 
         hipLaunchKernelGGL(conv_wino_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, p);
     }
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const float* mask, float* y,
+                                   float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
+                                   float* yup, const float* upmask, float up_mul,
+                                   int N, int H, int W, int Cin, int Cout, int ups,
+                                   float scale, float slope, float mask_slope, pg_stream_t stream)
+{
+    return wino_conv(x, u, bias, mask, y, ypool, pool_other, pool_a, pool_b, pool_only, yup, upmask, up_mul,
+                     N, H, W, Cin, Cout, ups, scale, slope, mask_slope, nullptr, 0.f, stream);
+}
+
+extern "C" int pg_conv2d_wino_pixelnorm_nhwc(const float* x, const float* u, const float* bias, float* y, float* r,
+                                             int N, int H, int W, int Cin, int Cout, int ups,
+                                             float scale, float slope, float eps, pg_stream_t stream)
+{
+    if (!r) return PG_E_ARG;
+    return wino_conv(x, u, bias, nullptr, y, nullptr, nullptr, 1.f, 0.f, 0, nullptr, nullptr, 1.f,
+                     N, H, W, Cin, Cout, ups ? PG_FLAG_UPSAMPLE : 0, scale, slope, 0.2f, r, eps, stream);
 }

@@ -354,6 +354,8 @@ def generator_forward(G, z, save=False, out=None):
     def layer(x, lay, H, ups=False):
         if lay.pixelnorm:
             u = _wino(lay, N, H, lay.conv.weight.shape[2]) if lay.ksize == 3 else None
+            if u is not None and u.shape[1] <= 32:   # all couts of a pixel in one workgroup: PixelNorm in the Winograd epilogue
+                return ops.conv2d_wino_pixelnorm(x, u, lay.conv.bias.data, N, H, H, lay.c, lay.slope, lay.eps, ups=ups)
             if u is not None:                     # wide layers: Winograd conv, PixelNorm as its own (HBM-bound) pass
                 y = ops.conv2d_wino(x, u, lay.conv.bias.data, N, H, H, lay.c, lay.slope, ups=ups)
                 return ops.pixelnorm_fwd(y, lay.eps, inplace=True)

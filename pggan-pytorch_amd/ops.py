@@ -123,6 +123,16 @@ def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2
     return y
 
 
+def conv2d_wino_pixelnorm(x, u, bias, N, H, W, scale, slope, eps=1e-8, ups=False):
+    """conv2d_pixelnorm on Winograd-domain weights (3x3 pad 1, at most 32 couts: ops.Unsupported otherwise).  Returns (y, r)."""
+    cout, cin = u.shape[1], u.shape[2]
+    y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    r = torch.empty((N * H * W,), device=x.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_wino_pixelnorm_nhwc', _p(x), _p(u), _p(bias), _p(y), _p(r), N, H, W, cin, cout, 1 if ups else 0,
+              scale, slope, eps, _stream())
+    return y, r
+
+
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
                 pool_only=False, y_bytes=False):
     """conv2d with the following 2x2 average pool (+ fade-in blend a*pool + b*other) fused into the epilogue.

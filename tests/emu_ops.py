@@ -143,6 +143,12 @@ def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2
     return (y, signbytes_of(y)) if signs_out else y
 
 
+def conv2d_wino_pixelnorm(x, u, bias, N, H, W, scale, slope, eps=1e-8, ups=False):
+    if u.shape[1] > 32:
+        raise Unsupported('PixelNorm epilogue: at most 32 couts')
+    return pixelnorm_fwd(conv2d(x, _unwino(u), bias, N, H, W, 3, 1, scale, slope=slope, ups=ups), eps)
+
+
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
                 pool_only=False, y_bytes=False):
     y = conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=slope, mask=mask, mask_slope=mask_slope)

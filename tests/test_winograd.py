@@ -136,6 +136,25 @@ def _wino_kernel_case(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 64, 16, 16, 0), (2, 32, 32, 32, 1), (1, 16, 64, 24, 0), (5, 8, 8, 16, 0), (3, 128, 32, 16, 1),
+                                  (2, 16, 16, 8, 0), (1, 32, 128, 32, 0)])
+def test_conv2d_wino_pixelnorm_kernel(case):
+    """conv -> bias -> LeakyReLU -> PixelNorm in the Winograd epilogue (pg_conv2d_wino_pixelnorm_nhwc) against the torch
+    restatement of network.py:32-52; couts 8 / 16 (one block), 24 / 32 (two blocks), upsample-fused input; > 32 couts refused."""
+    N, H, ci, co, ups = case
+    ops = pg.ops
+    hin = H // 2 if ups else H
+    x, w, b = rnd(N, hin, hin, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    u = ops.wino_transform_weights(w.cuda())
+    y, r = ops.conv2d_wino_pixelnorm(x.cuda(), u, b.cuda(), N, H, H, 0.37, 0.2, 1e-8, ups=bool(ups))
+    ry, rr = E.conv2d_pixelnorm(x, w, b, N, H, H, 3, 1, 0.37, 0.2, 1e-8, ups=bool(ups))
+    assert rel_err(y, ry) < 2e-5 and rel_err(r, rr.reshape(-1)) < 2e-5
+    wide = ops.wino_transform_weights(rnd(3, 3, 48, 16, seed=3).cuda())
+    with pytest.raises(ops.Unsupported):
+        ops.conv2d_wino_pixelnorm(rnd(1, 16, 16, 16).cuda(), wide, rnd(48).cuda(), 1, 16, 16, 1.0, 0.2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', [(2, 16, 32, 32, 0), (3, 16, 64, 96, 0), (1, 32, 36, 48, 0), (9, 16, 128, 64, 0), (2, 64, 32, 64, 1),
                                   (5, 32, 8, 40, 1), (1, 128, 32, 32, 0), (7, 16, 100, 36, 0), (2, 16, 32, 32, 1),
                                   (2, 16, 16, 16, 0), (3, 32, 16, 32, 0), (2, 32, 32, 16, 1), (1, 64, 12, 20, 0), (3, 64, 8, 16, 0)])
