@@ -12,6 +12,7 @@
 // LDS, each lane loads ITS tile's 4x4 patch (16 b128 reads), transforms it in registers (32 float4 adds) and feeds
 // 64 MFMAs; the output transform is lane-local because a lane holds all 16 products of its (tile, 4 couts).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,6 +31,7 @@ struct WinoP {
     float scale, slope, mask_slope;
     int lgTW, lgTH, TN, blocksW, blocksH, ncob, cout_minor; // workgroup = TN images x 2^lgTH x 2^lgTW tiles (64 tiles); cout blocks of 16
     unsigned mWT, mHT;                         // magic reciprocals of the halo region width / height in pixels
+    int ntb, lgBW, lgBH; unsigned mDiv;        // second generation: tile blocks, log2(blocksW / blocksH), magic reciprocal of ncob (cout_minor) or ntb
     // fused epilogues (same semantics as the direct kernel, see pggan_hip.h)
     float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
     float* yup; const float* upmask; float up_mul;
@@ -447,10 +449,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
 #endif
     int b = (int)pg_xcd_remap(blockIdx.x, gridDim.x);
     int cob;
-    if (p.cout_minor) { cob = b % p.ncob; b /= p.ncob; }
-    else { const int ntb = (int)gridDim.x / p.ncob; cob = b / ntb; b -= cob * ntb; }
-    const int bw = b % p.blocksW; b /= p.blocksW;
-    const int bh = b % p.blocksH; b /= p.blocksH;
+    // no runtime divisions (five of them were ~100 of the ~450 fixed VALU instructions of a wave): blocksW / blocksH are powers of
+    // two, the cout-block split is a magic multiplication (exact for b * divisor < 2^32, checked by the host)
+    if (p.ncob == 1) cob = 0;
+    else if (p.cout_minor) { const int q = (int)__umulhi((unsigned)b, p.mDiv); cob = b - q * p.ncob; b = q; }
+    else { cob = (int)__umulhi((unsigned)b, p.mDiv); b -= cob * p.ntb; }
+    const int bw = b & (p.blocksW - 1); b >>= p.lgBW;
+    const int bh = b & (p.blocksH - 1); b >>= p.lgBH;
     const int n0 = b * p.TN;
     const int ty0 = bh << p.lgTH, tx0 = bw << p.lgTW;
     const int co0 = cob * 16 * NCB;
@@ -523,15 +528,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
             if ((i * 4) * 64 < XPL * npixp) dma16(rxs, xsrc[i], soff, dst + i * 4096);     // (workgroup-uniform: skips unused instructions)
     };
 
-    f32x4 acc[NCB][16];
-#pragma unroll
-    for (int c = 0; c < NCB; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NCB][16];                                      // first written by chunk 0
 
     dma_u(0);
     dma_x(0);
-    for (int k0 = 0; k0 < p.Cin; k0 += KC) {
+    // One K chunk.  The first one starts its accumulators from the MFMA's constant-zero C operand instead of 64 zeroed registers
+    // (the fixed per-workgroup instruction count is what bounds the 16/32-channel layers: rocprofv3 SQ_INSTS_VALU per wave).
+    auto chunk = [&](const int k0, auto first) {
         PG_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of the chunk has landed ...
         PG_STAMP(1);
@@ -578,11 +581,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int c = 0; c < NCB; ++c)
-                        acc[c][4 * g + j] = MFMA16(af[c][j][s2], d[g][j][s2], acc[c][4 * g + j]);
+                        {
+                            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                            acc[c][4 * g + j] = MFMA16(af[c][j][s2], d[g][j][s2], (decltype(first)::value && s2 == 0) ? zero4 : acc[c][4 * g + j]);
+                        }
         }
         PG_STAMP(5);
         PG_STAMP(6);
-    }
+        };
+    chunk(0, std::true_type{});
+    for (int k0 = KC; k0 < p.Cin; k0 += KC) chunk(k0, std::false_type{});
     if (p.pn_r) {                                             // (workgroup-uniform; the host launches ncob == 1 then)
         wino_epilogue_pixelnorm<NCB>(p, acc, 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
     } else {
@@ -761,7 +769,12 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
         const int xs = xk == 2 ? 7 : (xslots <= 768 && xs_env == 3) ? 3 : 4;
         p.mWT = (unsigned)((1ull << 32) / (unsigned)WTP) + 1u;
         p.ncob = (Cout + 16 * ncb - 1) / (16 * ncb);
-        p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20);
+        p.ntb = ntb; p.lgBW = ilog2i(p.blocksW); p.lgBH = ilog2i(p.blocksH);
+        // cout blocks of one tile block adjacent (small weights) or all tile blocks of one cout block adjacent; the magic
+        // division by ntb is exact only while ncob * ntb^2 < 2^32
+        p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20) || (long long)p.ncob * ntb * ntb >= (1ll << 32) || ntb == 1;
+        if ((long long)p.ncob * p.ncob * ntb >= (1ll << 32)) return PG_E_UNSUP;
+        p.mDiv = (unsigned)((1ull << 32) / (unsigned)(p.cout_minor ? p.ncob : ntb)) + 1u;
         const size_t smem2 = (size_t)2 * (xs * 256 + 512 * ncb) * 16;
         dim3 grid2((unsigned)(ntb * p.ncob));
         snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d>", ncb, xk, xs);
