@@ -158,6 +158,12 @@ int pg_conv2d_wino_pixelnorm_nhwc(const float* x, const float* u, const float* b
  * H >= 8, W >= 16; commits with fp32 atomics.  Same arguments as pg_conv2d_wgrad_nhwc (KS 3, pad 1 implied).          */
 int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float* dw, float* db,
                               int N, int H, int W, int Cin, int Cout, int ups, float scale, pg_stream_t stream);
+/* Two batches of the same layer in one launch (the regions of both walk through the same workgroups, dW is committed once):
+ * dW += scale * (wgrad(x, gz) + wgrad(x2, gz2)); db += sum gz of the batches named in db_batches (bit 0: first, bit 1: second).
+ * N2 = 0: the single-batch form.  Used for the gradient-penalty tangent term + the batched adjoint sweep of D (wgan_gp_loss.py:36-55). */
+int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N, const float* x2, const float* gz2, int N2,
+                               float* dw, float* db, int db_batches,
+                               int H, int W, int Cin, int Cout, int ups, float scale, pg_stream_t stream);
 
 /* Repack forward weights [KS][KS][Cout][Cin] into the weights of the backward-data convolution
  * [KS][KS][Cin][Cout] (spatially flipped, channels transposed).                               */

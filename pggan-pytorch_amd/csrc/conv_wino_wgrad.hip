@@ -25,6 +25,11 @@ namespace {
 
 struct WWP {
     const float* x; const float* gz; float* dw; float* db;
+    // optional second batch (x2, gz2) of the SAME layer summed into the same launch: the regions of both batches form one
+    // sequence (first batch: regions [0, nregions1)), so dW is committed once per workgroup for both (the commit is 35 % of a
+    // small-batch launch).  db_batches: bit 0 / 1 = the first / second batch contributes to db.
+    const float* x2; const float* gz2;
+    int nregions1, db_batches;
     int N, H, W, Cin, Cout, ups;
     float scale;
     int blocksW, blocksH, nregions, regions_per_block;     // region = one image x 4 x 8 tiles (8 x 16 pixels)
@@ -94,12 +99,15 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     const unsigned zimg = (unsigned)((size_t)p.H * p.W * p.Cout * 4), ximg = (unsigned)((size_t)xH * xW * p.Cin * 4);
     float4 zreg[ZPT], xreg[XPT];
     auto fetch = [&](int region) {
-        int r = region;
+        const bool second = region >= p.nregions1;
+        int r = second ? region - p.nregions1 : region;
+        const float* xb = second ? p.x2 : p.x;
+        const float* gb = second ? p.gz2 : p.gz;
         const int bw = r % p.blocksW; r /= p.blocksW;
         const int bh = r % p.blocksH; const int n = r / p.blocksH;
         const int oy0 = bh * PH, ox0 = bw * PW;
-        const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(p.gz + (size_t)n * p.H * p.W * p.Cout + co0, zimg - 4u * (unsigned)co0);
-        const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(p.x + (size_t)n * xH * xW * p.Cin + ci0, ximg - 4u * (unsigned)ci0);
+        const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(gb + (size_t)n * p.H * p.W * p.Cout + co0, zimg - 4u * (unsigned)co0);
+        const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(xb + (size_t)n * xH * xW * p.Cin + ci0, ximg - 4u * (unsigned)ci0);
         const unsigned zbase = 4u * (unsigned)((oy0 * p.W + ox0) * p.Cout);
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) zreg[i] = pg_buf_load4(rz, zoff[i], zbase);
@@ -130,6 +138,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
         __syncthreads();
         PG_RSTAMP(2);
         if (region + 1 < r_end) fetch(region + 1);
+        const bool bias_here = (p.db_batches >> (region >= p.nregions1 ? 1 : 0)) & 1;      // (workgroup-uniform)
         PG_RSTAMP(3);
         // 32 tiles = 8 k-steps of 4 tiles; lane (li, kk): tile 4*step + kk, A channel co = wave_co*16 + li, B channel ci = wave_ci*16 + li
 #pragma unroll 2
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
             const int ttx = t & (RTW - 1), tty = t >> 3;
             const float* gp = gzt + ((2 * tty) * PW + 2 * ttx) * SZ + wave_co * 16 + li;
             const float y00 = gp[0], y01 = gp[SZ], y10 = gp[PW * SZ], y11 = gp[(PW + 1) * SZ];
-            bsum += (y00 + y01) + (y10 + y11);
+            if (bias_here) bsum += (y00 + y01) + (y10 + y11);
             // Z = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
             const float c0a = y00, c0b = y01;                 // rows of (A dY): r0 = y0., r1 = y0. + y1., r2 = y0. - y1., r3 = -y1.
             const float c1a = y00 + y10, c1b = y01 + y11;
@@ -249,20 +258,27 @@ extern "C" const char* pg_debug_last_wino_wgrad_kernel(void) { return g_ww_last;
 extern "C" int pg_debug_wino_wgrad_trace(void* buf) { g_ww_trace = (unsigned long long*)buf; return 0; }
 #endif
 
-extern "C" int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float* dw, float* db,
-                                         int N, int H, int W, int Cin, int Cout, int ups, float scale, pg_stream_t stream)
+extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N, const float* x2, const float* gz2, int N2,
+                                          float* dw, float* db, int db_batches,
+                                          int H, int W, int Cin, int Cout, int ups, float scale, pg_stream_t stream)
 {
-    if (!x || !gz || !dw || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
+    if (!x || !gz || !dw || N <= 0 || N2 < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
+    if (N2 > 0 && (!x2 || !gz2)) return PG_E_ARG;
+    if (db_batches & ~3) return PG_E_ARG;
+    if (!db) db_batches = 0;
+    if (N2 > 0 && ((long long)N2 * H * W * Cin >= (1ll << 31) || (long long)N2 * H * W * Cout >= (1ll << 31))) return PG_E_UNSUP;
     if ((Cin & 3) || (Cout & 3)) return PG_E_ALIGN;
     if (!pow2(H) || !pow2(W) || H < PH || W < PW) return PG_E_UNSUP;
     if (ups && ((H | W) & 1)) return PG_E_ARG;
     if ((long long)N * H * W * Cin >= (1ll << 31) || (long long)N * H * W * Cout >= (1ll << 31)) return PG_E_UNSUP;
     if ((long long)H * W * Cin * 4 >= (1ll << 31) || (long long)H * W * Cout * 4 >= (1ll << 31)) return PG_E_UNSUP;      // 32-bit buffer offsets per image
     WWP p;
-    p.x = x; p.gz = gz; p.dw = dw; p.db = db;
-    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups; p.scale = scale;
+    p.x = x; p.gz = gz; p.dw = dw; p.db = db_batches ? db : nullptr;
+    p.x2 = N2 > 0 ? x2 : x; p.gz2 = N2 > 0 ? gz2 : gz; p.db_batches = db_batches;
+    p.N = N + N2; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups; p.scale = scale;
     p.blocksW = W / PW; p.blocksH = H / PH;
-    p.nregions = N * p.blocksW * p.blocksH;
+    p.nregions1 = N * p.blocksW * p.blocksH;
+    p.nregions = (N + N2) * p.blocksW * p.blocksH;
 #ifdef PG_WINO_TRACE
     p.trace = g_ww_trace;
 #endif
@@ -287,4 +303,10 @@ extern "C" int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float*
     else if (nco == 2 && nci == 1) hipLaunchKernelGGL((conv_wino_wgrad_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
+}
+
+extern "C" int pg_conv2d_wgrad_wino_nhwc(const float* x, const float* gz, float* dw, float* db,
+                                         int N, int H, int W, int Cin, int Cout, int ups, float scale, pg_stream_t stream)
+{
+    return pg_conv2d_wgrad_wino2_nhwc(x, gz, N, nullptr, nullptr, 0, dw, db, 1, H, W, Cin, Cout, ups, scale, stream);
 }

@@ -305,17 +305,49 @@ def _grads_ready(net, layers):
         hook(layers, side)
 
 
-def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False):
+# The gradient-penalty tangent term and the batched adjoint sweep both add to the weight gradient of every D layer.  For the
+# Winograd layers the first contribution (3 images) is not launched on its own: it waits on the layer and rides in the launch of
+# the second (pg_conv2d_wgrad_wino2_nhwc) -- one commit of dW instead of two, and the commit is a third of a 3-image launch.
+DEFER_TANGENT_WGRAD = _os.environ.get('PGGAN_DEFER_TANGENT_WGRAD', '1') != '0'
+
+
+def _wino_wgrad_ok(layer, Hin):
+    return (USE_WINOGRAD_WGRAD and layer.ksize == 3 and layer.pad == 1 and Hin >= 16 and not (Hin & (Hin - 1))
+            and min(layer._gw.shape[2], layer._gw.shape[3]) >= WINO_WGRAD_MIN_CHANNELS)
+
+
+def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False, defer=False):
     """Weight (and bias) gradient of one conv layer on the side stream.  The wide 3x3 layers take the Winograd form
     (2.25x fewer MFMAs, 1.3-1.7x faster from 16x16 up, 16-channel sides included); the 8-channel layers and the
-    4x4 / 8x8 maps keep the direct kernels."""
-    with _on_side(x, gz):
-        if (USE_WINOGRAD_WGRAD and layer.ksize == 3 and layer.pad == 1 and Hin >= 16 and not (Hin & (Hin - 1))
-                and min(layer._gw.shape[2], layer._gw.shape[3]) >= WINO_WGRAD_MIN_CHANNELS):
-            ops.conv2d_wgrad_wino(x, gz, layer._gw, layer._gb if bias else None, N, Hin, Hin, layer.c, ups=ups)
+    4x4 / 8x8 maps keep the direct kernels.  ``defer``: a bias-free contribution that a later ``_wgrad`` of the same layer
+    (same step, same input geometry) will carry along."""
+    wino = _wino_wgrad_ok(layer, Hin)
+    if defer and wino and DEFER_TANGENT_WGRAD and not bias and not ups:
+        layer._pending_wgrad = (x, gz, N, Hin)
+        return
+    pend = layer.__dict__.get('_pending_wgrad')
+    if pend is not None and not (wino and pend[3] == Hin and not ups):
+        _flush_wgrad(layer)
+        pend = None
+    layer._pending_wgrad = None
+    with _on_side(x, gz, *(pend[:2] if pend is not None else ())):
+        if wino:
+            ops.conv2d_wgrad_wino(x, gz, layer._gw, layer._gb if bias else None, N, Hin, Hin, layer.c, ups=ups,
+                                  second=(pend[0], pend[1], pend[2], False) if pend is not None else None)
             return
         ops.conv2d_wgrad(x, gz, layer._gw, layer._gb if bias else None, N, Hin, Hin, layer.ksize, layer.pad,
                          layer.c, ups=ups)
+
+
+def _flush_wgrad(layer):
+    """Launch a deferred contribution on its own (nothing came to carry it)."""
+    pend = layer.__dict__.get('_pending_wgrad')
+    if pend is None:
+        return
+    layer._pending_wgrad = None
+    x, gz, N, Hin = pend
+    with _on_side(x, gz):
+        ops.conv2d_wgrad_wino(x, gz, layer._gw, None, N, Hin, Hin, layer.c)
 
 
 _ONES = {}
@@ -817,20 +849,20 @@ def d_tangent_wgrad(D, sub, adj, u):
         if rec['last']:
             tmb, tstats = ops.mbstd_tangent(rec['inp'], cur, rec['stats'], c1.cin_store)
             hvp = (cur, tstats, adj[idx]['gmb'])
-            _wgrad(tmb, adj[idx]['gz1'], c1, N, H, bias=False)
+            _wgrad(tmb, adj[idx]['gz1'], c1, N, H, bias=False, defer=True)
             t1 = _conv(tmb, c1, N, H, mask=rec['a1'], bias=False)
             if pn:
                 t1, injs[idx]['inj1'] = ops.pixelnorm_tangent(t1, rec['a1'], rec['r1'], adj[idx]['gy1'])
-            _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False)
+            _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False, defer=True)
             t2 = _conv(t1, c2, N, H, mask=rec['a2'], bias=False)
             if pn:
                 t2, injs[idx]['inj2'] = ops.pixelnorm_tangent(t2, rec['a2'], rec['r2'], adj[idx]['gy2'])
         else:
-            _wgrad(cur, adj[idx]['gz1'], c1, N, H, bias=False)
+            _wgrad(cur, adj[idx]['gz1'], c1, N, H, bias=False, defer=True)
             t1 = _conv(cur, c1, N, H, mask=(rec['a1'], rec.get('a1b')), bias=False)
             if pn:
                 t1, injs[idx]['inj1'] = ops.pixelnorm_tangent(t1, rec['a1'], rec['r1'], adj[idx]['gy1'])
-            _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False)
+            _wgrad(t1, adj[idx]['gz2'], c2, N, H, bias=False, defer=True)
             tpf = None
             if rec['first'] and alpha < 1.0:
                 nfr = recs[idx + 1]['blk'].fromRGB
@@ -930,9 +962,13 @@ def d_loss_backward(state, scale=1.0):
     ops.zero_(D._flat_grad)
     if scale != 1.0:
         D._grad_hook = None                      # the gradients are rescaled after the sweep: nothing may travel early
+    for lay in _live_conv_layers(D):             # (nothing of an aborted earlier step may ride along)
+        lay._pending_wgrad = None
     hvp = d_tangent_wgrad(D, state['sub'], state['adj'], state['u'])
     gs = state['gscore'][:2 * N]
     d_backward(D, ctx, gs, full=True, want_gimg=False, hvp=(2 * N,) + hvp)
+    for lay in _live_conv_layers(D):             # (a deferred tangent contribution that no launch of the sweep carried)
+        _flush_wgrad(lay)
     if not (getattr(D, '_skip_join', False) and scale == 1.0):
         _join_side()         # default: the gradients are complete for whatever the caller does next on this stream
     # (Trainer sets _skip_join when the whole D update follows on the second stream, in order behind the weight

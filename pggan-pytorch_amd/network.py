@@ -109,6 +109,7 @@ class PGConv2d(nn.Module):
         d['_wt_ver'] = None
         d['_wu'] = d['_wtu'] = None
         d['_net'] = None
+        d['_pending_wgrad'] = None
         return d
 
 

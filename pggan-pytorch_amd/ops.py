@@ -208,10 +208,17 @@ def conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=False):
               1 if ups else 0, scale, _stream())
 
 
-def conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=False):
-    """Winograd form of conv2d_wgrad for 3x3 pad-1 layers: accumulates into dw [3,3,Cout,Cin] (and db)."""
+def conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=False, second=None):
+    """Winograd form of conv2d_wgrad for 3x3 pad-1 layers: accumulates into dw [3,3,Cout,Cin] (and db).
+    ``second`` = (x2, gz2, N2, bias2): another batch of the same layer summed in the same launch (one commit of dW);
+    its gz joins db when ``bias2``."""
     cout, cin = dw.shape[2], dw.shape[3]
-    _lib.call('pg_conv2d_wgrad_wino_nhwc', _p(x), _p(gz), _p(dw), _p(db), N, H, W, cin, cout, 1 if ups else 0, scale, _stream())
+    if second is None:
+        _lib.call('pg_conv2d_wgrad_wino_nhwc', _p(x), _p(gz), _p(dw), _p(db), N, H, W, cin, cout, 1 if ups else 0, scale, _stream())
+        return
+    x2, gz2, n2, bias2 = second
+    _lib.call('pg_conv2d_wgrad_wino2_nhwc', _p(x), _p(gz), N, _p(x2), _p(gz2), n2, _p(dw), _p(db),
+              (1 if db is not None else 0) | (2 if (bias2 and db is not None) else 0), H, W, cin, cout, 1 if ups else 0, scale, _stream())
 
 
 def pack_dgrad_weights(w, wt):

@@ -87,8 +87,11 @@ def conv2d_wgrad_unpooled(x, g, gbytes, gmul, gslope, dw, db, N, Hin, Win, scale
     conv2d_wgrad(x, _unpooled(g, gbytes, gmul, gslope), dw, db, N, Hin, Win, 3, 1, scale)
 
 
-def conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=False):
+def conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=False, second=None):
     conv2d_wgrad(x, gz, dw, db, N, H, W, 3, 1, scale, ups=ups)
+    if second is not None:
+        x2, gz2, n2, bias2 = second
+        conv2d_wgrad(x2, gz2, dw, db if bias2 else None, n2, H, W, 3, 1, scale, ups=ups)
 
 
 def pack_dgrad_weights_batched(flat_w, flat_wt, layers):

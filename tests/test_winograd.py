@@ -178,6 +178,63 @@ def test_conv2d_wgrad_wino_kernel(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', [(6, 3, 32, 32, 32, 0), (2, 1, 16, 64, 96, 0), (1, 3, 64, 16, 16, 0), (4, 2, 32, 20, 36, 1), (9, 3, 16, 128, 64, 0)])
+@pytest.mark.parametrize('bias2', [False, True])
+def test_conv2d_wgrad_wino_two_batches(case, bias2):
+    """pg_conv2d_wgrad_wino2_nhwc: two batches of one layer in one launch == the two launches (the deferred gradient-penalty
+    tangent term riding in the launch of D's batched adjoint sweep); db from the first batch, optionally the second."""
+    N, N2, H, ci, co, ups = case
+    ops = pg.ops
+    hin = H // 2 if ups else H
+    x, gz = rnd(N, hin, hin, ci), rnd(N, H, H, co, seed=1)
+    x2, gz2 = rnd(N2, hin, hin, ci, seed=4), rnd(N2, H, H, co, seed=5)
+    dw0, db0 = rnd(3, 3, co, ci, seed=2), rnd(co, seed=3)
+    rdw, rdb = dw0.clone(), db0.clone()
+    E.conv2d_wgrad(x, gz, rdw, rdb, N, H, H, 3, 1, 0.41, ups=bool(ups))
+    E.conv2d_wgrad(x2, gz2, rdw, rdb if bias2 else None, N2, H, H, 3, 1, 0.41, ups=bool(ups))
+    dw, db = dw0.cuda(), db0.cuda()
+    ops.conv2d_wgrad_wino(x.cuda(), gz.cuda(), dw, db, N, H, H, 0.41, ups=bool(ups), second=(x2.cuda(), gz2.cuda(), N2, bias2))
+    assert rel_err(dw, rdw) < 2e-5 and rel_err(db, rdb) < 2e-5
+    dw = dw0.cuda()                                  # no bias gradient at all
+    ops.conv2d_wgrad_wino(x.cuda(), gz.cuda(), dw, None, N, H, H, 0.41, ups=bool(ups), second=(x2.cuda(), gz2.cuda(), N2, bias2))
+    assert rel_err(dw, rdw) < 2e-5
+
+
+@pytest.mark.gpu
+def test_deferred_tangent_wgrad_matches_separate_launches(monkeypatch):
+    """engine.DEFER_TANGENT_WGRAD: D's gradients with the tangent term carried by the sweep's launches == launched on its own,
+    and the two-batch entry point is really taken."""
+    from helpers import synthetic
+    calls = []
+    orig = pg.ops.conv2d_wgrad_wino
+    monkeypatch.setattr(pg.ops, 'conv2d_wgrad_wino', lambda *a, **k: (calls.append(k.get('second') is not None), orig(*a, **k))[1])
+    grads = {}
+    for flag in (True, False):
+        monkeypatch.setattr(pg.engine, 'DEFER_TANGENT_WGRAD', flag)
+        torch.manual_seed(5)
+        shape = (1, 3, 64, 64)
+        G, D = pg.Generator(shape, fmap_base=1024).cuda(), pg.Discriminator(shape, fmap_base=1024).cuda()
+        G.depth = D.depth = 4
+        G.alpha = D.alpha = 1.0
+        real, z_d, _, mix = synthetic(3, 3, 3, 64, G.latent_size)
+        pg.wgan_gp_loss.set_mixing_factors(mix)
+        try:
+            cost, _, _ = pg.wgan_gp_D_loss(D, G, real.cuda(), z_d.cuda())
+            cost.backward()
+        finally:
+            pg.wgan_gp_loss.set_mixing_factors(None)
+        grads[flag] = reference_grads(D)
+        if flag:
+            assert any(calls), 'no launch carried a deferred contribution'
+            calls.clear()
+        else:
+            assert not any(calls)
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 8
+    for name in grads[True]:                     # (atomic commits: sums with cancellation repeat to ~1e-4 run to run; a lost or doubled
+        assert rel_err(grads[True][name], grads[False][name]) < 5e-4, name      #  contribution would be O(1))
+
+
+@pytest.mark.gpu
 def test_conv2d_wgrad_wino_rejects_small_maps():
     ops = pg.ops
     x, gz = torch.zeros(2, 8, 8, 32, device='cuda'), torch.zeros(2, 8, 8, 32, device='cuda')
