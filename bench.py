@@ -256,10 +256,14 @@ def timed_steps(tr, steps, warmup, dp, fn=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    HOST_ENQUEUE['ms'] = 1e3 * (time.perf_counter() - t0) / steps      # host time to ENQUEUE a step (the device is still running)
     torch.cuda.synchronize()
     if dp is not None:
         dp.barrier()
     return _max_over_ranks(time.perf_counter() - t0, dp)
+
+
+HOST_ENQUEUE = {'ms': None}
 
 
 def robust_ms(tr, dp, fn=None, prime=20, window_s=0.35, windows=3):
@@ -489,6 +493,7 @@ def main():
         dp.stats.update(collectives=0, bytes=0)
     dt = timed_steps(tr, args.steps, args.warmup, dp)
     ms_per_step = 1e3 * dt / args.steps
+    host_ms = HOST_ENQUEUE['ms']
     value = n_gpus * mb * args.steps / dt
     w_d, w = step_flops(tr.G, tr.D, depth, args.alpha)
 
@@ -505,6 +510,7 @@ def main():
                    'parallelism': 'dp%d' % n_gpus, 'fmap_base': args.fmap_base},
         'step_algorithmic_gflop_per_image': w / 1e9,
         'algorithmic_frac': w * (value / n_gpus) / MFMA_F32_PEAK,
+        'host_enqueue_ms_per_step': host_ms,       # Python + launch time of one step on the host; the device runs behind it
     }
     out['config']['hip_graphs'] = bool((args.graphs or depth == 0) and args.alpha >= 1.0)
     if rccl is not None:
@@ -552,14 +558,15 @@ def main():
         try:                                   # HBM bytes per launch / MFMA-busy of that symbol from the committed PMC pass
             with open(os.path.join(ROOT, src)) as f:
                 prof = json.load(f)['per_kernel']
-            traffic = prof[dom]['hbm_bytes_per_launch']
         except Exception:
-            src = None
+            prof, src = None, None
+        if prof is not None and dom in prof:
+            traffic = prof[dom]['hbm_bytes_per_launch']
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': MFMA_F32_PEAK / 1e12,
                            'unit': 'TFLOP/s', 'frac': d['tflops'] * 1e12 / MFMA_F32_PEAK,
                            'frac_is': 'ALGORITHMIC FLOP of the launches / HIP-event time / nominal peak (not MFMA utilisation)',
                            'executed_mfma_frac': d['exec_tflops'] * 1e12 / MFMA_F32_PEAK,
-                           'traffic': traffic, 'traffic_source': src,
+                           'traffic': traffic, 'traffic_source': src if traffic is not None else None,
                            'mfma_busy_pct': prof[dom]['mfma_busy_pct'] if prof and dom in prof else None,
                            'avg_launch_us': d['avg_launch_us'], 'launches_per_step': d['launches_per_step'],
                            'ms_per_step_in_kernel': d['ms_per_step'],
