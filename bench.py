@@ -119,7 +119,7 @@ class KernelTimer(object):
             e0.record()
             out = orig(*a, **k)
             e1.record()
-            sym = (lib.pg_debug_last_wino_kernel() if name == 'conv2d_wino' else
+            sym = (lib.pg_debug_last_wino_kernel() if name in ('conv2d_wino', 'conv2d_wino_pixelnorm') else
                    lib.pg_debug_last_wino_wgrad_kernel() if name == 'conv2d_wgrad_wino' else
                    lib.pg_debug_last_conv_kernel()).decode()
             fl, tag = describe(a, k)
@@ -157,8 +157,12 @@ class KernelTimer(object):
             u, n, h = a[1], a[3], a[4]
             return (conv_flops(n, h, h, 3, 1, u.shape[1], u.shape[2]),
                     'conv %d->%d k3 @%d n%d winograd%s' % (u.shape[2], u.shape[1], h, n, ' masked' if k.get('mask') is not None else ''))
+        def wino_pn_desc(a, k):       # conv2d_wino_pixelnorm(x, u, bias, N, H, W, scale, slope, eps, ups=)
+            fl, tag = wino_desc(a, {})
+            return fl, tag + ' +pixelnorm'
         self._wrap('conv2d', conv_desc)
         self._wrap('conv2d_wino', wino_desc)
+        self._wrap('conv2d_wino_pixelnorm', wino_pn_desc)
         self._wrap('conv2d_pool', pool_desc)
         self._wrap('conv2d_pixelnorm', generic(1, 3, '+pixelnorm'))
         self._wrap('conv2d_unpool', generic(1, 2, '+unpool'))

@@ -248,6 +248,192 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 32 x 32 blocks, second mapping: a wave owns BOTH cout halves of one cin half (two 16 x 16 accumulator sets) and the two wave
+// pairs split the k-steps of a region.  Per 32 MFMAs a wave then transforms Z for 32 couts (24 VALU, 8 reads) and V for 16 cins
+// (32 VALU, 16 reads): 56 VALU + 24 LDS reads per 32 MFMAs instead of 2 x (44 + 20) -- the phase trace put the k-steps of the
+// first mapping at 1460 cycles per 16 MFMAs per wave (512 of MFMA issue), i.e. bound by the transform and fragment traffic every
+// wave repeats.  The wave pairs fold their sums through LDS at the end (as the 16-channel variants do).
+__global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
+{
+    constexpr int SZ = stride_for(2), SX = stride_for(2);
+    constexpr int VZ = 8, VX = 8;                          // float4 per pixel
+    __shared__ __align__(16) float smem[PH * PW * SZ + HH_ * HW_ * SX];
+    float* gzt = smem;                                     // [128 px][32 co]
+    float* xt = smem + PH * PW * SZ;                       // [180 px][32 ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int wave_ci = wave & 1, wk = wave >> 1;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
+    const bool do_bias = p.db != nullptr && blockIdx.z == 0 && wave_ci == 0;
+
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+
+    constexpr int ZPT = (PH * PW * VZ) / 256;              // 4
+    constexpr int XPT = (HH_ * HW_ * VX + 255) / 256;      // 6
+    unsigned zoff[ZPT];
+    int xpy[XPT], xpx[XPT], xcv[XPT];
+#pragma unroll
+    for (int i = 0; i < ZPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / VZ, v = idx % VZ;
+        const int py = q / PW, px = q - py * PW;
+        zoff[i] = co0 + 4 * v < p.Cout ? 4u * (unsigned)((py * p.W + px) * p.Cout + 4 * v) : PG_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx / VX, v = idx % VX;
+        const int py = q / HW_, px = q - py * HW_;
+        const bool live = q < HH_ * HW_ && ci0 + 4 * v < p.Cin;
+        xpy[i] = live ? py - 1 : -(1 << 20);
+        xpx[i] = px - 1;
+        xcv[i] = 4 * v;
+    }
+    const unsigned zimg = (unsigned)((size_t)p.H * p.W * p.Cout * 4), ximg = (unsigned)((size_t)xH * xW * p.Cin * 4);
+    float4 zreg[ZPT], xreg[XPT];
+    auto fetch = [&](int region) {
+        const bool second = region >= p.nregions1;
+        int r = second ? region - p.nregions1 : region;
+        const float* xb = second ? p.x2 : p.x;
+        const float* gb = second ? p.gz2 : p.gz;
+        const int bw = r % p.blocksW; r /= p.blocksW;
+        const int bh = r % p.blocksH; const int n = r / p.blocksH;
+        const int oy0 = bh * PH, ox0 = bw * PW;
+        const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(gb + (size_t)n * p.H * p.W * p.Cout + co0, zimg - 4u * (unsigned)co0);
+        const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(xb + (size_t)n * xH * xW * p.Cin + ci0, ximg - 4u * (unsigned)ci0);
+        const unsigned zbase = 4u * (unsigned)((oy0 * p.W + ox0) * p.Cout);
+#pragma unroll
+        for (int i = 0; i < ZPT; ++i) zreg[i] = pg_buf_load4(rz, zoff[i], zbase);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            int ih = oy0 + xpy[i], iw = ox0 + xpx[i];
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            if (p.ups) { ih >>= 1; iw >>= 1; }
+            xreg[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)((ih * xW + iw) * p.Cin + xcv[i]) : PG_OOB, 0);
+        }
+    };
+    const int r_begin = (int)pg_xcd_remap(blockIdx.x, gridDim.x) * p.regions_per_block;
+    const int r_end = min(r_begin + p.regions_per_block, p.nregions);
+    if (r_begin < r_end) fetch(r_begin);
+    for (int region = r_begin; region < r_end; ++region) {
+#pragma unroll
+        for (int i = 0; i < ZPT; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<float4*>(gzt + (idx / VZ) * SZ + 4 * (idx % VZ)) = zreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx / VX < HH_ * HW_) *reinterpret_cast<float4*>(xt + (idx / VX) * SX + 4 * (idx % VX)) = xreg[i];
+        }
+        __syncthreads();
+        if (region + 1 < r_end) fetch(region + 1);
+        const bool bias_here = (p.db_batches >> (region >= p.nregions1 ? 1 : 0)) & 1;
+#pragma unroll 2
+        for (int step = wk; step < 8; step += 2) {
+            const int t = 4 * step + kk;
+            const int ttx = t & (RTW - 1), tty = t >> 3;
+            // V = B^T d B from the 4x4 x patch (B operand, shared by both cout halves)
+            const float* xp = xt + ((2 * tty) * HW_ + 2 * ttx) * SX + wave_ci * 16 + li;
+            float d[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[a][c] = xp[(a * HW_ + c) * SX];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
+                d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float t0 = d[a][0] - d[a][2], t1 = d[a][1] + d[a][2], t2 = d[a][2] - d[a][1], t3 = d[a][1] - d[a][3];
+                d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                    // Z = A dY A^T of cout half h (A operand)
+                const float* gp = gzt + ((2 * tty) * PW + 2 * ttx) * SZ + h * 16 + li;
+                const float y00 = gp[0], y01 = gp[SZ], y10 = gp[PW * SZ], y11 = gp[(PW + 1) * SZ];
+                if (bias_here) bsum[h] += (y00 + y01) + (y10 + y11);
+                const float c0a = y00, c0b = y01;
+                const float c1a = y00 + y10, c1b = y01 + y11;
+                const float c2a = y00 - y10, c2b = y01 - y11;
+                const float c3a = -y10, c3b = -y11;
+                float z[16];
+                z[0] = c0a; z[1] = c0a + c0b; z[2] = c0a - c0b; z[3] = -c0b;
+                z[4] = c1a; z[5] = c1a + c1b; z[6] = c1a - c1b; z[7] = -c1b;
+                z[8] = c2a; z[9] = c2a + c2b; z[10] = c2a - c2b; z[11] = -c2b;
+                z[12] = c3a; z[13] = c3a + c3b; z[14] = c3a - c3b; z[15] = -c3b;
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) acc[h][xi] = MFMA16(z[xi], d[xi >> 2][xi & 3], acc[h][xi]);
+            }
+        }
+        __syncthreads();
+    }
+    // dg = G^T M G, lane-local; the second wave pair hands its sums over through LDS (the tile buffers are free now)
+    static_assert(2 * 2 * 36 * 64 <= PH * PW * SZ + HH_ * HW_ * SX, "reduction slots reuse the tile buffers");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float g[4][9];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m[4][4];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = acc[h][xi][r];
+            float t[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s2 = 0.5f * (m[1][j] + m[2][j]), dlt = 0.5f * (m[1][j] - m[2][j]);
+                t[0][j] = m[0][j] + s2; t[1][j] = dlt; t[2][j] = s2 + m[3][j];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float s2 = 0.5f * (t[a][1] + t[a][2]), dlt = 0.5f * (t[a][1] - t[a][2]);
+                g[r][3 * a] = t[a][0] + s2; g[r][3 * a + 1] = dlt; g[r][3 * a + 2] = s2 + t[a][3];
+            }
+        }
+        float* slot = smem + ((wave_ci * 2 + h) * 36) * 64 + lane;
+        if (wk == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int v = 0; v < 9; ++v) slot[(9 * r + v) * 64] = g[r][v];
+        }
+        __syncthreads();
+        if (wk == 0) {
+            const int ci = ci0 + wave_ci * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + h * 16 + 4 * kk + r;
+                if (co < p.Cout && ci < p.Cin) {
+                    float* dst = p.dw + (size_t)co * p.Cin + ci;
+#pragma unroll
+                    for (int v = 0; v < 9; ++v) atomicAdd(dst + (size_t)v * p.Cout * p.Cin, (g[r][v] + slot[(9 * r + v) * 64]) * p.scale);
+                }
+            }
+        }
+        __syncthreads();                                  // (the slots are reused by nobody, but keep the two halves' barriers paired)
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float b = bsum[h];
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+            const int co = co0 + h * 16 + li;
+            if (kk == 0 && co < p.Cout) atomicAdd(p.db + co, b);
+        }
+    }
+}
+
+
 thread_local char g_ww_last[64] = "";
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -298,7 +484,14 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
     chunks = (p.nregions + p.regions_per_block - 1) / p.regions_per_block;
     snprintf(g_ww_last, sizeof(g_ww_last), "conv_wino_wgrad_kernel<%d, %d>", nco, nci);
     const dim3 grid(chunks, gy, gz_);
-    if (nco == 2 && nci == 2) hipLaunchKernelGGL((conv_wino_wgrad_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    // measured (tools/sweep_wino_wgrad.py, PG_WW_PAIR=0/1/2): the pair mapping wins 8-9 % from ~9 regions per workgroup on
+    // (n9 @64 128->256: 137 -> 126 us) and loses up to 15 % at 3 (its extra fold through LDS); 1: built-in choice, 0 / 2: never / always
+    static const int pair_env = getenv("PG_WW_PAIR") ? atoi(getenv("PG_WW_PAIR")) : 1;
+    if (nco == 2 && nci == 2 && (pair_env == 2 || (pair_env == 1 && p.regions_per_block >= 6))) {
+        snprintf(g_ww_last, sizeof(g_ww_last), "conv_wino_wgrad_pair_kernel");
+        hipLaunchKernelGGL(conv_wino_wgrad_pair_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
+    else if (nco == 2 && nci == 2) hipLaunchKernelGGL((conv_wino_wgrad_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (nco == 1 && nci == 2) hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (nco == 2 && nci == 1) hipLaunchKernelGGL((conv_wino_wgrad_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -157,7 +157,8 @@ def test_conv2d_wino_pixelnorm_kernel(case):
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', [(2, 16, 32, 32, 0), (3, 16, 64, 96, 0), (1, 32, 36, 48, 0), (9, 16, 128, 64, 0), (2, 64, 32, 64, 1),
                                   (5, 32, 8, 40, 1), (1, 128, 32, 32, 0), (7, 16, 100, 36, 0), (2, 16, 32, 32, 1),
-                                  (2, 16, 16, 16, 0), (3, 32, 16, 32, 0), (2, 32, 32, 16, 1), (1, 64, 12, 20, 0), (3, 64, 8, 16, 0)])
+                                  (2, 16, 16, 16, 0), (3, 32, 16, 32, 0), (2, 32, 32, 16, 1), (1, 64, 12, 20, 0), (3, 64, 8, 16, 0),
+                                  (6, 32, 256, 256, 0), (5, 64, 200, 144, 0), (8, 64, 96, 160, 1)])     # (the last three: pair mapping)
 def test_conv2d_wgrad_wino_kernel(case):
     """csrc/conv_wino_wgrad.hip vs the torch restatement of the weight gradient, accumulating onto non-zero dw/db;
     ragged channel counts (not multiples of the 32x32 block) and the upsample-fused input included."""
@@ -170,7 +171,10 @@ def test_conv2d_wgrad_wino_kernel(case):
     E.conv2d_wgrad(x, gz, rdw, rdb, N, H, H, 3, 1, 0.41, ups=bool(ups))
     dw, db = dw0.cuda(), db0.cuda()
     ops.conv2d_wgrad_wino(x.cuda(), gz.cuda(), dw, db, N, H, H, 0.41, ups=bool(ups))
-    assert pg._lib.load().pg_debug_last_wino_wgrad_kernel().decode().startswith('conv_wino_wgrad_kernel')
+    sym = pg._lib.load().pg_debug_last_wino_wgrad_kernel().decode()
+    assert sym.startswith('conv_wino_wgrad_')
+    if N >= 5 and min(ci, co) >= 96:
+        assert sym == 'conv_wino_wgrad_pair_kernel'         # >= 6 regions per workgroup: the wave-pair mapping
     assert rel_err(dw, rdw) < 2e-5 and rel_err(db, rdb) < 2e-5
     dw2 = dw0.cuda()
     ops.conv2d_wgrad_wino(x.cuda(), gz.cuda(), dw2, None, N, H, H, 0.41, ups=bool(ups))
@@ -178,7 +182,8 @@ def test_conv2d_wgrad_wino_kernel(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', [(6, 3, 32, 32, 32, 0), (2, 1, 16, 64, 96, 0), (1, 3, 64, 16, 16, 0), (4, 2, 32, 20, 36, 1), (9, 3, 16, 128, 64, 0)])
+@pytest.mark.parametrize('case', [(6, 3, 32, 32, 32, 0), (2, 1, 16, 64, 96, 0), (1, 3, 64, 16, 16, 0), (4, 2, 32, 20, 36, 1), (9, 3, 16, 128, 64, 0),
+                                  (6, 3, 32, 256, 256, 0)])
 @pytest.mark.parametrize('bias2', [False, True])
 def test_conv2d_wgrad_wino_two_batches(case, bias2):
     """pg_conv2d_wgrad_wino2_nhwc: two batches of one layer in one launch == the two launches (the deferred gradient-penalty
