@@ -235,8 +235,13 @@ def test_deferred_tangent_wgrad_matches_separate_launches(monkeypatch):
         else:
             assert not any(calls)
     assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 8
-    for name in grads[True]:                     # (atomic commits: sums with cancellation repeat to ~1e-4 run to run; a lost or doubled
-        assert rel_err(grads[True][name], grads[False][name]) < 5e-4, name      #  contribution would be O(1))
+    # Two runs of the same step agree only to the branch-flip level of tests/test_e2e_gpu.py (split-K atomics in the low-resolution
+    # layers move activations by an ulp, a LeakyReLU branch may flip: 1e-4 .. 5e-3 per tensor); a lost or doubled tangent term is O(0.1 .. 1)
+    num = sum(float(((grads[True][n] - grads[False][n]).double() ** 2).sum()) for n in grads[True])
+    den = sum(float((grads[False][n].double() ** 2).sum()) for n in grads[True])
+    assert (num / den) ** 0.5 < 4e-3
+    for name in grads[True]:
+        assert rel_err(grads[True][name], grads[False][name]) < 3e-2, name
 
 
 @pytest.mark.gpu
