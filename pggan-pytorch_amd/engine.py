@@ -84,7 +84,9 @@ def _derived(net):
     ops.pack_dgrad_weights_batched(net._flat_param, net._flat_wt,
                                    [((m.conv.weight.data_ptr() - base) // 4, m.ksize, m.conv.weight.shape[2],
                                      m.conv.weight.shape[3]) for m in todo])
-    wl = [(m, woff, uoff) for m, woff, uoff in (net._wino_layers or []) if id(m) in live]
+    # ... and of those only the layers the Winograd path has actually asked for (_wino marks them): the 512-channel layers of the
+    # 4x4 / 8x8 stages never reach the workgroup threshold at the reference minibatches, yet are half of all Winograd-domain bytes
+    wl = [(m, woff, uoff) for m, woff, uoff in (net._wino_layers or []) if id(m) in live and getattr(m, '_wino_wanted', False)]
     if USE_WINOGRAD and wl:
         ops.wino_transform_weights_batched(net._flat_param, net._flat_wu,
                                            [(woff, uoff, m.conv.weight.shape[2], m.conv.weight.shape[3]) for m, woff, uoff in wl])
@@ -108,7 +110,11 @@ def _wino(layer, N, H, cout, transposed=False):
         return None
     if -(-(N * (H // 2) * (H // 2)) // 64) * -(-cout // 16) < WINO_MIN_WORKGROUPS:
         return None
-    _derived(layer._net())
+    net = layer._net()
+    if not getattr(layer, '_wino_wanted', False):       # first request: from now on the refresh after every update includes this layer
+        layer._wino_wanted = True
+        net._derived_ver = None
+    _derived(net)
     return layer._wtu if transposed else layer._wu
 
 
