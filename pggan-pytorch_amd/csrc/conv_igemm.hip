@@ -1576,7 +1576,10 @@ int launch_wgrad(WgP& p, hipStream_t s)
 // 16/NB pixels (4 for 8x8, 2 for 8x16) with every lane doing useful work.  Lane l: block b = l>>2, A row / B col
 // = l&3; D register r of lane 4b+j is element [r][j] of block b.  Blocks of the same (co-quad, ci-quad) but
 // different pixel slot are separate accumulators, summed by xor-shuffles before the workgroup reduction.
-template <int CO, int CI, int BPX>
+// FIX: the tile is 16 x 4 pixels of one image (every layer this kernel serves from 16 x 16 maps up): the k-step -> LDS address map is
+// then a per-lane base plus compile-time constants, i.e. immediate offsets of the ds_reads instead of ~12 VALU instructions per k-step
+// (rocprofv3 SQ_INSTS_VALU per wave, 8->16 @1024^2 n9: 9.2 k non-MFMA VALU next to 10.4 k MFMAs before).
+template <int CO, int CI, int BPX, bool FIX>
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
 {
     constexpr int KS = 3, TAPS = 9;
@@ -1591,7 +1594,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
     constexpr int XPT = (XMAX * XV + 255) / 256;
     extern __shared__ __align__(16) float lds[];
 
-    const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
+    static_assert(!FIX || BPX == 64, "the fixed geometry is 16 x 4 pixels");
+    const int TW = FIX ? 16 : 1 << p.lgTW, TH = FIX ? 4 : 1 << p.lgTH;
     const int HT = TH + KS - 1, WT = TW + KS - 1;
     float* gzt = lds;                        // [BPX][SZ]
     float* xt = lds + BPX * SZ;              // [TN*HT*WT][SX]
@@ -1650,6 +1654,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
     int tapoff[TAPS];
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp) tapoff[tp] = ((tp / KS) * WT + (tp % KS)) * SX;
+    int abase[GQ], bbase;                                        // FIX: LDS offsets of this lane's fragments at k-step 0
+    {
+        const int q0 = PPM * wave + slot;
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) abase[g] = q0 * SZ + 4 * ho[g] + i4;
+        bbase = q0 * SX + 4 * hi + i4;
+    }
 
     float4 zreg[ZPT], xreg[XPT];
     unsigned char zb[ZPT];                   // sign bytes of the prefetched gz values (pool adjoint in the gather)
@@ -1718,14 +1729,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
         if (tile + 1 < t_end) fetch();
         PG_WSTAMP(3);
 
-        auto load_frags = [&](int step, float (&af)[GQ], float (&bf)[TAPS]) {
-            const int q = PPM * step + slot;
-            const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
+        auto load_frags = [&](int kstep, float (&af)[GQ], float (&bf)[TAPS]) {      // k-step of this wave: step = wave + 4 kstep
+            if constexpr (FIX) {
+                // pixel q = q0 + 4 PPM kstep with q0 = PPM wave + slot < 4 PPM <= 16: q0 stays inside tile row 0, kstep walks along the
+                // row (16 / (4 PPM) steps) and then down: every offset below is a per-lane base + a compile-time constant
+                constexpr int PER_ROW = 16 / (4 * PPM);
+                const int th = kstep / PER_ROW, dw_ = (kstep % PER_ROW) * 4 * PPM;
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) af[g] = gzt[q * SZ + 4 * ho[g] + i4];
-            const int bo = ((tn * HT + th) * WT + tw) * SX + 4 * hi + i4;
+                for (int g = 0; g < GQ; ++g) af[g] = gzt[abase[g] + (th * 16 + dw_) * SZ];
 #pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) bf[tp] = xt[bo + tapoff[tp]];
+                for (int tp = 0; tp < TAPS; ++tp) bf[tp] = xt[bbase + ((th + tp / KS) * 18 + dw_ + tp % KS) * SX];
+            } else {
+                const int q = PPM * (wave + 4 * kstep) + slot;
+                const int tw = q & (TW - 1), th = (q >> p.lgTW) & (TH - 1), tn = q >> (p.lgTW + p.lgTH);
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) af[g] = gzt[q * SZ + 4 * ho[g] + i4];
+                const int bo = ((tn * HT + th) * WT + tw) * SX + 4 * hi + i4;
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) bf[tp] = xt[bo + tapoff[tp]];
+            }
         };
         auto mfmas = [&](const float (&af)[GQ], const float (&bf)[TAPS]) {
 #pragma unroll
@@ -1737,13 +1759,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
         };
         float a[2][GQ], b[2][TAPS];
         static_assert(T % 2 == 0, "k-steps per wave must be even");
-        load_frags(wave, a[0], b[0]);
+        load_frags(0, a[0], b[0]);
+#pragma unroll
         for (int s2 = 0; s2 < T; s2 += 2) {
-            load_frags(wave + (s2 + 1) * 4, a[1], b[1]);
+            load_frags(s2 + 1, a[1], b[1]);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(a[0], b[0]);
             __builtin_amdgcn_sched_barrier(0);
-            if (s2 + 2 < T) load_frags(wave + (s2 + 2) * 4, a[0], b[0]);
+            if (s2 + 2 < T) load_frags(s2 + 2, a[0], b[0]);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(a[1], b[1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -1822,8 +1845,12 @@ int launch_wgrad_thin(WgP& p, hipStream_t s)
 #ifdef PG_WINO_TRACE
     p.trace = g_wgrad_trace;
 #endif
-#define THIN(CO_, CI_) { auto kern = conv_wgrad_thin_kernel<CO_, CI_, BPX>; if (int rc = set_smem(kern, smem)) return rc; \
-                         hipLaunchKernelGGL(kern, dim3(chunks), dim3(256), smem, s, p); }
+    static const int fix_env = getenv("PG_WGRAD_THIN_FIX") ? atoi(getenv("PG_WGRAD_THIN_FIX")) : 1;
+    const bool fix = BPX == 64 && g.lgTW == 4 && g.lgTH == 2 && g.TN == 1 && fix_env;
+#define THIN(CO_, CI_) { if (fix) { auto kern = conv_wgrad_thin_kernel<CO_, CI_, BPX, BPX == 64>; if (int rc = set_smem(kern, smem)) return rc; \
+                             hipLaunchKernelGGL(kern, dim3(chunks), dim3(256), smem, s, p); } \
+                         else { auto kern = conv_wgrad_thin_kernel<CO_, CI_, BPX, false>; if (int rc = set_smem(kern, smem)) return rc; \
+                             hipLaunchKernelGGL(kern, dim3(chunks), dim3(256), smem, s, p); } }
     if (p.Cout == 8 && p.Cin == 8) THIN(8, 8)
     else if (p.Cout == 16 && p.Cin == 8) THIN(16, 8)
     else if (p.Cout == 8 && p.Cin == 16) THIN(8, 16)
