@@ -78,9 +78,12 @@ __device__ __forceinline__ unsigned char pg_sign_byte(float4 o)
     return (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
 }
 
+#ifndef PG_KCP4
+#define PG_KCP4 24
+#endif
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
 //   VEC=4 (ds_read_b128, 4x16 lanes, 64 banks): 24   VEC=2 (ds_read_b64): 12   VEC=1: 8
-template <int VEC> struct RowStride { static constexpr int value = VEC == 4 ? 24 : (VEC == 2 ? 12 : 8); };
+template <int VEC> struct RowStride { static constexpr int value = VEC == 4 ? PG_KCP4 : (VEC == 2 ? 12 : 8); };
 
 // Upper bound of the halo pixels of one tile (sizes the register prefetch): KS=3 with TH,TW >= 4 needs at most
 // 2.25*BPX; tiles of >= 512 pixels are always 32 wide (make_geom), so (BPX/32+2)*34 is exact there.
@@ -1270,7 +1273,10 @@ int launch_conv(ConvP& p, hipStream_t s)
 template <int WN>
 __global__ __launch_bounds__(256) void conv_ksplit_kernel(ConvP p)
 {
-    constexpr int KS = 3, TAPS = 9, BCO = 16, BPX = 16 * WN, KCP = 24, RS = 4 * KCP;   // LDS row = 4 wave slices
+    // LDS row = 4 wave slices + 4 floats: with a row stride of 96 floats the 16 lanes (li) of a ds_read_b128 group sat on TWO
+    // 4-bank groups (96 li mod 64 = 0 / 32: eight-way conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.65); 100 li mod 64
+    // walks through all sixteen 4-bank groups
+    constexpr int KS = 3, TAPS = 9, BCO = 16, BPX = 16 * WN, KCP = 24, RS = 4 * KCP + 4;
     constexpr int WEL = TAPS * BCO * 16;                        // float4 per weight super-chunk
     constexpr int WPT = (WEL + 255) / 256;
     constexpr int XMAX = BPX <= 16 ? 36 : (BPX * 9) / 4;
@@ -1433,7 +1439,7 @@ int launch_ksplit(ConvP& p, hipStream_t s)
     if (g.TN * HT * WT > XMAX) return PG_E_UNSUP;
     if ((long long)p.N * p.Hin * p.Win * p.Cin * 4 >= (1ll << 31) || (long long)9 * p.Cout * p.Cin * 4 >= (1ll << 31)) return PG_E_UNSUP;   // 32-bit buffer offsets
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
-    size_t smem = (size_t)(9 * 16 + g.TN * HT * WT) * 96 * sizeof(float);
+    size_t smem = (size_t)(9 * 16 + g.TN * HT * WT) * 100 * sizeof(float);      // RS of the kernel
     const size_t red = (size_t)3 * WN * 256 * sizeof(float);
     if (red > smem) smem = red;
     auto kern = conv_ksplit_kernel<WN>;
