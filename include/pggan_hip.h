@@ -153,6 +153,14 @@ int pg_conv2d_wino_pixelnorm_nhwc(const float* x, const float* u, const float* b
                                   int N, int H, int W, int Cin, int Cout, int ups,
                                   float scale, float slope, float eps, pg_stream_t stream);
 
+/* Backward-data conv of a generator layer on the transformed weights + the adjoint of the previous layer's (LeakyReLU -> PixelNorm)
+ * (network.py:44-52) in the Winograd epilogue: y = r * (g - ysaved * mean_c(g * ysaved)) * lrelu'(ysaved) with g = scale * conv(x),
+ * or, pool != 0, g = pool_a * avgpool2(scale * conv(x)) + pool_b * pool_other (the adjoint of the nearest x2 upsample is 4 * avgpool2:
+ * network.py:62-66); y, ysaved [N][H(/2)][W(/2)][Cout], r [N*H*W(/4)].  Cout <= 32 (PG_E_UNSUP otherwise: second pass).          */
+int pg_conv2d_wino_pnbwd_nhwc(const float* x, const float* u, const float* ysaved, const float* r, float* y,
+                              int pool, const float* pool_other, float pool_a, float pool_b,
+                              int N, int H, int W, int Cin, int Cout, float scale, float slope, pg_stream_t stream);
+
 /* Winograd weight gradient of the same layers: dW[kh][kw][co][ci] += scale * sum gz*x (3x3, pad 1), db[co] += sum gz, computed as
  * G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G  -- 16 MFMAs per 4 output tiles instead of 36.  H, W powers of two with
  * H >= 8, W >= 16; commits with fp32 atomics.  Same arguments as pg_conv2d_wgrad_nhwc (KS 3, pad 1 implied).          */
@@ -207,6 +215,10 @@ int pg_torgb_fwd(const float* x, const float* w, const float* bias, const float*
  * down != 0: g is [N][C][2H][2W] and is 2x2-SUMMED on the fly (adjoint of the upsample of `prev`). */
 int pg_torgb_bwd_data(const float* g, const float* w, float* gx,
                       int N, int C, int H, int W, int Cin, int down, float mul_scale, pg_stream_t stream);
+/* ... followed by the adjoint of the block's (LeakyReLU -> PixelNorm), network.py:44-52, in the same launch:
+ * gx = r * (gh - ysaved * mean_c(gh * ysaved)) * lrelu'(ysaved).  8 features on large maps; PG_E_UNSUP otherwise. */
+int pg_torgb_bwd_data_pnbwd(const float* g, const float* w, const float* ysaved, const float* r, float* gx,
+                            int N, int C, int H, int W, int Cin, float mul_scale, float slope, pg_stream_t stream);
 
 /* dw[c][ci] += mul_scale * sum_pix g[pix,c]*x[pix,ci];  db[c] += mul * sum_pix g[pix,c].       */
 int pg_torgb_wgrad(const float* g, const float* x, float* dw, float* db,

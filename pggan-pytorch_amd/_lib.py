@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class PgganLibraryError(RuntimeError):
@@ -37,6 +37,7 @@ SIGNATURES = {
     'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P],
     'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wino_pixelnorm_nhwc': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
+    'pg_conv2d_wino_pnbwd_nhwc': [P, P, P, P, P, I, P, F, F, I, I, I, I, I, F, F, P],
     'pg_conv2d_wgrad_wino_nhwc': [P, P, P, P, I, I, I, I, I, I, F, P],
     'pg_conv2d_wgrad_wino2_nhwc': [P, P, I, P, P, I, P, P, I, I, I, I, I, I, F, P],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
@@ -47,6 +48,7 @@ SIGNATURES = {
     'pg_fromrgb_wgrad': [P, P, P, P, I, I, I, I, I, I, F, P],
     'pg_torgb_fwd': [P, P, P, P, P, I, I, I, I, I, F, F, F, P],
     'pg_torgb_bwd_data': [P, P, P, I, I, I, I, I, I, F, P],
+    'pg_torgb_bwd_data_pnbwd': [P, P, P, P, P, I, I, I, I, I, F, F, P],
     'pg_torgb_wgrad': [P, P, P, P, I, I, I, I, I, I, F, F, P],
     'pg_avgpool2_fwd': [P, P, P, I, I, I, I, F, F, P],
     'pg_avgpool2_bwd': [P, P, P, I, I, I, I, F, F, P],

@@ -38,6 +38,7 @@ struct WinoP {
     int mask_bytes, y_bytes;                   // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES, pggan_hip.h)
     unsigned char* ysigns;                     // PG_FLAG_SIGNS_OUT
     float* pn_r; float pn_eps;                 // PixelNorm epilogue (pg_conv2d_wino_pixelnorm_nhwc): r[pixel] = rsqrt(mean_c y^2 + eps)
+    const float* pnb_y; const float* pnb_r;    // adjoint of (LeakyReLU -> PixelNorm) on the (optionally pooled) result (pg_conv2d_wino_pnbwd_nhwc)
 #ifdef PG_WINO_TRACE
     unsigned long long* trace;                 // [workgroup][wave][chunk][8] s_memtime stamps (tools/exp/wino_trace.py)
 #endif
@@ -239,6 +240,79 @@ __device__ __forceinline__ void wino_epilogue_pixelnorm(const WinoP& p, const f3
             }
         }
         if (cb0 == 0) p.pn_r[pix] = rr;
+    }
+}
+
+
+// Backward-data conv (optionally + the 2x2 pool that is the adjoint of the nearest x2 upsample) followed by the adjoint of the
+// previous layer's (LeakyReLU -> PixelNorm): out = r * (g - y * mean_c(g * y)) * lrelu'(y), y / r saved by the forward pass
+// (network.py:44-52).  Like the PixelNorm epilogue it needs every cout of a pixel in the workgroup (Cout <= 16 NCB).
+template <int NCB>
+__device__ __forceinline__ void wino_epilogue_pnbwd(const WinoP& p, const f32x4 (&acc)[NCB][16], int cb0, int ni, int oy0, int ox0)
+{
+    const bool pooled = p.ypool != nullptr;
+    float4 g[NCB][4];                                        // pooled: only g[c][0] is used
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        f32x4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = acc[c][0 + j] + acc[c][4 + j] + acc[c][8 + j];
+            s[1][j] = acc[c][4 + j] - acc[c][8 + j] - acc[c][12 + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = q >> 1;
+            const f32x4 v = (q & 1) ? s[a][1] - s[a][2] - s[a][3] : s[a][0] + s[a][1] + s[a][2];
+            g[c][q] = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
+        }
+    }
+    const int Ho = pooled ? p.H >> 1 : p.H, Wo = pooled ? p.W >> 1 : p.W;
+    const int nq = pooled ? 1 : 4;
+    if (pooled) {                                            // same form as the pooled epilogue of wino_epilogue
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int cb = cb0 + 16 * c;
+            float4 v;
+            v.x = ((g[c][0].x + g[c][1].x) + (g[c][2].x + g[c][3].x)) * 0.25f; v.y = ((g[c][0].y + g[c][1].y) + (g[c][2].y + g[c][3].y)) * 0.25f;
+            v.z = ((g[c][0].z + g[c][1].z) + (g[c][2].z + g[c][3].z)) * 0.25f; v.w = ((g[c][0].w + g[c][1].w) + (g[c][2].w + g[c][3].w)) * 0.25f;
+            if (p.pool_other && cb < p.Cout && ni < p.N) {
+                const size_t poff = (((size_t)ni * Ho + (oy0 >> 1)) * Wo + (ox0 >> 1)) * p.Cout + cb;
+                const float4 o = *reinterpret_cast<const float4*>(p.pool_other + poff);
+                v.x = fmaf(v.x, p.pool_a, p.pool_b * o.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * o.y);
+                v.z = fmaf(v.z, p.pool_a, p.pool_b * o.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * o.w);
+            } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
+            g[c][0] = v;
+        }
+    }
+    float* out = pooled ? p.ypool : p.y;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q >= nq) break;
+        const int oy = pooled ? (oy0 >> 1) : oy0 + (q >> 1), ox = pooled ? (ox0 >> 1) : ox0 + (q & 1);
+        const size_t pix = ((size_t)ni * Ho + oy) * Wo + ox;
+        float4 yv[NCB];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int cb = cb0 + 16 * c;
+            yv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cb < p.Cout && ni < p.N) yv[c] = *reinterpret_cast<const float4*>(p.pnb_y + pix * p.Cout + cb);
+            dot += (g[c][q].x * yv[c].x + g[c][q].y * yv[c].y) + (g[c][q].z * yv[c].z + g[c][q].w * yv[c].w);
+        }
+        dot += __shfl_xor(dot, 16, 64);                       // (every lane takes part: lanes without a live pixel add zeros)
+        dot += __shfl_xor(dot, 32, 64);
+        if (ni >= p.N) continue;
+        const float rr = p.pnb_r[pix], mean = dot / (float)p.Cout;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int cb = cb0 + 16 * c;
+            if (cb >= p.Cout) continue;
+            const float4 gv = g[c][q], y4 = yv[c];
+            *reinterpret_cast<float4*>(out + pix * p.Cout + cb) =
+                make_float4(rr * (gv.x - y4.x * mean) * (y4.x > 0.f ? 1.f : p.mask_slope), rr * (gv.y - y4.y * mean) * (y4.y > 0.f ? 1.f : p.mask_slope),
+                            rr * (gv.z - y4.z * mean) * (y4.z > 0.f ? 1.f : p.mask_slope), rr * (gv.w - y4.w * mean) * (y4.w > 0.f ? 1.f : p.mask_slope));
+        }
     }
 }
 
@@ -593,6 +667,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
     for (int k0 = KC; k0 < p.Cin; k0 += KC) chunk(k0, std::false_type{});
     if (p.pn_r) {                                             // (workgroup-uniform; the host launches ncob == 1 then)
         wino_epilogue_pixelnorm<NCB>(p, acc, 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
+    } else if (p.pnb_y) {
+        wino_epilogue_pnbwd<NCB>(p, acc, 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
     } else {
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
@@ -706,7 +782,8 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
               float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
               float* yup, const float* upmask, float up_mul,
               int N, int H, int W, int Cin, int Cout, int ups,
-              float scale, float slope, float mask_slope, float* pn_r, float pn_eps, pg_stream_t stream)
+              float scale, float slope, float mask_slope, float* pn_r, float pn_eps, pg_stream_t stream,
+              const float* pnb_y = nullptr, const float* pnb_r = nullptr)
 {
     if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
     if ((Cin & 7) || (Cout & 3)) return PG_E_ALIGN;         // 8-channel packs of U, four couts per lane
@@ -735,6 +812,8 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
     p.yup = yup; p.upmask = upmask; p.up_mul = up_mul;
     p.pn_r = pn_r; p.pn_eps = pn_eps;
     if (pn_r && (Cout > 32 || mask || ypool || yup || flags != ups || (g_wino_vec != 0 && g_wino_vec < 10))) return PG_E_UNSUP;
+    p.pnb_y = pnb_y; p.pnb_r = pnb_r;
+    if (pnb_y && (!pnb_r || pn_r || Cout > 32 || mask || yup || flags != 0 || (g_wino_vec != 0 && g_wino_vec < 10))) return PG_E_UNSUP;
     const int tilesW = W >> 1, tilesH = H >> 1;
     int TTW = tilesW < 8 ? tilesW : 8;
     int TTH = 64 / TTW; if (TTH > tilesH) TTH = tilesH;
@@ -755,7 +834,7 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
         // when that still leaves at least two workgroups per CU
         int ncb = vec >= 10 ? vec - 10 : ((Cin >= 512 && (long long)ntb * ((Cout + 31) / 32) >= 768) ? 2 : 1);   // measured: tools/sweep_wino.py
         if (ncb != 1 && ncb != 2) return PG_E_ARG;
-        if (pn_r) ncb = Cout > 16 ? 2 : 1;                    // PixelNorm epilogue: all couts of a pixel in one workgroup
+        if (pn_r || pnb_y) ncb = Cout > 16 ? 2 : 1;           // PixelNorm epilogue / adjoint: all couts of a pixel in one workgroup
         // Staging the input region 16 channels at a time (XK = 2: every activation line comes from L2 twice instead of four times)
         // costs a third workgroup per CU (74 KB of LDS) and measured SLOWER on every layer of the 1024^2 step but 512->512 @16
         // (n9 @256 32->64: 137 -> 170 us, step 13.8 -> 14.6 ms): PG_WINO_XK=2 keeps it reachable for sweeps.  Issuing the copies
@@ -822,4 +901,14 @@ extern "C" int pg_conv2d_wino_pixelnorm_nhwc(const float* x, const float* u, con
     if (!r) return PG_E_ARG;
     return wino_conv(x, u, bias, nullptr, y, nullptr, nullptr, 1.f, 0.f, 0, nullptr, nullptr, 1.f,
                      N, H, W, Cin, Cout, ups ? PG_FLAG_UPSAMPLE : 0, scale, slope, 0.2f, r, eps, stream);
+}
+
+extern "C" int pg_conv2d_wino_pnbwd_nhwc(const float* x, const float* u, const float* ysaved, const float* r, float* y,
+                                         int pool, const float* pool_other, float pool_a, float pool_b,
+                                         int N, int H, int W, int Cin, int Cout, float scale, float slope, pg_stream_t stream)
+{
+    if (!ysaved || !r) return PG_E_ARG;
+    if (pool && ((H | W) & 1)) return PG_E_ARG;
+    return wino_conv(x, u, nullptr, nullptr, y, pool ? y : nullptr, pool ? pool_other : nullptr, pool_a, pool_b, pool ? 1 : 0, nullptr, nullptr, 1.f,
+                     N, H, W, Cin, Cout, 0, scale, 1.f, slope, nullptr, 0.f, stream, ysaved, r);
 }

@@ -349,10 +349,13 @@ __global__ __launch_bounds__(256) void torgb_bwd_data_narrow_kernel(
 }
 
 // thread -> pixel variant for 8 features (see fromrgb_fwd_pix_kernel).
-template <int CI>
+// PNB: the adjoint of the block's (LeakyReLU -> PixelNorm) on top (network.py:44-52 after :32-41): the thread holds all CI
+// features of its pixel, so  gx = r * (gh - y * mean_c(gh * y)) * lrelu'(y)  needs no second pass over the 1024^2 map.
+template <int CI, bool PNB = false>
 __global__ __launch_bounds__(256) void torgb_bwd_data_pix_kernel(
     const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ gx,
-    int N, int C, int H, int W, int down, float mul_scale)
+    int N, int C, int H, int W, int down, float mul_scale,
+    const float* __restrict__ pnb_y = nullptr, const float* __restrict__ pnb_r = nullptr, float slope = 1.f)
 {
     const unsigned total = (unsigned)N * H * W, HW = (unsigned)H * W;
     for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < total; pix += gridDim.x * 256u) {
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(256) void torgb_bwd_data_pix_kernel(
         float gv[MAXC];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) gv[c] = c < C ? g_fetch(g, (int)n, c, h, wv, C, H, W, down) : 0.f;
+        float4 ov[CI / 4];
 #pragma unroll
         for (int c4 = 0; c4 < CI / 4; ++c4) {
             float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -370,9 +374,26 @@ __global__ __launch_bounds__(256) void torgb_bwd_data_pix_kernel(
                 o[0] = fmaf(gv[c], wv4.x, o[0]); o[1] = fmaf(gv[c], wv4.y, o[1]);
                 o[2] = fmaf(gv[c], wv4.z, o[2]); o[3] = fmaf(gv[c], wv4.w, o[3]);
             }
-            *reinterpret_cast<float4*>(gx + (size_t)pix * CI + 4 * c4) =
-                make_float4(o[0] * mul_scale, o[1] * mul_scale, o[2] * mul_scale, o[3] * mul_scale);
+            ov[c4] = make_float4(o[0] * mul_scale, o[1] * mul_scale, o[2] * mul_scale, o[3] * mul_scale);
         }
+        if (PNB) {
+            float4 yv[CI / 4];
+            float dot = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < CI / 4; ++c4) {
+                yv[c4] = *reinterpret_cast<const float4*>(pnb_y + (size_t)pix * CI + 4 * c4);
+                dot += (ov[c4].x * yv[c4].x + ov[c4].y * yv[c4].y) + (ov[c4].z * yv[c4].z + ov[c4].w * yv[c4].w);
+            }
+            const float rr = pnb_r[pix], mean = dot / (float)CI;
+#pragma unroll
+            for (int c4 = 0; c4 < CI / 4; ++c4) {
+                const float4 gq = ov[c4], y4 = yv[c4];
+                ov[c4] = make_float4(rr * (gq.x - y4.x * mean) * (y4.x > 0.f ? 1.f : slope), rr * (gq.y - y4.y * mean) * (y4.y > 0.f ? 1.f : slope),
+                                     rr * (gq.z - y4.z * mean) * (y4.z > 0.f ? 1.f : slope), rr * (gq.w - y4.w * mean) * (y4.w > 0.f ? 1.f : slope));
+            }
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < CI / 4; ++c4) *reinterpret_cast<float4*>(gx + (size_t)pix * CI + 4 * c4) = ov[c4];
     }
 }
 
@@ -688,7 +709,7 @@ extern "C" int pg_torgb_bwd_data(const float* g, const float* w, float* gx,
     const size_t npix = (size_t)N * H * W;
     if (npix >= 65536 && npix < (1ull << 29) && (Cin == 8 || Cin == 16 || Cin == 32)) {      // measured: tools/bench_rgb_stream.py
         hipStream_t s = (hipStream_t)stream;
-        if (Cin == 8) hipLaunchKernelGGL(torgb_bwd_data_pix_kernel<8>, dim3(grid_for(npix, 256, 256 * 16)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale);
+        if (Cin == 8) hipLaunchKernelGGL((torgb_bwd_data_pix_kernel<8, false>), dim3(grid_for(npix, 256, 256 * 16)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale, (const float*)nullptr, (const float*)nullptr, 1.f);
         else if (Cin == 16) hipLaunchKernelGGL(torgb_bwd_data_narrow_kernel<16>, dim3(grid_for(npix * 4, 256, 256 * 32)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale);
         else hipLaunchKernelGGL(torgb_bwd_data_narrow_kernel<32>, dim3(grid_for(npix * 8, 256, 256 * 32)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale);
         return (int)hipGetLastError();
@@ -696,6 +717,20 @@ extern "C" int pg_torgb_bwd_data(const float* g, const float* w, float* gx,
     const size_t total = npix * (Cin >> 2);
     hipLaunchKernelGGL(torgb_bwd_data_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        g, w, gx, N, C, H, W, Cin, down, mul_scale);
+    return (int)hipGetLastError();
+}
+
+// pg_torgb_bwd_data followed by the adjoint of the block's (LeakyReLU -> PixelNorm) in the same launch; 8 features on >= 256 x 256 maps
+// (the 1024^2 stage of the default widths), PG_E_UNSUP otherwise (the caller runs pg_torgb_bwd_data + pg_pixelnorm_lrelu_bwd).
+extern "C" int pg_torgb_bwd_data_pnbwd(const float* g, const float* w, const float* ysaved, const float* r, float* gx,
+                                       int N, int C, int H, int W, int Cin, float mul_scale, float slope, pg_stream_t stream)
+{
+    if (!g || !w || !gx || !ysaved || !r || N <= 0) return PG_E_ARG;
+    if (C < 1 || C > MAXC) return PG_E_UNSUP;
+    const size_t npix = (size_t)N * H * W;
+    if (Cin != 8 || npix < 65536 || npix >= (1ull << 29)) return PG_E_UNSUP;
+    hipLaunchKernelGGL((torgb_bwd_data_pix_kernel<8, true>), dim3(grid_for(npix, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       g, w, gx, N, C, H, W, 0, mul_scale, ysaved, r, slope);
     return (int)hipGetLastError();
 }
 

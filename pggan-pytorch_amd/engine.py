@@ -192,9 +192,15 @@ def _dgrad(net, gz, layer, N, Hout, mask=None, mask_slope=0.2):
     return run(mask)
 
 
-def _dgrad_pool(net, gz, layer, N, H, other=None, a=1.0, b=0.0):
-    """Backward-data conv + 2x2 pooled epilogue (a * mean + b * other); only the pooled result is produced."""
+def _dgrad_pool(net, gz, layer, N, H, other=None, a=1.0, b=0.0, pnb=None):
+    """Backward-data conv + 2x2 pooled epilogue (a * mean + b * other); only the pooled result is produced.
+    ``pnb`` = (ysaved, r, slope): the adjoint of the coarser block's last (LeakyReLU -> PixelNorm) follows -- in the same launch
+    where the Winograd epilogue holds every channel of the pooled pixel.  Returns (result, adjoint applied?)."""
     u = _wino(layer, N, H, layer.conv.weight.shape[3], transposed=True)
+    if pnb is not None:
+        if u is not None and u.shape[1] <= 32 and pnb[1] is not None:
+            return ops.conv2d_wino_pnbwd(gz, u, pnb[0], pnb[1], N, H, H, layer.c, pnb[2], pool=True, other=other, a=a, b=b), True
+        return _dgrad_pool(net, gz, layer, N, H, other=other, a=a, b=b), False
     if u is not None:
         return ops.conv2d_wino(gz, u, None, N, H, H, layer.c, 1.0, pool=True, other=other, a=a, b=b, pool_only=True)[1]
     return ops.conv2d_pool(gz, _wt(net, layer), None, N, H, H, layer.ksize, layer.ksize - 1 - layer.pad, layer.c, 1.0,
@@ -220,6 +226,8 @@ def _dgrad_unpool(net, gz, layer, N, H, upmask, mul, mask_slope):
 def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
     """Backward-data conv + adjoint of the previous layer's (LeakyReLU -> PixelNorm)."""
     u = _wino(layer, N, H, layer.conv.weight.shape[3], transposed=True)
+    if u is not None and u.shape[1] <= 32 and r is not None:      # every channel of a pixel in one workgroup: the adjoint in the Winograd epilogue
+        return ops.conv2d_wino_pnbwd(gz, u, ysaved, r, N, H, H, layer.c, slope)
     if u is not None:                              # wide layers: Winograd conv, then the (HBM-bound) adjoint kernel in place
         g = ops.conv2d_wino(gz, u, None, N, H, H, layer.c, 1.0)
         return ops.pixelnorm_lrelu_bwd(g, ysaved, r, slope, inplace=True)
@@ -436,6 +444,7 @@ def generator_backward(G, ctx, g_out):
     b0 = G.block0
     active = [b0.c1, b0.c2]
     g_extra = None
+    top_done = False
     if depth == 0:
         t = b0.toRGB
         with _on_side(g_out, ctx['y2']):
@@ -448,7 +457,12 @@ def generator_backward(G, ctx, g_out):
         t = rec['blk'].toRGB
         with _on_side(g_out, rec['a2']):
             ops.torgb_wgrad(g_out, rec['a2'], t._gw, t._gb, N, C, H, H, alpha * t.c, alpha)
-        g = ops.torgb_bwd_data(g_out, t.conv.weight.data, N, C, H, H, alpha * t.c)
+        # toRGB's adjoint + the adjoint of the top block's last (LeakyReLU -> PixelNorm) in one launch (network.py:138, :44-52)
+        if rec['r2'] is not None:
+            g = ops.torgb_bwd_data_pnbwd(g_out, t.conv.weight.data, rec['a2'], rec['r2'], N, C, H, H, alpha * t.c, rec['blk'].c2.slope)
+            top_done = True
+        else:                                         # (a generator built without PixelNorm: the adjoint is LeakyReLU' alone)
+            g = ops.torgb_bwd_data(g_out, t.conv.weight.data, N, C, H, H, alpha * t.c)
         active.append(t)
         if alpha < 1.0:
             pt = G.blocks[depth - 2].toRGB if depth > 1 else b0.toRGB
@@ -458,21 +472,28 @@ def generator_backward(G, ctx, g_out):
             g_extra = ops.torgb_bwd_data(g_out, pt.conv.weight.data, N, C, H // 2, H // 2, (1 - alpha) * pt.c, down=True)
             active.append(pt)
     _grads_ready(G, active[2:])
-    for rec in reversed(ctx['recs']):
+    recs = ctx['recs']
+    for k in range(len(recs) - 1, -1, -1):
+        rec = recs[k]
         blk, H = rec['blk'], rec['H']
         c1, c2 = blk.c1, blk.c2
-        gz2 = ops.pixelnorm_lrelu_bwd(g, rec['a2'], rec['r2'], c2.slope, inplace=True)
+        if top_done:                                  # (the top block's adjoint came with toRGB's)
+            gz2, top_done = g, False
+        else:
+            gz2 = ops.pixelnorm_lrelu_bwd(g, rec['a2'], rec['r2'], c2.slope, inplace=True)
         _wgrad(rec['a1'], gz2, c2, N, H)
         # backward-data conv of c2 + adjoint of c1's (LeakyReLU -> PixelNorm) in one launch
         gz1 = _dgrad_pnbwd(G, gz2, c2, N, H, rec['a1'], rec['r1'], c1.slope)
         _wgrad(rec['inp'], gz1, c1, N, H, ups=True)
         # backward-data conv of c1 + adjoint of the nearest x2 upsample (sum over 2x2 = 4 * average pool, exact in fp32)
         # + the fade-in branch's gradient, all in the conv epilogue
-        g = _dgrad_pool(G, gz1, c1, N, H, other=g_extra, a=4.0, b=1.0)
+        # ... and, where it fits, the adjoint of the coarser block's last (LeakyReLU -> PixelNorm) as well
+        prev = (recs[k - 1]['a2'], recs[k - 1]['r2'], recs[k - 1]['blk'].c2.slope) if k > 0 else (ctx['y2'], ctx['r2'], b0.c2.slope)
+        g, top_done = _dgrad_pool(G, gz1, c1, N, H, other=g_extra, a=4.0, b=1.0, pnb=prev)
         g_extra = None
         active += [c1, c2]
         _grads_ready(G, [c1, c2])
-    gz2 = ops.pixelnorm_lrelu_bwd(g, ctx['y2'], ctx['r2'], b0.c2.slope, inplace=True)
+    gz2 = g if top_done else ops.pixelnorm_lrelu_bwd(g, ctx['y2'], ctx['r2'], b0.c2.slope, inplace=True)
     _wgrad(ctx['y1'], gz2, b0.c2, N, 4)
     g1 = _dgrad(G, gz2, b0.c2, N, 4)
     gz1 = ops.pixelnorm_lrelu_bwd(g1, ctx['y1'], ctx['r1'], b0.c1.slope, inplace=True)

@@ -133,6 +133,16 @@ def conv2d_wino_pixelnorm(x, u, bias, N, H, W, scale, slope, eps=1e-8, ups=False
     return y, r
 
 
+def conv2d_wino_pnbwd(x, u, ysaved, r, N, H, W, scale, slope, pool=False, other=None, a=1.0, b=0.0):
+    """Backward-data conv on Winograd-domain weights (+ 2x2 pool blend a * pool + b * other) + the adjoint of the previous layer's
+    (LeakyReLU -> PixelNorm), one launch; at most 32 couts (ops.Unsupported otherwise)."""
+    cout, cin = u.shape[1], u.shape[2]
+    y = torch.empty((N, H // 2, W // 2, cout) if pool else (N, H, W, cout), device=x.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_wino_pnbwd_nhwc', _p(x), _p(u), _p(ysaved), _p(r), _p(y), 1 if pool else 0, _p(other), a, b,
+              N, H, W, cin, cout, scale, slope, _stream())
+    return y
+
+
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
                 pool_only=False, y_bytes=False):
     """conv2d with the following 2x2 average pool (+ fade-in blend a*pool + b*other) fused into the epilogue.
@@ -277,6 +287,17 @@ def torgb_bwd_data(g, w, N, C, H, W, mul_scale, down=False):
     gx = torch.empty((N, H, W, cin), device=g.device, dtype=torch.float32)
     _lib.call('pg_torgb_bwd_data', _p(g), _p(w), _p(gx), N, C, H, W, cin, 1 if down else 0, mul_scale, _stream())
     return gx
+
+
+def torgb_bwd_data_pnbwd(g, w, ysaved, r, N, C, H, W, mul_scale, slope):
+    """torgb_bwd_data + the adjoint of the block's (LeakyReLU -> PixelNorm), one launch where the kernel exists, two otherwise."""
+    cin = w.shape[1]
+    gx = torch.empty((N, H, W, cin), device=g.device, dtype=torch.float32)
+    try:
+        _lib.call('pg_torgb_bwd_data_pnbwd', _p(g), _p(w), _p(ysaved), _p(r), _p(gx), N, C, H, W, cin, mul_scale, slope, _stream())
+        return gx
+    except Unsupported:
+        return pixelnorm_lrelu_bwd(torgb_bwd_data(g, w, N, C, H, W, mul_scale), ysaved, r, slope, inplace=True)
 
 
 def torgb_wgrad(g, x, dw, db, N, C, H, W, mul_scale, mul, down=False):

@@ -152,6 +152,15 @@ def conv2d_wino_pixelnorm(x, u, bias, N, H, W, scale, slope, eps=1e-8, ups=False
     return pixelnorm_fwd(conv2d(x, _unwino(u), bias, N, H, W, 3, 1, scale, slope=slope, ups=ups), eps)
 
 
+def conv2d_wino_pnbwd(x, u, ysaved, r, N, H, W, scale, slope, pool=False, other=None, a=1.0, b=0.0):
+    if u.shape[1] > 32:
+        raise Unsupported('PixelNorm adjoint epilogue: at most 32 couts')
+    g = conv2d(x, _unwino(u), None, N, H, W, 3, 1, scale)
+    if pool:
+        g = avgpool2_fwd(g, other, a, b)
+    return pixelnorm_lrelu_bwd(g, ysaved, r, slope)
+
+
 def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_slope=0.2, other=None, a=1.0, b=0.0,
                 pool_only=False, y_bytes=False):
     y = conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=slope, mask=mask, mask_slope=mask_slope)
@@ -232,6 +241,10 @@ def torgb_fwd(x, w, bias, N, C, H, W, scale, out_mul=1.0, prev=None, prev_mul=0.
 def torgb_bwd_data(g, w, N, C, H, W, mul_scale, down=False):
     gg = F.avg_pool2d(g, 2) * 4 if down else g
     return (torch.einsum('nchw,ci->nhwi', gg, w) * mul_scale).contiguous()
+
+
+def torgb_bwd_data_pnbwd(g, w, ysaved, r, N, C, H, W, mul_scale, slope):
+    return pixelnorm_lrelu_bwd(torgb_bwd_data(g, w, N, C, H, W, mul_scale), ysaved, r, slope)
 
 
 def torgb_wgrad(g, x, dw, db, N, C, H, W, mul_scale, mul, down=False):

@@ -237,6 +237,9 @@ def test_torgb(N, C, H, ci):
     check('torgb blend', y, E.torgb_fwd(x, w, b, N, C, H, H, 0.7, out_mul=0.3, prev=prev, prev_mul=0.7))
     g = rnd(N, C, H, H, seed=4)
     check('torgb bwd_data', ops.torgb_bwd_data(dev(g), dev(w), N, C, H, H, 0.21), E.torgb_bwd_data(g, w, N, C, H, H, 0.21))
+    ys, rs = rnd(N, H, H, ci, seed=8), rnd(N * H * H, seed=9).abs() + 0.5        # fused (8 features, large maps) or two launches
+    check('torgb bwd_data + pn adjoint', ops.torgb_bwd_data_pnbwd(dev(g), dev(w), dev(ys), dev(rs), N, C, H, H, 0.21, 0.2),
+          E.torgb_bwd_data_pnbwd(g, w, ys, rs, N, C, H, H, 0.21, 0.2))
     g2 = rnd(N, C, 2 * H, 2 * H, seed=5)
     check('torgb bwd_data down', ops.torgb_bwd_data(dev(g2), dev(w), N, C, H, H, 0.21, down=True),
           E.torgb_bwd_data(g2, w, N, C, H, H, 0.21, down=True))

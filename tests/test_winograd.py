@@ -155,6 +155,29 @@ def test_conv2d_wino_pixelnorm_kernel(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 64, 16, 16), (2, 32, 64, 32), (1, 16, 32, 24), (5, 8, 16, 8), (3, 128, 32, 16), (1, 32, 128, 32)])
+@pytest.mark.parametrize('pool', [False, True])
+def test_conv2d_wino_pnbwd_kernel(case, pool):
+    """Backward-data conv (+ the pool that is the upsample's adjoint, + fade-in blend) + the adjoint of (LeakyReLU -> PixelNorm) in the
+    Winograd epilogue (pg_conv2d_wino_pnbwd_nhwc) against the torch restatement; couts 8 .. 32; > 32 couts refused."""
+    N, H, ci, co = case
+    ops = pg.ops
+    ho = H // 2 if pool else H
+    x, w = rnd(N, H, H, ci), rnd(3, 3, co, ci, seed=1) * 0.2
+    ys, rs, other = rnd(N, ho, ho, co, seed=2), rnd(N * ho * ho, seed=3).abs() + 0.5, rnd(N, ho, ho, co, seed=4)
+    u = ops.wino_transform_weights(w.cuda())
+    for oth in ((None, other) if pool else (None,)):
+        y = ops.conv2d_wino_pnbwd(x.cuda(), u, ys.cuda(), rs.cuda(), N, H, H, 0.37, 0.2, pool=pool,
+                                  other=None if oth is None else oth.cuda(), a=4.0, b=1.0 if oth is not None else 0.0)
+        ref = E.conv2d_wino_pnbwd(x, E.wino_transform_weights(w), ys, rs, N, H, H, 0.37, 0.2, pool=pool, other=oth, a=4.0,
+                                  b=1.0 if oth is not None else 0.0)
+        assert rel_err(y, ref) < 3e-5
+    wide = ops.wino_transform_weights(rnd(3, 3, 48, 16, seed=5).cuda())
+    with pytest.raises(ops.Unsupported):
+        ops.conv2d_wino_pnbwd(rnd(1, 16, 16, 16).cuda(), wide, rnd(1, 16, 16, 48).cuda(), rnd(256).cuda(), 1, 16, 16, 1.0, 0.2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', [(2, 16, 32, 32, 0), (3, 16, 64, 96, 0), (1, 32, 36, 48, 0), (9, 16, 128, 64, 0), (2, 64, 32, 64, 1),
                                   (5, 32, 8, 40, 1), (1, 128, 32, 32, 0), (7, 16, 100, 36, 0), (2, 16, 32, 32, 1),
                                   (2, 16, 16, 16, 0), (3, 32, 16, 32, 0), (2, 32, 32, 16, 1), (1, 64, 12, 20, 0), (3, 64, 8, 16, 0),
