@@ -429,8 +429,8 @@ def grow_run(pg, dp, n_gpus, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--prime', type=int, default=PRIME_STEPS, help='untimed setup steps before the warmup (see PRIME_STEPS)')
     ap.add_argument('--depth', type=int, default=8)
     ap.add_argument('--alpha', type=float, default=1.0)
