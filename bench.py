@@ -28,6 +28,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -119,7 +120,7 @@ class KernelTimer(object):
             e0.record()
             out = orig(*a, **k)
             e1.record()
-            sym = (lib.pg_debug_last_wino_kernel() if name in ('conv2d_wino', 'conv2d_wino_pixelnorm') else
+            sym = (lib.pg_debug_last_wino_kernel() if name in ('conv2d_wino', 'conv2d_wino_pixelnorm', 'conv2d_wino_pnbwd') else
                    lib.pg_debug_last_wino_wgrad_kernel() if name == 'conv2d_wgrad_wino' else
                    lib.pg_debug_last_conv_kernel()).decode()
             fl, tag = describe(a, k)
@@ -139,8 +140,10 @@ class KernelTimer(object):
             ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
             return (conv_flops(n, ho, wo, ks, pad, dw.shape[2], dw.shape[3]),
                     'wgrad %d->%d k%d @%d n%d' % (dw.shape[3], dw.shape[2], ks, ho, n))
-        def wino_wgrad_desc(a, k):    # conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=)
+        def wino_wgrad_desc(a, k):    # conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=, second=(x2, gz2, N2, bias2))
             dw, n, h = a[2], a[4], a[5]
+            if k.get('second') is not None:      # a second batch of the same layer rides in the launch: its FLOPs count too
+                n += k['second'][2]
             return (conv_flops(n, h, h, 3, 1, dw.shape[2], dw.shape[3]),
                     'wgrad %d->%d k3 @%d n%d winograd' % (dw.shape[3], dw.shape[2], h, n))
         def pool_desc(a, k):          # conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, ...): the conv of conv_desc + pooled output
@@ -160,9 +163,14 @@ class KernelTimer(object):
         def wino_pn_desc(a, k):       # conv2d_wino_pixelnorm(x, u, bias, N, H, W, scale, slope, eps, ups=)
             fl, tag = wino_desc(a, {})
             return fl, tag + ' +pixelnorm'
+        def wino_pnbwd_desc(a, k):    # conv2d_wino_pnbwd(x, u, ysaved, r, N, H, W, scale, slope, pool=, ...)
+            u, n, h = a[1], a[4], a[5]
+            return (conv_flops(n, h, h, 3, 1, u.shape[1], u.shape[2]),
+                    'conv %d->%d k3 @%d n%d winograd +pn adjoint%s' % (u.shape[2], u.shape[1], h, n, ' +pool' if k.get('pool') else ''))
         self._wrap('conv2d', conv_desc)
         self._wrap('conv2d_wino', wino_desc)
         self._wrap('conv2d_wino_pixelnorm', wino_pn_desc)
+        self._wrap('conv2d_wino_pnbwd', wino_pnbwd_desc)
         self._wrap('conv2d_pool', pool_desc)
         self._wrap('conv2d_pixelnorm', generic(1, 3, '+pixelnorm'))
         self._wrap('conv2d_unpool', generic(1, 2, '+unpool'))
@@ -627,10 +635,26 @@ def main():
         out['configs'] = sec
 
     if rank == 0:
-        if not args.no_cpu and n_gpus == 1 and args.config == 5:
-            out['cpu_baseline'] = cpu_baseline(depth, mb)
-        else:
+        # The CPU baseline is a property of the host, measured once at N = 1 (rank 0's cores all to itself).  At N > 1 the
+        # line repeats that measurement when an N = 1 run of this box left it behind (the driver runs N = 1, 2, 4, 8 back to
+        # back); otherwise rank 0 measures it now, after the timed region, while the other ranks wait at the closing barrier.
+        cache = os.path.join(tempfile.gettempdir(), 'pggan_cpu_baseline_d%d_mb%d.json' % (depth, mb))
+        if args.no_cpu or args.config != 5:
             out['cpu_baseline'] = None
+        elif n_gpus == 1:
+            out['cpu_baseline'] = cpu_baseline(depth, mb)
+            try:
+                with open(cache, 'w') as f:
+                    json.dump(out['cpu_baseline'], f)
+            except OSError:
+                pass
+        else:
+            try:
+                with open(cache) as f:
+                    out['cpu_baseline'] = dict(json.load(f), measured_at_n_gpus=1, source='the N=1 run of this box (%s)' % cache)
+            except (OSError, ValueError):
+                out['cpu_baseline'] = dict(cpu_baseline(depth, mb), measured_at_n_gpus=n_gpus,
+                                           source='rank 0 after the timed region, the other ranks idle at the barrier')
     if dp is not None:
         dp.barrier()
         dp.close()

@@ -354,6 +354,16 @@ int pg_image_grid_u8(const float* img, uint8_t* grid, int n, int C, int h, int w
  *   pg_minmax_f32 + pg_stretch_to_u8: np.uint8(adjust_dynamic_range(s, (s.min(), s.max()), (0, max_out))) dataset.py:299. */
 int pg_stft_abslog(const float* y, int64_t nsamp, int channels, float* out, int n_fft, int hop_length,
                    int bins, int frames, pg_stream_t stream);
+/*   pg_stft_image: the same with the image mode as an argument: PG_SOUND_ABSLOG (dataset.py:296, = pg_stft_abslog) or
+ *       PG_SOUND_REALLOG log(1 + |Re s|) * sign(s) (dataset.py:298; sign of a complex number as in the reference's numpy 1.13:
+ *       the sign of the real part, of the imaginary part where the real part is zero — the image is real).
+ *   pg_mono_f32: img_mode 'raw' (dataset.py:287-291): out[i] = mono mix-down of sample i, i < count ((2^size)^2 samples,
+ *       reshaped by the caller); followed by the same min/max stretch. */
+#define PG_SOUND_ABSLOG 0
+#define PG_SOUND_REALLOG 1
+int pg_stft_image(const float* y, int64_t nsamp, int channels, float* out, int n_fft, int hop_length,
+                  int bins, int frames, int mode, pg_stream_t stream);
+int pg_mono_f32(const float* y, int64_t nsamp, int channels, float* out, int64_t count, pg_stream_t stream);
 int pg_minmax_f32(const float* x, int64_t n, float* lohi, pg_stream_t stream);
 int pg_stretch_to_u8(const float* x, uint8_t* out, int64_t n, const float* lohi, float max_out, pg_stream_t stream);
 

@@ -53,7 +53,8 @@ def istft(S, hop_length):
 
 def spectrogram_image(signal, n_fft, hop_length, img_mode='abslog', range_in=(0, 255)):
     """SoundImageDataset.load_file, reference dataset.py:285-300 (after the file read): mono mix-down, STFT, crop to
-    n_fft/2 x n_fft/2, log(1 + |s|), stretch [min, max] -> range_in, np.uint8 (truncation).  Returns [1, n_fft/2, n_fft/2]."""
+    n_fft/2 x n_fft/2, log(1 + |s|) ('abslog') or signed log of the real part ('reallog'), stretch [min, max] -> range_in,
+    np.uint8 (truncation) -> [1, n_fft/2, n_fft/2]; 'raw': the leading (2^k)^2 samples as a square image."""
     s = np.asarray(signal, dtype=np.float32)
     if s.ndim == 2:                                                       # :287-288 stereo to mono
         s = s.sum(axis=1) / 2
@@ -66,7 +67,12 @@ def spectrogram_image(signal, n_fft, hop_length, img_mode='abslog', range_in=(0,
         if img_mode == 'abslog':
             s = np.log(1 + np.abs(s))                                     # :296
         else:
-            raise NotImplementedError("img_mode 'reallog' applies np.sign to a complex array (dataset.py:298): not restated")
+            # :298 np.log(1 + np.abs(s.real)) * np.sign(s).  The reference pins numpy 1.13 (requirements.txt:2), whose sign of
+            # a complex number is sign(real) + 0j (sign(imag) where real == 0) -- NOT numpy >= 2's z / |z| of this image.  The
+            # product, min/max (lexicographic, imaginary parts all zero) and the stretch are then real arithmetic in float32
+            # and np.uint8 of the complex result keeps the real part: restated directly on the real part.
+            sg = np.where(s.real != 0, np.sign(s.real), np.sign(s.imag)).astype(np.float32)
+            s = (np.log(1 + np.abs(s.real)) * sg).astype(np.float32)
     s = np.uint8(adjust_dynamic_range(s, (s.min(), s.max()), range_in))   # :299
     return s[np.newaxis]
 
@@ -82,12 +88,17 @@ def griffin_lim(stft_mag, hop_length, n_iter, rng):
 
 
 def image_to_sound(image, mode, drange, hop_length, n_iter, rng):
-    """SoundSaver.image_to_sound, reference output_postprocess.py:124-145 ('abslog' and 'raw')."""
+    """SoundSaver.image_to_sound, reference output_postprocess.py:124-145."""
     if mode == 'abslog':
         x = np.zeros((image.shape[0] + 1, image.shape[1]))                # :126
         x[:image.shape[0], :image.shape[1]] = image                      # :128
         x = adjust_dynamic_range(x, drange, (0, 255))                     # :135
         signal = griffin_lim(x, hop_length, n_iter, rng)                  # :136
+    elif mode == 'reallog':
+        x = np.zeros((image.shape[0] + 1, image.shape[1]))                # :126
+        x[:image.shape[0], :image.shape[1]] = image
+        signed = adjust_dynamic_range(x, drange, (-1, 1))                 # :130
+        signal = istft((np.exp(np.abs(signed)) - 1) * np.sign(signed), hop_length)   # :131-133
     elif mode == 'raw':
         signal = image.ravel()                                            # :138
     else:

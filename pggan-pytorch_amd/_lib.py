@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class PgganLibraryError(RuntimeError):
@@ -75,6 +75,8 @@ SIGNATURES = {
     'pg_pyramid_level_u8': [P, P, L, I, I, I, F, F, P],
     'pg_zero': [P, L, P],
     'pg_stft_abslog': [P, L, I, P, I, I, I, I, P],
+    'pg_stft_image': [P, L, I, P, I, I, I, I, I, P],
+    'pg_mono_f32': [P, L, I, P, L, P],
     'pg_minmax_f32': [P, L, P, P],
     'pg_stretch_to_u8': [P, P, L, P, F, P],
     # gradient exchange (RCCL bound at run time inside the library)

@@ -26,10 +26,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include <cstdio>
 
-#ifndef PG_EXP
-#define PG_EXP 0
-#endif
-
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
@@ -78,12 +74,9 @@ __device__ __forceinline__ unsigned char pg_sign_byte(float4 o)
     return (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
 }
 
-#ifndef PG_KCP4
-#define PG_KCP4 24
-#endif
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
 //   VEC=4 (ds_read_b128, 4x16 lanes, 64 banks): 24   VEC=2 (ds_read_b64): 12   VEC=1: 8
-template <int VEC> struct RowStride { static constexpr int value = VEC == 4 ? PG_KCP4 : (VEC == 2 ? 12 : 8); };
+template <int VEC> struct RowStride { static constexpr int value = VEC == 4 ? 24 : (VEC == 2 ? 12 : 8); };
 
 // Upper bound of the halo pixels of one tile (sizes the register prefetch): KS=3 with TH,TW >= 4 needs at most
 // 2.25*BPX; tiles of >= 512 pixels are always 32 wide (make_geom), so (BPX/32+2)*34 is exact there.
@@ -192,22 +185,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 
     if (kc_begin < kc_end) fetch(kc_begin);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
-#if PG_EXP >= 3
-        if (kc == kc_begin) {
-#endif
 #pragma unroll
         for (int i = 0; i < WPT; ++i) if (wdst[i] >= 0) *reinterpret_cast<float4*>(wt + wdst[i]) = wreg[i];
 #pragma unroll
         for (int i = 0; i < XPT; ++i) if (xdst[i] >= 0) *reinterpret_cast<float4*>(xt + xdst[i]) = xreg[i];
-#if PG_EXP >= 3
-        }
-#endif
-#if PG_EXP != 1
         __syncthreads();
-#endif
-#if PG_EXP != 2 && PG_EXP < 3
         if (kc + 1 < kc_end) fetch(kc + 1);              // in flight while the MFMAs below run
-#endif
 
         float a[2][WM][VEC], b[2][WN][VEC];
 #pragma unroll
@@ -217,13 +200,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) {
             const int cur = tp & 1, nxt = cur ^ 1;
-#if PG_EXP == 4
-            if (tp + 1 < TAPS && tp < 1) {
-#elif PG_EXP == 5
-            if (tp + 1 < TAPS && (tp & 1)) {
-#else
             if (tp + 1 < TAPS) {
-#endif
 #pragma unroll
                 for (int m = 0; m < WM; ++m) lds_load<VEC>(wt + (tp + 1) * BCO * KCP + wbase[m], a[nxt][m]);
 #pragma unroll
@@ -248,9 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#if PG_EXP != 1
         __syncthreads();
-#endif
     }
     if constexpr (WM * WN == 1 && VEC > 1) acc[0][0] += acc_odd;
 

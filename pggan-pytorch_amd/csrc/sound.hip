@@ -20,8 +20,12 @@ namespace {
 
 constexpr int STFT_MAX_N = 2048;
 
-__global__ __launch_bounds__(256) void stft_abslog_kernel(const float* __restrict__ y, long long nsamp, int channels,
-                                                          float* __restrict__ out, int n_fft, int hop, int bins, int frames)
+// MODE 0: 'abslog' log(1 + |s|) (dataset.py:296); MODE 1: 'reallog' log(1 + |Re s|) * sign(s) (dataset.py:298) with the
+// reference's numpy (1.13, requirements.txt:2), whose sign of a complex number is the sign of its real part (of the imaginary
+// part when the real part is zero) + 0j: the image is real-valued, np.uint8 drops the zero imaginary part.
+template <int MODE>
+__global__ __launch_bounds__(256) void stft_image_kernel(const float* __restrict__ y, long long nsamp, int channels,
+                                                         float* __restrict__ out, int n_fft, int hop, int bins, int frames)
 {
     __shared__ double frame[STFT_MAX_N];
     __shared__ double twc[STFT_MAX_N], tws[STFT_MAX_N];
@@ -54,7 +58,21 @@ __global__ __launch_bounds__(256) void stft_abslog_kernel(const float* __restric
         }
         // librosa returns complex64; |.| and log(1 + .) then run in float32 (numpy keeps the dtype)
         const float fr = (float)re, fi = (float)im;
-        out[(size_t)k * frames + t] = logf(1.0f + hypotf(fr, fi));
+        if (MODE == 0) out[(size_t)k * frames + t] = logf(1.0f + hypotf(fr, fi));
+        else {
+            const float sg = fr > 0.f ? 1.f : fr < 0.f ? -1.f : fi > 0.f ? 1.f : fi < 0.f ? -1.f : 0.f;
+            out[(size_t)k * frames + t] = logf(1.0f + fabsf(fr)) * sg;
+        }
+    }
+}
+
+// 'raw' image mode (dataset.py:287-291): the mono mix-down alone, count = (2^size)^2 leading samples
+__global__ __launch_bounds__(256) void mono_kernel(const float* __restrict__ y, int channels, float* __restrict__ out, long long count)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < channels; ++c) acc += y[i * channels + c];
+        out[i] = channels > 1 ? acc / 2.0f : acc;
     }
 }
 
@@ -89,15 +107,34 @@ __global__ __launch_bounds__(256) void stretch_u8_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int pg_stft_abslog(const float* y, int64_t nsamp, int channels, float* out, int n_fft, int hop_length,
-                              int bins, int frames, pg_stream_t stream)
+extern "C" int pg_stft_image(const float* y, int64_t nsamp, int channels, float* out, int n_fft, int hop_length,
+                             int bins, int frames, int mode, pg_stream_t stream)
 {
     if (!y || !out || nsamp <= 0 || channels <= 0 || hop_length <= 0 || bins <= 0 || frames <= 0) return PG_E_ARG;
     if (n_fft < 4 || n_fft > STFT_MAX_N || (n_fft & (n_fft - 1))) return PG_E_UNSUP;
     if (bins > n_fft / 2 + 1 || nsamp <= n_fft / 2) return PG_E_ARG;     // reflect padding needs more samples than the pad
     if ((int64_t)(frames - 1) * hop_length > nsamp) return PG_E_ARG;       // frame t needs t*hop + n_fft <= nsamp + n_fft
-    hipLaunchKernelGGL(stft_abslog_kernel, dim3(frames), dim3(256), 0, (hipStream_t)stream, y, (long long)nsamp, channels, out,
-                       n_fft, hop_length, bins, frames);
+    if (mode == PG_SOUND_ABSLOG)
+        hipLaunchKernelGGL(stft_image_kernel<0>, dim3(frames), dim3(256), 0, (hipStream_t)stream, y, (long long)nsamp, channels, out,
+                           n_fft, hop_length, bins, frames);
+    else if (mode == PG_SOUND_REALLOG)
+        hipLaunchKernelGGL(stft_image_kernel<1>, dim3(frames), dim3(256), 0, (hipStream_t)stream, y, (long long)nsamp, channels, out,
+                           n_fft, hop_length, bins, frames);
+    else return PG_E_ARG;
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_stft_abslog(const float* y, int64_t nsamp, int channels, float* out, int n_fft, int hop_length,
+                              int bins, int frames, pg_stream_t stream)
+{
+    return pg_stft_image(y, nsamp, channels, out, n_fft, hop_length, bins, frames, PG_SOUND_ABSLOG, stream);
+}
+
+extern "C" int pg_mono_f32(const float* y, int64_t nsamp, int channels, float* out, int64_t count, pg_stream_t stream)
+{
+    if (!y || !out || channels <= 0 || count <= 0 || count > nsamp) return PG_E_ARG;
+    int64_t g = (count + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(mono_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, y, channels, out, (long long)count);
     return (int)hipGetLastError();
 }
 

@@ -93,11 +93,20 @@ def _derived(net):
         ops.wino_transform_weights_batched(net._flat_wt, net._flat_wtu,
                                            [(woff, uoff, m.conv.weight.shape[3], m.conv.weight.shape[2]) for m, woff, uoff in wl])
     net._derived_ver = key
+    net._derived_live = live
+
+
+def _assert_live(net, layer):
+    """The derived copies are refreshed for the layers that are live at the network's current growth stage only: asking for
+    any other layer's would silently compute with the weights of an earlier optimizer step."""
+    if id(layer) not in net._derived_live:
+        raise RuntimeError('derived weights requested for a conv layer that is not live at depth %d' % int(net.depth))
 
 
 def _wt(net, layer):
     """Backward-data (flipped/transposed) copy of a conv layer's weights, refreshed lazily."""
     _derived(net)
+    _assert_live(net, layer)
     return layer._wt
 
 
@@ -115,6 +124,7 @@ def _wino(layer, N, H, cout, transposed=False):
         layer._wino_wanted = True
         net._derived_ver = None
     _derived(net)
+    _assert_live(net, layer)
     return layer._wtu if transposed else layer._wu
 
 
@@ -313,6 +323,9 @@ def _grads_ready(net, layers):
     buffer can start travelling while the sweep goes on."""
     hook = getattr(net, '_grad_hook', None)
     if hook is not None:
+        for m in layers:                         # "complete" must never precede a deferred contribution that nothing carried
+            if m.__dict__.get('_pending_wgrad') is not None:
+                _flush_wgrad(m)
         side = None
         if ASYNC_WGRAD and net._flat_param.is_cuda:
             side = _SIDE.get(torch.cuda.current_device())
@@ -652,6 +665,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                     gz1 = ops.conv2d_unpooled(gc, _wt(D, c2), gb, gmul, gsl, NB, H, H, c2.c,
                                               mask=rec.get('a1b') if rec.get('a1b') is not None else rec['a1'], mask_slope=c1.slope)
                     if full:
+                        _flush_wgrad(c2)           # (this launch does not go through _wgrad: a deferred tangent term rides nowhere)
                         with _on_side(rec['a1'], gc, gb):
                             ops.conv2d_wgrad_unpooled(rec['a1'], gc, gb, gmul, gsl, c2._gw, c2._gb, NB, H, H, c2.c)
                 except ops.Unsupported:                    # (shape checks are identical for both entry points: nothing was accumulated)

@@ -218,6 +218,7 @@ class _FlatParamsMixin(object):
     def _apply(self, fn, recurse=True):
         super(_FlatParamsMixin, self)._apply(fn, recurse)
         self._flatten()
+        self.__dict__['_plist'] = None
         return self
 
     def _ensure_buffers(self):
@@ -276,7 +277,10 @@ class _FlatParamsMixin(object):
 
     def _sync_version(self):
         """Also notice parameter updates done by torch itself (torch.optim.*, load_state_dict, ...)."""
-        v = sum(p._version for p in self.parameters())
+        plist = self.__dict__.get('_plist')
+        if plist is None:                        # (walking the module tree on every forward is host time the 4x4 .. 32x32 stages feel)
+            plist = self.__dict__['_plist'] = list(self.parameters())
+        v = sum(p._version for p in plist)
         if v != getattr(self, '_torch_versions_seen', None):
             self._torch_versions_seen = v
             self._param_version += 1
@@ -292,6 +296,7 @@ class _FlatParamsMixin(object):
         d['_skip_join'] = False
         d['_lin_gw'] = d['_lin_gb'] = d['_lin_layer'] = None
         d['_grad_hook'] = d['_grad_exchange'] = None
+        d['_plist'] = None
         return d
 
     def __setstate__(self, state):

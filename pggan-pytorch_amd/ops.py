@@ -483,19 +483,32 @@ def real_prepare_u8(x_u8, alpha, range_in=(0, 255), range_out=(-1, 1)):
     return out
 
 
-def spectrogram_u8(signal, n_fft, hop_length, max_out=255.0):
-    """fp32 device waveform [nsamp] or [nsamp, channels] -> uint8 'abslog' spectrogram image [1, n_fft/2, n_fft/2]
-    (SoundImageDataset.load_file, dataset.py:285-300)."""
+SOUND_MODES = {'abslog': 0, 'reallog': 1}
+
+
+def spectrogram_u8(signal, n_fft, hop_length, max_out=255.0, img_mode='abslog'):
+    """fp32 device waveform [nsamp] or [nsamp, channels] -> uint8 image (SoundImageDataset.load_file, dataset.py:285-300):
+    'abslog' / 'reallog' spectrogram [1, n_fft/2, n_fft/2], or 'raw' [1, 2^s, 2^s] with 2^s = the largest power of two
+    <= sqrt(nsamp) (dataset.py:289-291)."""
     require_gpu()
     if not signal.is_cuda or signal.dtype != torch.float32 or not signal.is_contiguous() or signal.dim() not in (1, 2):
         raise ValueError('expected a contiguous float32 device tensor [nsamp] or [nsamp, channels]')
     nsamp = signal.shape[0]
     ch = 1 if signal.dim() == 1 else signal.shape[1]
-    side = n_fft // 2
-    if 1 + nsamp // hop_length < side:
-        raise ValueError('%d samples give %d frames, the %dx%d image needs %d' % (nsamp, 1 + nsamp // hop_length, side, side, side))
-    mag = torch.empty((side, side), device=signal.device, dtype=torch.float32)
-    _lib.call('pg_stft_abslog', _p(signal), nsamp, ch, _p(mag), n_fft, hop_length, side, side, _stream())
+    if img_mode == 'raw':
+        side = 1
+        while (2 * side) * (2 * side) <= nsamp:
+            side *= 2
+        mag = torch.empty((side, side), device=signal.device, dtype=torch.float32)
+        _lib.call('pg_mono_f32', _p(signal), nsamp, ch, _p(mag), side * side, _stream())
+    else:
+        if img_mode not in SOUND_MODES:
+            raise ValueError("img_mode must be 'abslog', 'reallog' or 'raw' (got %r)" % (img_mode,))
+        side = n_fft // 2
+        if 1 + nsamp // hop_length < side:
+            raise ValueError('%d samples give %d frames, the %dx%d image needs %d' % (nsamp, 1 + nsamp // hop_length, side, side, side))
+        mag = torch.empty((side, side), device=signal.device, dtype=torch.float32)
+        _lib.call('pg_stft_image', _p(signal), nsamp, ch, _p(mag), n_fft, hop_length, side, side, SOUND_MODES[img_mode], _stream())
     lohi = torch.empty(2, device=signal.device, dtype=torch.float32)
     _lib.call('pg_minmax_f32', _p(mag), mag.numel(), _p(lohi), _stream())
     out = torch.empty((1, side, side), device=signal.device, dtype=torch.uint8)

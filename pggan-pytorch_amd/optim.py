@@ -31,6 +31,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = grad_scale          # 1/world_size when gradients were SUM-all-reduced
         self._nets = []                       # networks whose derived (backward-data) weight copies go stale
         self._flat = {}                       # id(group) -> (base_ptr, m_flat, v_flat)
+        self._probe = {}                      # id(group) -> (address of the group's first parameter, number of parameters) at the last check
 
     def attach(self, *nets):
         self._nets.extend(nets)
@@ -38,7 +39,12 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _flat_state(self, gi, group):
         params = group['params']
+        probe = params[0].data_ptr()              # a re-flatten moves every parameter: the first one's address tells
+        hit = self._probe.get(gi)
+        if hit is not None and hit[0] == probe and len(params) == hit[1] and gi in self._flat:
+            return self._flat[gi]
         base = min(p.data_ptr() for p in params)
+        self._probe[gi] = (probe, len(params))
         if gi in self._flat:
             if self._flat[gi][0] == base:
                 return self._flat[gi]
@@ -85,6 +91,7 @@ class FusedAdam(torch.optim.Optimizer):
         plugins.py:142-174; this is the 'next row' checkpoint extension of SURVEY.md §8f.)"""
         super(FusedAdam, self).load_state_dict(state_dict)
         self._flat = {}
+        self._probe = {}
         for gi, group in enumerate(self.param_groups):
             base, mflat, vflat = self._flat_state(gi, group)
             for p in group['params']:

@@ -74,9 +74,9 @@ class DepthManager(Plugin):
         self.trainer = trainer
         stats = trainer.stats
         stats['minibatch_size'] = self.minibatch_default
-        stats['alpha'] = dict(log_name='alpha', log_epoch_fields=_STAT_FMT, val=self.alpha)
+        stats['alpha'] = dict(log_name='alpha', log_epoch_fields=list(_STAT_FMT), val=self.alpha)
         if self._reports_lod:
-            stats['lod'] = dict(log_name='lod', log_epoch_fields=_STAT_FMT, val=self.lod)
+            stats['lod'] = dict(log_name='lod', log_epoch_fields=list(_STAT_FMT), val=self.lod)
         self.iteration()                                             # stage 0 is applied before the first step
 
     def _enter_stage(self, depth):

@@ -21,18 +21,19 @@ from .utils import adjust_dynamic_range
 
 
 def spectrogram_u8(signal, n_fft=1024, hop_length=128, img_mode='abslog', range_in=(0, 255)):
-    """Waveform (numpy array or tensor, ``[nsamp]`` or ``[nsamp, channels]``) -> uint8 device image ``[1, n_fft/2, n_fft/2]``.
-    Defaults as SoundImageDataset.__init__ (dataset.py:259-274); only the STFT image modes the benchmarked configuration
-    uses ('abslog') run on the device."""
+    """Waveform (numpy array or tensor, ``[nsamp]`` or ``[nsamp, channels]``) -> uint8 device image: ``[1, n_fft/2, n_fft/2]``
+    for the spectrogram modes 'abslog' (log(1 + |s|), dataset.py:296) and 'reallog' (log(1 + |Re s|) * sign(s), dataset.py:298,
+    with numpy 1.13's complex sign = the sign of the real part), ``[1, 2^k, 2^k]`` for 'raw' (the waveform itself, dataset.py:289-291).
+    Defaults as SoundImageDataset.__init__ (dataset.py:259-274)."""
     import torch
     from . import ops
-    if img_mode != 'abslog':
-        raise NotImplementedError("device spectrogram front-end: img_mode 'abslog' only (got %r)" % (img_mode,))
+    if img_mode not in ('abslog', 'reallog', 'raw'):
+        raise ValueError("img_mode must be one of 'abslog', 'reallog', 'raw' (got %r)" % (img_mode,))
     if range_in[0] != 0:
         raise NotImplementedError('range_in must start at 0 (uint8 images)')
     t = signal if torch.is_tensor(signal) else torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float32))
     t = t.to(device='cuda', dtype=torch.float32).contiguous()
-    return ops.spectrogram_u8(t, int(n_fft), int(hop_length), float(range_in[1]))
+    return ops.spectrogram_u8(t, int(n_fft), int(hop_length), float(range_in[1]), img_mode=img_mode)
 
 
 def _frames(y, n_fft, hop):
@@ -83,7 +84,7 @@ class SoundSaver(object):
             previous = x
             x = istft(stft_mag * np.exp(1.0j * phase), self.hop_length)
             if self.verbose:
-                print('MSE between sub- and ultimate iteration: {}'.format(np.sqrt(np.square(x - previous).sum())))
+                print('Griffin-Lim: change of the signal in this round (L2) = %g' % np.sqrt(np.square(x - previous).sum()))
         return x
 
     def image_to_sound(self, image):
@@ -99,7 +100,7 @@ class SoundSaver(object):
         elif self.mode == 'raw':
             signal = image.ravel()
         else:
-            raise Exception('image_to_sound: unrecognized mode: {}. Available modes are: reallog, abslog, raw.'.format(self.mode))
+            raise ValueError('SoundSaver mode %r is not one of abslog / reallog / raw' % (self.mode,))
         return signal / np.abs(signal).max()
 
     def output_wav(self, signal, samples_description, ith):
@@ -112,7 +113,7 @@ class SoundSaver(object):
             wavfile.write(os.path.join(self.samples_path, fname.format(samples_description, ith)), self.sample_rate, wav)
         except Exception as e:
             with open(os.path.join(self.samples_path, 'error_{}_{}.txt'.format(samples_description, ith)), 'w') as f:
-                f.write('Exception trying to save sound: {}'.format(e))
+                f.write('writing the WAV file failed: %r' % (e,))
 
     def __call__(self, output, samples_description):
         output = np.asarray(output.cpu().numpy() if hasattr(output, 'cpu') else output)

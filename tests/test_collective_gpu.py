@@ -1,0 +1,146 @@
+"""The gradient-exchange face of the C-ABI on the MI355X (include/pggan_hip.h: pg_rccl_version, pg_comm_unique_id,
+pg_comm_init_rank, pg_comm_info, pg_allreduce_sum_f32, pg_comm_destroy; csrc/collective.hip) and the product path on top of
+it (``parallel.DataParallel`` / ``GradExchange`` / ``Trainer(parallel=...)``).
+
+The reference is single-GPU: its exchange points are after /root/reference/trainer.py:98 (D) and :111 (G).  The GPU box has
+ONE device, so the communicator here has one rank: every collective is then the identity, which makes the checks exact —
+an all-reduce must leave a random buffer bit-identical, and a data-parallel Trainer must land on the weights of the plain one.
+(The two-rank arithmetic — shard sums, 1/world in Adam, per-rank minibatch accounting — is covered against the oracle by
+the world-size-2 gloo tests of tests/test_parallel_cpu.py.)"""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import pggan_amd as pg
+from pggan_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+PG_E_ARG = -1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.fixture(scope='module')
+def dp():
+    """One-rank data-parallel group: torch.distributed as the control plane, the library's own RCCL communicator as the data plane."""
+    import torch.distributed as dist
+    saved = {k: os.environ.get(k) for k in ('MASTER_ADDR', 'MASTER_PORT', 'RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', LOCAL_RANK='0', WORLD_SIZE='1')
+    d = pg.DataParallel.from_env(force=True)
+    yield d
+    d.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def test_rccl_is_bound_and_argument_errors():
+    lib = _lib.load()
+    v = ctypes.c_int(-1)
+    assert lib.pg_rccl_version(ctypes.byref(v)) == 0 and v.value > 0            # e.g. 22205: an RCCL really was resolved
+    assert lib.pg_rccl_version(None) == PG_E_ARG
+    assert lib.pg_comm_unique_id(None) == PG_E_ARG
+    ident = ctypes.create_string_buffer(128)
+    assert lib.pg_comm_unique_id(ident) == 0 and any(ident.raw)
+    comm = ctypes.c_void_p()
+    assert lib.pg_comm_init_rank(None, 1, ident, 0) == PG_E_ARG
+    assert lib.pg_comm_init_rank(ctypes.byref(comm), 0, ident, 0) == PG_E_ARG      # no ranks
+    assert lib.pg_comm_init_rank(ctypes.byref(comm), 1, ident, 1) == PG_E_ARG      # rank out of range
+    assert lib.pg_comm_init_rank(ctypes.byref(comm), 1, ident, -1) == PG_E_ARG
+    assert lib.pg_comm_init_rank(ctypes.byref(comm), 1, None, 0) == PG_E_ARG
+    n, r = ctypes.c_int(), ctypes.c_int()
+    assert lib.pg_comm_info(None, ctypes.byref(n), ctypes.byref(r)) == PG_E_ARG
+    assert lib.pg_comm_destroy(None) == PG_E_ARG
+    buf = torch.ones(16, device=DEV)
+    assert lib.pg_allreduce_sum_f32(None, ctypes.c_void_p(buf.data_ptr()), 16, None) == PG_E_ARG
+
+
+def test_one_rank_allreduce_is_the_identity(dp):
+    lib = _lib.load()
+    assert dp.comm is not None and dp.comm_ranks == 1 and dp.world_size == 1 and dp.rank == 0
+    n, r = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib.pg_comm_info(dp.comm, ctypes.byref(n), ctypes.byref(r)) == 0 and (n.value, r.value) == (1, 0)
+    assert lib.pg_allreduce_sum_f32(dp.comm, None, 4, None) == PG_E_ARG
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for count in (1, 7, 4096, (16 << 20) // 4 + 3):                            # up to one 16 MB bucket, odd sizes included
+        buf = torch.randn(count, device=DEV, generator=g)
+        want = buf.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        assert lib.pg_allreduce_sum_f32(dp.comm, ctypes.c_void_p(buf.data_ptr()), count, ctypes.c_void_p(s.cuda_stream)) == 0
+        s.synchronize()
+        assert torch.equal(buf, want), count
+    assert lib.pg_allreduce_sum_f32(dp.comm, ctypes.c_void_p(buf.data_ptr()), 0, None) == 0      # empty span: no-op
+    # the product wrapper: a span of a larger buffer, on the current stream
+    flat = torch.randn(10000, device=DEV, generator=g)
+    want = flat.clone()
+    before = dict(dp.stats)
+    dp.all_reduce_flat(flat[100:9000])
+    torch.cuda.synchronize()
+    assert torch.equal(flat, want)
+    assert dp.stats['collectives'] == before['collectives'] + 1 and dp.stats['bytes'] == before['bytes'] + 8900 * 4
+
+
+def _train(parallel, buckets, monkeypatch, iters=3):
+    monkeypatch.setenv('PGGAN_DP_BUCKETS', '1' if buckets else '0')
+    monkeypatch.setattr(pg.parallel, 'BUCKET_BYTES', 1 << 16)                    # small buckets: several collectives per sweep
+    torch.manual_seed(31)
+    shape = (1, 3, 64, 64)
+    kw = dict(fmap_base=512, fmap_max=64)
+    G = pg.Generator(shape, latent_size=64, **kw).to(DEV)
+    D = pg.Discriminator(shape, **kw).to(DEV)
+    G.depth = D.depth = 4
+    G.alpha = D.alpha = 0.7                                                      # fade-in: both fromRGB / toRGB pairs are live
+    rs = np.random.RandomState(9)
+    reals = iter([torch.from_numpy(rs.rand(4, 3, 64, 64).astype(np.float32) * 2 - 1) for _ in range(iters)])
+    zs = iter([torch.from_numpy(rs.randn(4, 64).astype(np.float32)) for _ in range(2 * iters)])
+    mixes = iter([torch.from_numpy(rs.rand(4, 1).astype(np.float32)) for _ in range(iters)])
+
+    def d_loss(Dm, Gm, real, z):
+        pg.wgan_gp_loss.set_mixing_factors(next(mixes))
+        return pg.wgan_gp_D_loss(Dm, Gm, real, z)
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, None, reals, lambda: next(zs), parallel=parallel)
+    grads = []
+    for _ in range(iters):
+        tr.train()
+        grads.append((D._flat_grad.clone(), G._flat_grad.clone()))
+    torch.cuda.synchronize()
+    assert tr.cur_nimg == 4 * iters
+    return G._flat_param.clone(), D._flat_param.clone(), grads
+
+
+def test_trainer_with_one_rank_communicator_matches_plain_trainer(dp, monkeypatch):
+    """``Trainer(parallel=dp)`` — bucketed exchange on the third stream, and one exchange per network — against the plain
+    Trainer.  With one rank every collective is the identity and 1/world = 1, so the runs differ only by stream placement:
+    the pre-Adam gradients of the first iteration agree to the atomic-add order of the weight-gradient commits, the weights
+    after 3 iterations to the 2*lr per step a sign-like Adam (beta1 = 0) can move a near-zero gradient element."""
+    g0, d0, gr0 = _train(None, True, monkeypatch)
+    c0 = dp.stats['collectives']
+    g1, d1, gr1 = _train(dp, True, monkeypatch)
+    c1 = dp.stats['collectives']
+    g2, d2, gr2 = _train(dp, False, monkeypatch)
+    c2 = dp.stats['collectives']
+    assert c1 - c0 > c2 - c1 >= 2 * 3            # buckets: more, smaller collectives; without: >= one span per network and step
+    for name, ref, got in (('G bucketed', g0, g1), ('D bucketed', d0, d1), ('G flush', g0, g2), ('D flush', d0, d2)):
+        assert float((got - ref).abs().max()) <= 2 * 0.001 * 3 + 1e-6, name
+        assert float((got - ref).norm() / ref.norm()) < 1e-3, name
+    for other in (gr1, gr2):                     # first iteration: identical weights, so the gradients must agree tightly
+        for a, b in zip(gr0[0], other[0]):
+            assert float((a - b).norm() / b.norm()) < 1e-5

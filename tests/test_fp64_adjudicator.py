@@ -142,16 +142,20 @@ def test_thin1024_against_fp64(oracle, tag):
     _run(oracle, G, D, gp, dp, cfg, real, z_d, z_g, mix, case['depth'], case['alpha'], 'thin1024 ' + tag)
 
 
-@pytest.mark.parametrize('res,depth,alpha,n,C', [(128, 5, 1.0, 2, 3), (256, 6, 1.0, 2, 1), (128, 4, 0.5, 3, 3)])
-def test_baseline_widths_against_fp64(oracle, res, depth, alpha, n, C):
-    """Default widths (fmap_base 4096): the 128x128 network (config 3, fully grown and in a fade-in) and the one-channel
-    256x256 network (config 4)."""
+@pytest.mark.parametrize('res,depth,alpha,n,C,fmap_base', [
+    (128, 5, 1.0, 2, 3, 4096), (256, 6, 1.0, 2, 1, 4096), (128, 4, 0.5, 3, 3, 4096),
+    (1024, 8, 1.0, 3, 3, 4096),        # the BENCHMARKED network (BASELINE config 5): 1024^2 stage, minibatch 3, default widths
+    (1024, 8, 1.0, 2, 3, 8192)])       # the paper's widths at the same stage (bench.py's fmap_base 8192 line)
+def test_baseline_widths_against_fp64(oracle, res, depth, alpha, n, C, fmap_base):
+    """Default widths (fmap_base 4096): the 128x128 network (config 3, fully grown and in a fade-in), the one-channel
+    256x256 network (config 4), and the headline 1024x1024 network at its real minibatch (config 5) and at the paper's widths
+    (the fp64 oracle passes of the 1024^2 cases take a few minutes and ~20 GB on the GPU box's host)."""
     torch.manual_seed(1337)
     shape = (1, C, res, res)
-    G, D = pg.Generator(shape), pg.Discriminator(shape)
+    G, D = pg.Generator(shape, fmap_base=fmap_base), pg.Discriminator(shape, fmap_base=fmap_base)
     gp, dp = G.reference_state_dict(), D.reference_state_dict()
     G.to(DEV)
     D.to(DEV)
-    cfg = oracle.NetCfg(res, C)
+    cfg = oracle.NetCfg(res, C, fmap_base=fmap_base)
     real, z_d, z_g, mix = oracle.synthetic_batch(42 + depth, n, C, 4 * 2 ** depth, 512)
     _run(oracle, G, D, gp, dp, cfg, real, z_d, z_g, mix, depth, alpha, 'res %d depth %d alpha %.2f' % (res, depth, alpha))

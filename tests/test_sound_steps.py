@@ -28,6 +28,54 @@ def test_host_transforms_match_oracle_and_invert():
     assert np.abs(back[inner] - y[:len(back)][inner]).max() < 1e-6
 
 
+@pytest.mark.parametrize('n_fft,hop', [(512, 128), (1024, 128), (256, 64), (512, 200)])
+def test_stft_agrees_with_scipy_and_torch(n_fft, hop):
+    """The oracle's (and the product's) STFT against two implementations that were NOT written for this project:
+    ``scipy.signal.stft`` and ``torch.stft``.  librosa 0.4.3's definition (dataset.py:293, output_postprocess.py:111) in their
+    terms: periodic Hann window, the signal reflect-padded by n_fft/2, frame t = padded[t*hop : t*hop + n_fft], unnormalised
+    rFFT.  This does not pin parity with the reference (librosa itself is absent: the label stays "unpinned") but it rules out a
+    misreading shared by the three implementations of this repository (window symmetry, padding mode, frame count, sign)."""
+    import scipy.signal
+    y = _chirp(hop * 37 + 91, seed=n_fft + hop).astype(np.float64)
+    ours = oss.stft(y, n_fft, hop)
+    prod = pg.sound.stft(y, n_fft, hop)
+    assert np.abs(ours - prod).max() <= 1e-9 * np.abs(ours).max()
+    # scipy: no boundary extension / padding of its own on the signal we padded; scaling='spectrum' divides by sum(window)
+    yp = np.pad(y, n_fft // 2, mode='reflect')
+    win = scipy.signal.get_window('hann', n_fft, fftbins=True)               # periodic ("DFT-even") Hann
+    _, _, z = scipy.signal.stft(yp, window=win, nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft, boundary=None, padded=False,
+                                return_onesided=True, detrend=False)
+    z = z * win.sum()
+    assert z.shape == ours.shape, (z.shape, ours.shape)
+    assert np.abs(z - ours).max() <= 1e-6 * np.abs(ours).max()
+    # torch: center=True pads by n_fft/2 with pad_mode itself
+    zt = torch.stft(torch.from_numpy(y), n_fft, hop_length=hop, win_length=n_fft,
+                    window=torch.hann_window(n_fft, periodic=True, dtype=torch.float64), center=True, pad_mode='reflect',
+                    normalized=False, onesided=True, return_complex=True).numpy()
+    assert zt.shape == ours.shape, (zt.shape, ours.shape)
+    assert np.abs(zt - ours).max() <= 1e-6 * np.abs(ours).max()
+    # ... and the inverse against torch.istft (librosa 0.4.3's fixed 2/3 gain is the exact window-sum normalisation at hop = n_fft/4)
+    if hop * 4 == n_fft:
+        back = torch.istft(torch.from_numpy(ours), n_fft, hop_length=hop, win_length=n_fft,
+                           window=torch.hann_window(n_fft, periodic=True, dtype=torch.float64), center=True).numpy()
+        mine = oss.istft(ours, hop)
+        inner = slice(n_fft, min(len(back), len(mine)) - n_fft)
+        assert np.abs(back[inner] - mine[inner]).max() < 1e-9
+
+
+def test_oracle_image_modes():
+    """'reallog' with numpy 1.13's complex sign (the reference's pin) and 'raw': shapes, ranges, and the sign convention."""
+    y = _chirp(128 * 140, 1)
+    a = oss.spectrogram_image(y, 256, 128, img_mode='reallog')
+    assert a.shape == (1, 128, 128) and a.dtype == np.uint8 and a.min() == 0 and a.max() >= 254
+    s = oss.stft(y, 256, 128).astype(np.complex64)[:128, :128]
+    v = np.log(1 + np.abs(s.real)) * np.sign(s.real)
+    ref = np.uint8((v - v.min()) * (255.0 / (v.max() - v.min())))
+    assert (np.abs(a[0].astype(int) - ref.astype(int)) <= 1).all()
+    r = oss.spectrogram_image(np.stack([y, y[::-1]], axis=1), 256, 128, img_mode='raw')
+    assert r.shape == (1, 128, 128) and r.min() == 0 and r.max() >= 254       # 17920 samples -> 128^2 = 16384 of them
+
+
 def test_sound_saver_matches_oracle(tmp_path):
     rs = np.random.RandomState(3)
     img = oss.spectrogram_image(_chirp(128 * 140, 1), 256, 128)[0].astype(np.float64) / 127.5 - 1      # [128,128] in drange (-1,1)
@@ -71,6 +119,27 @@ def test_device_spectrogram_against_oracle(n_fft, hop, stereo):
     diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())
     assert got.min() == 0 and got.max() >= 254                                   # the stretch uses the full range
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,n_fft,hop,stereo', [('reallog', 512, 128, False), ('reallog', 256, 64, True),
+                                                   ('raw', 0, 0, False), ('raw', 0, 0, True)])
+def test_device_reallog_and_raw_against_oracle(mode, n_fft, hop, stereo):
+    """pg_stft_image(PG_SOUND_REALLOG) / pg_mono_f32 + min/max stretch vs the oracle (dataset.py:289-291, :298)."""
+    n = hop * (n_fft // 2 + 3) + 11 if mode == 'reallog' else 70000          # 'raw': 256^2 = 65536 <= 70000 < 512^2
+    y = _chirp(n, seed=17)
+    if stereo:
+        y = np.stack([y, _chirp(n, seed=7)], axis=1)
+    ref = oss.spectrogram_image(y, n_fft, hop, img_mode=mode)
+    got = pg.spectrogram_u8(y, n_fft or 1024, hop or 128, img_mode=mode).cpu().numpy()
+    assert got.shape == ref.shape and got.dtype == np.uint8
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    # reallog: a bin whose real part is within round-off of zero may take the other sign in the fp64-accumulated device DFT;
+    # the image value then moves by 2 log(1 + |re|) ~ 0: still <= 1 LSB
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+    assert got.min() == 0 and got.max() >= 254
+    with pytest.raises(ValueError):
+        pg.spectrogram_u8(y, 512, 128, img_mode='phase')
 
 
 @pytest.mark.gpu
