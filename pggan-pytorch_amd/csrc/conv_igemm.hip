@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include "pggan_hip.h"
 #include "bufload.h"
+#include "convp.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -31,6 +32,17 @@ namespace {
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
 thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling, 10: unfused unpooling, 11 / 12: unfused PixelNorm forward / adjoint
 
+template <typename K>
+inline int set_smem(K kern, size_t smem)
+{
+    if (smem > 160 * 1024) return PG_E_UNSUP;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 template <int VEC> __device__ __forceinline__ void lds_load(const float* p, float (&o)[VEC]);
 template <> __device__ __forceinline__ void lds_load<4>(const float* p, float (&o)[4]) {
     float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -40,39 +52,9 @@ template <> __device__ __forceinline__ void lds_load<2>(const float* p, float (&
 }
 template <> __device__ __forceinline__ void lds_load<1>(const float* p, float (&o)[1]) { o[0] = *p; }
 
-struct ConvP {
-    const float* x; const float* w; const float* bias; const float* mask; float* y;
-    int N, Hin, Win, Cin, Cout, Hout, Wout, KS, pad, ups;
-    float scale, slope, mask_slope;
-    int lgTW, lgTH, TN, tilesW, tilesH;
-    unsigned mWT, mHT;          // floor(2^32/WT)+1, floor(2^32/HT)+1: exact n/d for n < 2^16 via __umulhi
-    int ksplit;                 // >1: blockIdx.z owns a slice of the Cin chunks, partial sums are
-                                // committed with fp32 atomics into a pre-zeroed y (epilogue deferred)
-    // fused 2x2 average pool of the activated output (pg_conv2d_pool_nhwc): ypool = pool_a * avgpool2(y) + pool_b * pool_other
-    float* ypool; const float* pool_other; float pool_a, pool_b; int pool_only;
-    // fused adjoint of that pool (pg_conv2d_unpool_nhwc): yup[n][2h+dy][2w+dx][c] = 0.25*up_mul * y[n][h][w][c] * lrelu'(upmask[...])
-    float* yup; const float* upmask; float up_mul;
-    // fused PixelNorm of the activated output (pg_conv2d_pixelnorm_nhwc): y *= rsqrt(mean_c y^2 + pn_eps), pn_r[pixel] = that factor
-    float* pn_r; float pn_eps;
-    // fused adjoint of (LeakyReLU -> PixelNorm) applied to the conv result g (pg_conv2d_pnbwd_nhwc):
-    //   y = r[pix] * (g - pnb_y * mean_c(g * pnb_y)) * lrelu'(pnb_y)
-    const float* pnb_y; const float* pnb_r;
-    // sign-byte activations (PG_FLAG_MASK_BYTES / PG_FLAG_Y_BYTES): one byte per float4, bit j = (channel 4q+j > 0)
-    int mask_bytes, y_bytes;
-    unsigned char* ysigns;      // PG_FLAG_SIGNS_OUT: the sign bytes of y are written here IN ADDITION to y (forward mode)
-    // pool adjoint fused into the input gather (pg_conv2d_unpooled_nhwc): xin[n][h][w][c] = gmul * x[n][h/2][w/2][c] * lrelu'(gbytes[n][h][w][c])
-    const unsigned char* gbytes; float gmul, gslope;
-};
-
-// LeakyReLU' factors of four channels from a sign byte / the sign byte of four activated outputs
-__device__ __forceinline__ float4 pg_sign_factors(unsigned char b, float slope)
-{
-    return make_float4((b & 1) ? 1.f : slope, (b & 2) ? 1.f : slope, (b & 4) ? 1.f : slope, (b & 8) ? 1.f : slope);
-}
-__device__ __forceinline__ unsigned char pg_sign_byte(float4 o)
-{
-    return (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
-}
+using pgk::ConvP;
+using pgk::pg_sign_factors;
+using pgk::pg_sign_byte;
 
 // LDS row stride (floats) of a KC-channel row: conflict-free for the gfx950 lane groups
 //   VEC=4 (ds_read_b128, 4x16 lanes, 64 banks): 24   VEC=2 (ds_read_b64): 12   VEC=1: 8
@@ -469,19 +451,7 @@ __global__ __launch_bounds__(256) void conv_epilogue_kernel(float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-struct WgP {
-    const float* x; const float* gz; float* dw; float* db;
-    int N, Hin, Win, Cin, Cout, Hout, Wout, pad, ups;
-    float scale;
-    int lgTW, lgTH, TN, tilesW, tilesH, ntiles, tiles_per_block;
-    unsigned mWT, mHT;          // magic reciprocals of the halo tile width / height (see ConvP)
-    int atomic;                 // 0: this workgroup is the only writer of its dW block -> plain +=
-    // pool adjoint fused into the gz gather (pg_conv2d_wgrad_unpooled_nhwc): gz[n][h][w][c] = gmul * g[n][h/2][w/2][c] * lrelu'(gbytes[n][h][w][c])
-    const unsigned char* gbytes; float gmul, gslope;
-#ifdef PG_WINO_TRACE
-    unsigned long long* trace;  // [workgroup][wave][tile < 8][8] s_memtime stamps (tools/exp/wgrad_trace.py)
-#endif
-};
+using pgk::WgP;
 
 #ifdef PG_WINO_TRACE
 #define PG_WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (p.trace && lane == 0 && blockIdx.x < 1024 && (tile - t_begin) < 8) \
@@ -1058,6 +1028,10 @@ int launch_thin(ConvP& p, hipStream_t s)
 
 int dispatch_thin(ConvP& p, hipStream_t s)
 {
+    if (g_tune[3] != 20) {                        // row-streaming kernel (conv_strip.hip) where the shape allows; 20: tile kernel (A/B)
+        const int rc = pgk::launch_conv_strip(p, s, g_last_kernel, sizeof(g_last_kernel));
+        if (rc != PG_E_UNSUP) return rc;
+    }
 #define THIN(CO_, CI_) if (p.Cout == CO_ && p.Cin == CI_) return launch_thin<CO_, CI_, 8>(p, s);
     THIN(8, 8) THIN(8, 16) THIN(16, 8)
 #undef THIN
@@ -1174,16 +1148,6 @@ inline TileGeom make_geom(int N, int Hout, int Wout, int BPX, int max_tw = 32)
     return g;
 }
 
-template <typename K>
-inline int set_smem(K kern, size_t smem)
-{
-    if (smem > 160 * 1024) return PG_E_UNSUP;
-    if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
-}
 
 template <int KS, int VEC, int WAVES_CO, int WM, int WN>
 int launch_conv(ConvP& p, hipStream_t s)

@@ -1,0 +1,429 @@
+// Row-streaming 3x3 convolution for the 8-cout layers of the 1024^2 stage (gfx950 / CDNA4).
+//
+// Replaces F.conv2d + bias + LeakyReLU of reference network.py:33-36 (and its backward-data / gradient-penalty tangent forms)
+// for the layers 8->8 and 16->8 — the shapes conv_thin_kernel (conv_igemm.hip) serves with one 8 x 32 pixel tile per workgroup.
+// Those layers sit at the HBM ridge (18-24 FLOP/B); a tile kernel loses there to (a) the halo re-read of a small tile (1.33x on
+// the input), (b) 1 KB row pieces scattered over ten DRAM pages per workgroup, (c) a load -> barrier -> compute -> store life
+// cycle whose overlap depends on other workgroups being in a different phase, and (d) ~700 scalar / vector instructions of
+// address arithmetic and run-time epilogue selection per 144 MFMAs (measured: the scalar unit, the VALU, the LDS and the matrix
+// pipe all sit at 40-75 % — nothing saturates, everything waits).
+//
+// This kernel: a workgroup owns a STRIP of 64 output columns and walks DOWN `seg` rows of one image, four rows per step.
+//   * input rows enter LDS exactly once per strip (66 of 64 columns: 3 % horizontal halo, no vertical re-read) through LDS-DMA
+//     (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass; rows above / below the image fall outside the
+//     records of the per-image buffer and are zero-filled by the hardware, the left / right border columns carry an
+//     out-of-range offset from the start; a ring of three blocks of four rows, the block two steps ahead is in flight while the
+//     current one is consumed, ONE barrier per step;
+//   * LDS layout "quad-planar" (plane q = channels 4q..4q+3 of every pixel as consecutive 16-byte slots): the only layout LDS-DMA
+//     can write, and conflict-free for the ds_read_b128 of v_mfma_f32_4x4x1_16B operands (16 consecutive pixels per lane group);
+//     every LDS address is a per-lane base plus a compile-time constant (the ring phase is a template parameter);
+//   * MFMA mapping as in conv_thin_kernel: v_mfma_f32_4x4x1_16B_f32, block = (cout quad, pixel quad), A = weights, B = pixels,
+//     so a lane ends up with 4 consecutive couts of one pixel (16-byte NHWC stores); wave w owns rows {2(w>>1), 2(w>>1)+1} x
+//     columns [32(w&1), +32) of the step, i.e. complete 2x2 pooling windows; same accumulation order as the tile kernel
+//     (bit-identical results);
+//   * the epilogue is a TEMPLATE parameter (forward / masked / PixelNorm / PixelNorm adjoint / generic), every global access goes
+//     through a per-image raw buffer with a 32-bit offset that advances by a constant per step, the masks of the step are
+//     fetched before its MFMAs, and the next step waits for its DMA only (counted vmcnt: the stores of a step drain under the
+//     MFMAs of the next one).
+// Fused epilogues (same set as the tile kernel): x scale, + bias, LeakyReLU | x LeakyReLU'(saved activation, fp32 or sign bytes),
+// sign bytes out, 2x2 average pool + fade-in blend, PixelNorm, adjoint of the previous (LeakyReLU -> PixelNorm); nearest x2
+// upsample fused into the row gather (the DMA source address).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <cstdio>
+#include <type_traits>
+#include "pggan_hip.h"
+#include "bufload.h"
+#include "convp.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef PG_STRIP_ABL            // ablation build of tools/bench_strip.py: 1 no DMA after the prologue, 2 no stores, 4 one tap only
+#define PG_STRIP_ABL 0
+#endif
+
+namespace {
+
+using pgk::ConvP;
+using pgk::pg_sign_byte;
+using pgk::pg_sign_factors;
+
+constexpr int SW = 64;            // output columns of a strip
+constexpr int RP = SW + 2;        // slots of one plane row (left / right halo column included)
+constexpr int RB = 4;             // rows of a block = output rows per step
+constexpr int NBLK = 3;           // ring: blocks it, it + 1 are read while block it + 2 lands
+
+enum { EPI_GENERIC = 0, EPI_FWD = 1, EPI_MASK = 2, EPI_PN = 3, EPI_PNB = 4 };
+
+struct SArgs {
+    const float* x; const float* w; const float* bias; const void* mask; float* y;
+    unsigned char* ysigns; float* pn_r; const float* pnb_y; const float* pnb_r; float* ypool; const float* pool_other;
+    float scale, slope, mask_slope, pn_eps, pool_a, pool_b;
+    int H, W, ups, mask_bytes, y_bytes, pool_only;
+    int strips, segs, seg_rows;
+};
+
+template <int CIN> struct Blk {
+    static constexpr int C4 = CIN / 4;
+    static constexpr int USED = C4 * RB * RP;                 // slots carrying data: [plane q][row m][pixel]
+    static constexpr int NWI = (USED + 63) / 64;              // DMA wave-instructions per block
+    static constexpr int NI = (NWI + 3) / 4;                  // ... per thread (instruction ii = i * 4 + wave)
+    static constexpr int SLOTS = NWI * 64;                    // block pitch (the tail of the last instruction is zero-filled padding)
+};
+
+typedef __attribute__((address_space(3))) const char* lds_cptr;
+typedef __attribute__((address_space(3))) const f32x4* lds_v4ptr;
+
+__device__ __forceinline__ pg_u32x4 rsrc_words(const void* base, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)base;
+    return pg_u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)), bytes, 0x00020000u};
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(pg_u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
+                                           r, (int)voff, 0, 0);
+}
+
+template <int COUT, int CIN, int EPI, bool WREG>
+__global__ __launch_bounds__(256, WREG ? 3 : 4) void conv_strip_kernel(SArgs p)
+{
+    using B = Blk<CIN>;
+    constexpr int C4 = B::C4;
+    constexpr int QO = COUT / 4, QP = 16 / QO, PXG = 4 * QP;             // pixels per MFMA group: 32 (8 couts)
+    constexpr int GPR = 32 / PXG, G = 2 * GPR;                           // groups per row of the wave's 32 columns; groups per wave
+    constexpr int BLKB = B::SLOTS * 16;                                   // bytes of a ring block
+    constexpr bool GEN = EPI == EPI_GENERIC;
+    extern __shared__ __align__(16) float lds[];
+    float* wl = lds + NBLK * B::SLOTS * 4;                                // [9][COUT][CIN] (only when the weights are not in registers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = lane >> 2, j = lane & 3, qo = blk % QO, qp = blk / QO;
+
+    int t = (int)pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = __builtin_amdgcn_readfirstlane(t % p.strips); t /= p.strips;      // (scalar: the buffer descriptors live in SGPRs)
+    const int seg = __builtin_amdgcn_readfirstlane(t % p.segs), n = __builtin_amdgcn_readfirstlane(t / p.segs);
+    const int r0 = seg * p.seg_rows, ow0 = strip * SW;
+    const int niter = p.seg_rows / RB;
+    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
+    const unsigned npix = (unsigned)(p.H * p.W);
+
+    // ---- DMA offsets (per thread): instruction i of wave w fills slots [(4 i + w) 64, +64) of a block.  voff[i] = byte offset of
+    // the lane's source inside the image for block 0 of the segment; it advances by a constant per block.  A row above the image
+    // makes the offset negative (= huge), a row below it exceeds the records: the hardware returns zeros.  Border columns and the
+    // padding slots carry PG_OOB and never advance.
+    const unsigned rowbytes = 4u * (unsigned)(xW * CIN);
+    unsigned voff[B::NI], vstep[B::NI];
+    const unsigned blkstep = (p.ups ? 2u : 4u) * rowbytes;
+#pragma unroll
+    for (int i = 0; i < B::NI; ++i) {
+        const int sl = (i * 4 + wave) * 64 + lane;
+        const int q = sl / (RB * RP), rem = sl - q * (RB * RP);
+        const int m = rem / RP, px = rem - m * RP;
+        const int col = ow0 - 1 + px, row = r0 - 1 + m;
+        const bool ok = sl < B::USED && (unsigned)col < (unsigned)p.W;
+        // (mod 2^32: a row above the image is "negative" = beyond the records, and walks into the image as blocks are added)
+        voff[i] = ok ? (unsigned)(p.ups ? (row >> 1) : row) * rowbytes + 4u * (unsigned)((p.ups ? (col >> 1) : col) * CIN + 4 * q) : PG_OOB;
+        vstep[i] = ok ? blkstep : 0u;                               // (an out-of-range lane stays out of range)
+    }
+    const size_t ximg = (size_t)xH * xW * CIN;
+    const pg_u32x4 rxs = rsrc_words(p.x + (size_t)n * ximg, (unsigned)(ximg * 4));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned wdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    // LDS-DMA through inline asm (hipcc would order every later ds_read behind a DMA it can see); M0 = the wave's 1 KiB destination
+    auto dma16 = [&](unsigned vo, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo), "s"(rxs), "s"(dst) : "memory");
+    };
+    auto issue_block = [&](int pos) {                         // the next block of four input rows -> ring position pos
+#pragma unroll
+        for (int i = 0; i < B::NI; ++i) {
+            if (i * 4 + wave < B::NWI) dma16(voff[i], wdst + (unsigned)pos * BLKB + (unsigned)i * 4096u);
+            voff[i] += vstep[i];
+        }
+    };
+
+    // ---- weights of this lane's cout row (4 qo + j): registers (Cin = 8, optional) or LDS
+    float4 wreg[WREG ? 9 : 1][WREG ? C4 : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4)
+                wreg[tp][c4] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tp * COUT + 4 * qo + j) * CIN + 4 * c4));
+    } else {
+        for (int e = tid; e < 9 * COUT * C4; e += 256)
+            *reinterpret_cast<float4*>(wl + 4 * e) = *reinterpret_cast<const float4*>(p.w + 4 * e);
+    }
+    const float* wrow = wl + (4 * qo + j) * CIN;
+
+    issue_block(0);
+    issue_block(1);
+
+    const int rp = wave >> 1;                                     // row pair of the step owned by this wave
+    const int col0 = (wave & 1) * 32;
+    const lds_cptr lbase = (lds_cptr)lds + (col0 + 4 * qp + j) * 16;
+
+    // ---- epilogue operands: per-image raw buffers, 32-bit offsets.  pix = pixel index inside the image of group 0 at step `it`
+    const bool has_mask = (GEN && p.mask) || EPI == EPI_MASK;
+    const bool mask_bytes = has_mask && p.mask_bytes;
+    const bool has_pnb = (GEN && p.pnb_y) || EPI == EPI_PNB;
+    const bool has_pn = (GEN && p.pn_r) || EPI == EPI_PN;
+    const bool has_signs = (GEN || EPI == EPI_FWD) && p.ysigns;
+    const bool has_pool = GEN && p.ypool;
+    const bool y_bytes = GEN && p.y_bytes;
+    const bool y_store = !(has_pool && p.pool_only) && !y_bytes;
+    const __amdgpu_buffer_rsrc_t ry = y_bytes ? pg_make_rsrc((const unsigned char*)p.y + (size_t)n * npix * (COUT / 4), npix * (COUT / 4))
+                                              : pg_make_rsrc(p.y + (size_t)n * npix * COUT, npix * COUT * 4u);
+    __amdgpu_buffer_rsrc_t rmask = ry, rsig = ry, rpnr = ry, rpnby = ry, rpnbr = ry;
+    if (has_mask) rmask = mask_bytes ? pg_make_rsrc((const unsigned char*)p.mask + (size_t)n * npix * (COUT / 4), npix * (COUT / 4))
+                                     : pg_make_rsrc((const float*)p.mask + (size_t)n * npix * COUT, npix * COUT * 4u);
+    if (has_signs) rsig = pg_make_rsrc(p.ysigns + (size_t)n * npix * (COUT / 4), npix * (COUT / 4));
+    if (has_pn) rpnr = pg_make_rsrc(p.pn_r + (size_t)n * npix, npix * 4u);
+    if (has_pnb) {
+        rpnby = pg_make_rsrc(p.pnb_y + (size_t)n * npix * COUT, npix * COUT * 4u);
+        rpnbr = pg_make_rsrc(p.pnb_r + (size_t)n * npix, npix * 4u);
+    }
+    const unsigned pix0 = (unsigned)((r0 + 2 * rp) * p.W + ow0 + col0 + 4 * qp + j);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!has_mask && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + 4 * qo);
+
+    f32x4 acc[G], acc2[G];
+    // MFMAs of one step: ring phase PH (block of the step at ring position PH) and row pair RPAIR are compile-time, so every LDS
+    // address below is lbase + constant
+    auto compute = [&](auto ph_, auto rp_) {
+        constexpr int PH = decltype(ph_)::value, RPAIR = decltype(rp_)::value;
+#pragma unroll
+        for (int g = 0; g < G; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int tp = 0; tp < ((PG_STRIP_ABL & 4) ? 1 : 9); ++tp) {
+            const int dy = tp / 3, dx = tp % 3;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+                float4 a;
+                if constexpr (WREG) a = wreg[tp][c4];
+                else a = *reinterpret_cast<const float4*>(wrow + tp * COUT * CIN + 4 * c4);
+                f32x4 bq[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int m = 2 * RPAIR + g / GPR + dy;                          // row of the 6-row window of the step
+                    const int pos = m < RB ? PH : (PH + 1) % NBLK;
+                    const int off = ((pos * B::SLOTS) + c4 * (RB * RP) + (m & (RB - 1)) * RP + (g % GPR) * PXG + dx) * 16;
+                    bq[g] = *(lds_v4ptr)(lbase + off);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, bq[g][0], acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc2[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, bq[g][1], acc2[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, bq[g][2], acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc2[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, bq[g][3], acc2[g], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] += acc2[g];
+    };
+
+    // Operands of the epilogue that do not depend on the MFMAs (LeakyReLU' mask, saved PixelNorm output): fetched BEFORE the MFMAs of
+    // the step, so that their latency is not a serial stall of this wave between its MFMAs and its stores
+    float4 pm[G];
+    unsigned pmb[G];
+    float prr[G];
+    auto prefetch_epilogue = [&](unsigned pix) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned pg_ = pix + (unsigned)((g / GPR) * p.W + (g % GPR) * PXG);
+            if (has_mask) {
+                if (mask_bytes) pmb[g] = __builtin_amdgcn_raw_buffer_load_b8(rmask, (int)(pg_ * (COUT / 4) + qo), 0, 0);
+                else pm[g] = pg_buf_load4(rmask, (pg_ * COUT + 4 * qo) * 4u, 0);
+            } else if (has_pnb) {
+                pm[g] = pg_buf_load4(rpnby, (pg_ * COUT + 4 * qo) * 4u, 0);
+                prr[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rpnbr, (int)(pg_ * 4u), 0, 0));
+            }
+        }
+    };
+    // D register r of this lane = out[pixel][cout 4 qo + r]
+    auto epilogue = [&](unsigned pix) {
+        float4 ov[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned pg_ = pix + (unsigned)((g / GPR) * p.W + (g % GPR) * PXG);
+            const unsigned off = pg_ * COUT + 4 * qo;                                     // element offset inside the image
+            float4 o = make_float4(acc[g][0] * p.scale, acc[g][1] * p.scale, acc[g][2] * p.scale, acc[g][3] * p.scale);
+            if (has_mask) {
+                float4 f;
+                if (mask_bytes) f = pg_sign_factors((unsigned char)pmb[g], p.mask_slope);
+                else {
+                    const float4 mk = pm[g];
+                    f = make_float4(mk.x > 0.f ? 1.f : p.mask_slope, mk.y > 0.f ? 1.f : p.mask_slope,
+                                    mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
+                }
+                o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+            } else {
+                o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+                o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
+                o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+                if (has_signs && !(PG_STRIP_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b8(pg_sign_byte(o), rsig, (int)(off >> 2), 0, 0);
+            }
+            if (has_pnb) {                               // adjoint of the previous layer's (LeakyReLU -> PixelNorm), see ConvP
+                const float4 yv = pm[g];
+                const float4 gv = make_float4(acc[g][0] * p.scale, acc[g][1] * p.scale, acc[g][2] * p.scale, acc[g][3] * p.scale);
+                float dt = (gv.x * yv.x + gv.y * yv.y) + (gv.z * yv.z + gv.w * yv.w);
+                dt += __shfl_xor(dt, 4, 64);
+                if (QO >= 4) dt += __shfl_xor(dt, 8, 64);
+                const float rr = prr[g], mean = dt / (float)COUT;
+                o.x = rr * (gv.x - yv.x * mean) * (yv.x > 0.f ? 1.f : p.mask_slope);
+                o.y = rr * (gv.y - yv.y * mean) * (yv.y > 0.f ? 1.f : p.mask_slope);
+                o.z = rr * (gv.z - yv.z * mean) * (yv.z > 0.f ? 1.f : p.mask_slope);
+                o.w = rr * (gv.w - yv.w * mean) * (yv.w > 0.f ? 1.f : p.mask_slope);
+            }
+            if (has_pn) {                                // PixelNorm over the COUT channels of the pixel: QO lanes (4 apart) share it
+                float ssq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                ssq += __shfl_xor(ssq, 4, 64);
+                if (QO >= 4) ssq += __shfl_xor(ssq, 8, 64);
+                const float rr = rsqrtf(ssq / (float)COUT + p.pn_eps);
+                o.x *= rr; o.y *= rr; o.z *= rr; o.w *= rr;
+                if (qo == 0 && !(PG_STRIP_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rr), rpnr, (int)(pg_ * 4u), 0, 0);
+            }
+            if (!(PG_STRIP_ABL & 2)) {
+                if (y_bytes) __builtin_amdgcn_raw_buffer_store_b8(pg_sign_byte(o), ry, (int)(off >> 2), 0, 0);
+                else if (y_store) buf_store4(ry, off * 4u, o);
+            }
+            ov[g] = o;
+        }
+        if (has_pool) {                              // 2x2 mean: column partner = lane ^ 1, row partner = group g + GPR (same wave)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {                 // (same order of additions as the tile kernel: columns first, then rows)
+                ov[g].x += __shfl_xor(ov[g].x, 1, 64); ov[g].y += __shfl_xor(ov[g].y, 1, 64);
+                ov[g].z += __shfl_xor(ov[g].z, 1, 64); ov[g].w += __shfl_xor(ov[g].w, 1, 64);
+            }
+#pragma unroll
+            for (int g = 0; g < GPR; ++g) {
+                float4 v = make_float4((ov[g].x + ov[g + GPR].x) * 0.25f, (ov[g].y + ov[g + GPR].y) * 0.25f,
+                                       (ov[g].z + ov[g + GPR].z) * 0.25f, (ov[g].w + ov[g + GPR].w) * 0.25f);
+                if (j & 1) continue;
+                const unsigned pg_ = pix + (unsigned)(g * PXG);
+                const unsigned oy = pg_ / (unsigned)p.W, ox = pg_ - oy * (unsigned)p.W;
+                const size_t poff = (((size_t)n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * COUT + 4 * qo;
+                if (p.pool_other) {
+                    const float4 q = *reinterpret_cast<const float4*>(p.pool_other + poff);
+                    v.x = fmaf(v.x, p.pool_a, p.pool_b * q.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * q.y);
+                    v.z = fmaf(v.z, p.pool_a, p.pool_b * q.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * q.w);
+                } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
+                *reinterpret_cast<float4*>(p.ypool + poff) = v;
+            }
+        }
+    };
+
+    // Vector-memory instructions a step issues AFTER its DMA and whose completion the next step need not wait for: the stores of
+    // the epilogue (the gfx9-family vmcnt retires loads and stores in issue order, so "at most S outstanding" = "everything issued
+    // before them is done"; the loads of the epilogue have been consumed by then).
+    int nstores = (y_bytes || y_store) ? G : 0;
+    if (has_signs) nstores += G;
+    if (has_pn) nstores += G;
+    if (has_pool) nstores += GPR;
+    if (PG_STRIP_ABL & 2) nstores = 0;
+    nstores = __builtin_amdgcn_readfirstlane(nstores);
+    auto wait_dma = [&]() {
+        if constexpr (EPI == EPI_MASK || EPI == EPI_PNB) { static_assert(G == 2, ""); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else if constexpr (EPI == EPI_PN) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else switch (nstores) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        }
+    };
+    unsigned pix = pix0;
+    const unsigned pixstep = (unsigned)(RB * p.W);
+    auto step = [&](int it, auto ph_) {
+        constexpr int PH = decltype(ph_)::value;
+        if (it == 0 || (PG_STRIP_ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else wait_dma();                                          // this wave's share of blocks it, it + 1 has landed ...
+        __syncthreads();                                          // ... everyone's has, and nobody still reads block it - 1
+        if (it + 2 <= niter && !((PG_STRIP_ABL & 1) && it > 0)) issue_block((PH + 2) % NBLK);   // (block niter: the two rows below the segment)
+        prefetch_epilogue(pix);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rp == 0) compute(ph_, std::integral_constant<int, 0>{});
+        else compute(ph_, std::integral_constant<int, 1>{});
+        epilogue(pix);
+        pix += pixstep;
+    };
+    for (int it = 0; it < niter; it += 3) {
+        step(it, std::integral_constant<int, 0>{});
+        if (it + 1 < niter) step(it + 1, std::integral_constant<int, 1>{});
+        if (it + 2 < niter) step(it + 2, std::integral_constant<int, 2>{});
+    }
+}
+
+template <int COUT, int CIN, int EPI, bool WREG>
+int launch_strip(const SArgs& a, int N, hipStream_t s, char* name, size_t name_len)
+{
+    using B = Blk<CIN>;
+    const size_t smem = (size_t)NBLK * B::SLOTS * 16 + (WREG ? 0 : (size_t)9 * COUT * CIN * 4);
+    auto kern = conv_strip_kernel<COUT, CIN, EPI, WREG>;
+    static bool attr_done = false;                                // (idempotent; a race only repeats the call)
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return (int)hipGetLastError();
+        attr_done = true;
+    }
+    snprintf(name, name_len, "conv_strip_kernel<%d, %d, %d, %s>", COUT, CIN, EPI, WREG ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
+    return (int)hipGetLastError();
+}
+
+template <int COUT, int CIN, bool WREG>
+int launch_strip_epi(const SArgs& a, int epi, int N, hipStream_t s, char* name, size_t name_len)
+{
+    switch (epi) {
+        case EPI_FWD: return launch_strip<COUT, CIN, EPI_FWD, WREG>(a, N, s, name, name_len);
+        case EPI_MASK: return launch_strip<COUT, CIN, EPI_MASK, WREG>(a, N, s, name, name_len);
+        case EPI_PN: return launch_strip<COUT, CIN, EPI_PN, WREG>(a, N, s, name, name_len);
+        case EPI_PNB: return launch_strip<COUT, CIN, EPI_PNB, WREG>(a, N, s, name, name_len);
+        default: return launch_strip<COUT, CIN, EPI_GENERIC, WREG>(a, N, s, name, name_len);
+    }
+}
+
+}  // namespace
+
+int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
+{
+    static const int seg_env = getenv("PG_STRIP_SEG") ? atoi(getenv("PG_STRIP_SEG")) : 0;
+    static const int wreg_env = getenv("PG_STRIP_WREG") ? atoi(getenv("PG_STRIP_WREG")) : 0;
+    static const int epi_env = getenv("PG_STRIP_EPI") ? atoi(getenv("PG_STRIP_EPI")) : -1;      // 0: always the generic epilogue (A/B)
+    if (p.KS != 3 || p.pad != 1 || p.gbytes || p.yup || p.ksplit != 1) return PG_E_UNSUP;
+    if ((p.Wout % SW) || (p.Hout % 16) || p.Hout != p.Hin || p.Wout != p.Win) return PG_E_UNSUP;
+    if (!(p.Cout == 8 && (p.Cin == 8 || p.Cin == 16))) return PG_E_UNSUP;       // (16 couts: the tile / Winograd kernels keep those layers)
+    if ((long long)p.Hin * p.Win * 16 * 4 >= (1ll << 31)) return PG_E_UNSUP;     // 32-bit byte offsets inside an image
+    // rows per workgroup: long enough to amortise the two-block prologue, short enough for >= 3 workgroups per CU
+    int seg = seg_env > 0 ? seg_env : 64;
+    while (seg > 16 && ((long long)p.N * (p.Wout / SW) * (p.Hout / seg) < 768 || (p.Hout % seg))) seg >>= 1;
+    if (seg < 16 || (seg % RB) || (p.Hout % seg)) return PG_E_UNSUP;
+    SArgs a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.mask = p.mask; a.y = p.y;
+    a.ysigns = p.ysigns; a.pn_r = p.pn_r; a.pnb_y = p.pnb_y; a.pnb_r = p.pnb_r; a.ypool = p.ypool; a.pool_other = p.pool_other;
+    a.scale = p.scale; a.slope = p.slope; a.mask_slope = p.mask_slope; a.pn_eps = p.pn_eps; a.pool_a = p.pool_a; a.pool_b = p.pool_b;
+    a.H = p.Hout; a.W = p.Wout; a.ups = p.ups; a.mask_bytes = p.mask_bytes; a.y_bytes = p.y_bytes; a.pool_only = p.pool_only;
+    a.strips = p.Wout / SW; a.segs = p.Hout / seg; a.seg_rows = seg;
+    int epi = EPI_GENERIC;
+    if (!p.ypool && !p.y_bytes) {
+        if (p.pnb_y && !p.mask && !p.pn_r && !p.ysigns) epi = EPI_PNB;
+        else if (p.pn_r && !p.mask && !p.pnb_y && !p.ysigns) epi = EPI_PN;
+        else if (p.mask && !p.pnb_y && !p.pn_r) epi = EPI_MASK;
+        else if (!p.mask && !p.pnb_y && !p.pn_r) epi = EPI_FWD;
+    }
+    if (epi_env == 0) epi = EPI_GENERIC;
+    // 8 -> 8: the weights of a lane's cout row fit in registers (72 VGPRs, three waves per SIMD) or stay in LDS (four+ waves per SIMD)
+    if (p.Cin == 8) return wreg_env ? launch_strip_epi<8, 8, true>(a, epi, p.N, s, name, name_len)
+                                    : launch_strip_epi<8, 8, false>(a, epi, p.N, s, name, name_len);
+    return launch_strip_epi<8, 16, false>(a, epi, p.N, s, name, name_len);
+}
+
+int pgk::launch_wgrad_strip(WgP&, hipStream_t, char*, size_t) { return PG_E_UNSUP; }

@@ -67,3 +67,20 @@ def build_flag_nets(meta, case, device='cpu'):
         G.to(device)
         D.to(device)
     return G, D
+
+
+def grads_by_name(net):
+    """{parameter name: clone of its gradient} (after a device sync) for every parameter that has one."""
+    torch.cuda.synchronize()
+    return {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
+
+
+def assert_same_contributions(ga, gb, tol=5e-3):
+    """Two runs of the same backward pass that differ only in stream placement / launch grouping: every parameter must have
+    received the same contributions.  Not bit-wise: small layers take split-K forward launches whose atomic order flips a few
+    LeakyReLU branches (1e-5 .. 3e-4 on a gradient tensor, measured), but a DROPPED or doubled contribution of one layer is an
+    O(1) relative error of that layer's tensor, which a bound on the whole buffer would hide for a bias or an RGB layer."""
+    assert sorted(ga) == sorted(gb)
+    for k in ga:
+        a, b = ga[k].double(), gb[k].double()
+        assert float((a - b).norm()) <= tol * float(b.norm()) + 1e-12, (k, float((a - b).norm() / (b.norm() + 1e-30)))

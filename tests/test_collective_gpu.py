@@ -17,6 +17,7 @@ import torch
 
 import pggan_amd as pg
 from pggan_amd import _lib
+from helpers import assert_same_contributions, grads_by_name
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -120,7 +121,7 @@ def _train(parallel, buckets, monkeypatch, iters=3):
     grads = []
     for _ in range(iters):
         tr.train()
-        grads.append((D._flat_grad.clone(), G._flat_grad.clone()))
+        grads.append((grads_by_name(D), grads_by_name(G)))
     torch.cuda.synchronize()
     assert tr.cur_nimg == 4 * iters
     return G._flat_param.clone(), D._flat_param.clone(), grads
@@ -141,6 +142,7 @@ def test_trainer_with_one_rank_communicator_matches_plain_trainer(dp, monkeypatc
     for name, ref, got in (('G bucketed', g0, g1), ('D bucketed', d0, d1), ('G flush', g0, g2), ('D flush', d0, d2)):
         assert float((got - ref).abs().max()) <= 2 * 0.001 * 3 + 1e-6, name
         assert float((got - ref).norm() / ref.norm()) < 1e-3, name
-    for other in (gr1, gr2):                     # first iteration: identical weights, so the gradients must agree tightly
-        for a, b in zip(gr0[0], other[0]):
-            assert float((a - b).norm() / b.norm()) < 1e-5
+    for other in (gr1, gr2):                     # first iteration: every layer received the same contributions
+        assert_same_contributions(other[0][0], gr0[0][0])
+        # (G's gradients go through D AFTER its first update, where a sign-like Adam has turned round-off noise into +-lr)
+        assert_same_contributions(other[0][1], gr0[0][1], tol=5e-2)

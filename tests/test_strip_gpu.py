@@ -1,0 +1,151 @@
+"""Row-streaming kernels of the 8/16-channel 1024^2 layers (csrc/conv_strip.hip) on the MI355X.
+
+conv_strip_kernel serves the same C-ABI entry points as the tile kernel it replaces (pg_conv2d_nhwc, pg_conv2d_pool_nhwc,
+pg_conv2d_pixelnorm_nhwc, pg_conv2d_pnbwd_nhwc for 3x3 / pad 1 / 8 couts / 8 or 16 input channels; reference network.py:33-36
+and its adjoint forms) with the SAME MFMA accumulation order, so for every fused epilogue its result must be BIT-IDENTICAL to
+the tile kernel's (selected with pg_debug_set_tuning(3, 20)) and within fp32 round-off of the torch-CPU statement of the
+contract (tests/emu_ops.py).  Shapes: every strip / segment geometry the launcher can pick (64 .. 512 wide, 1 .. 9 images,
+segments of 16 / 32 / 64 rows), image borders on all four sides of a strip, the x2-upsample gather."""
+import numpy as np
+import pytest
+import torch
+
+import emu_ops as E
+from conftest import rel_err
+
+import pggan_amd as pg
+
+pytestmark = pytest.mark.gpu
+ops = pg.ops
+lib = pg._lib.load()
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g)
+
+
+def last_kernel():
+    return lib.pg_debug_last_conv_kernel().decode()
+
+
+class tile_kernel(object):
+    """``with tile_kernel():`` launches go to conv_thin_kernel (the A/B switch of the dispatcher)."""
+    def __enter__(self):
+        assert lib.pg_debug_set_tuning(3, 20) == 0
+
+    def __exit__(self, *exc):
+        lib.pg_debug_set_tuning(3, -1)
+        return False
+
+
+def both(fn):
+    """fn() through the strip kernel and through the tile kernel; asserts that each really ran."""
+    a = fn()
+    assert last_kernel().startswith('conv_strip_kernel'), last_kernel()
+    with tile_kernel():
+        b = fn()
+        assert last_kernel().startswith('conv_thin_kernel'), last_kernel()
+    torch.cuda.synchronize()
+    return a, b
+
+
+def same(a, b):
+    """Strip vs tile kernel: same MFMA order, so the results agree to the last bits — up to the one place where hipcc may or may
+    not contract ``acc * scale + bias`` into an FMA in the two kernels (1 ulp); integer outputs (sign bytes) must be equal."""
+    if isinstance(a, (tuple, list)):
+        return all(same(x, y) for x, y in zip(a, b))
+    if a is None or b is None:
+        return a is None and b is None
+    if a.dtype == torch.uint8:
+        return float((a != b).float().mean()) < 1e-5          # (a value within 1 ulp of zero may take the other sign)
+    return rel_err(a, b) < 1e-6
+
+
+CASES = [(1, 64, 64, 8, 8), (2, 128, 128, 8, 8), (3, 256, 256, 8, 8), (1, 64, 64, 16, 8), (2, 128, 128, 16, 8),
+         (9, 64, 64, 8, 8), (1, 512, 512, 8, 8), (1, 256, 256, 16, 8)]      # N, H, W, Cin, Cout
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_strip_equals_tile_kernel_and_contract(case):
+    N, H, W, ci, co = case
+    assert H == W
+    x, w, b = rnd(N, H, H, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    m = rnd(N, H, H, co, seed=3)
+    md, mb = m.cuda(), E.signbytes_of(m).cuda()
+    # forward (bias + LeakyReLU), masked linear map with fp32 / byte masks, linear
+    s, t = both(lambda: ops.conv2d(xd, wd, bd, N, H, H, 3, 1, 0.37, slope=0.2))
+    assert same(s, t) and rel_err(s, E.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2)) < 2e-5
+    s, t = both(lambda: ops.conv2d(xd, wd, None, N, H, H, 3, 1, 0.37, mask=md, mask_slope=0.2))
+    assert same(s, t) and rel_err(s, E.conv2d(x, w, None, N, H, H, 3, 1, 0.37, mask=m, mask_slope=0.2)) < 2e-5
+    s2, t2 = both(lambda: ops.conv2d(xd, wd, None, N, H, H, 3, 1, 0.37, mask=mb, mask_slope=0.2))
+    assert same(s2, t2) and same(s2, s)
+    s, t = both(lambda: ops.conv2d(xd, wd, bd, N, H, H, 3, 1, 0.4, 0.2, signs_out=True))
+    assert same(s, t) and torch.equal(s[1].cpu(), E.signbytes_of(s[0].cpu()))        # (bytes consistent with the SAME launch's y: exact)
+    # PixelNorm epilogue and the adjoint of (LeakyReLU -> PixelNorm)
+    s, t = both(lambda: ops.conv2d_pixelnorm(xd, wd, bd, N, H, H, 3, 1, 0.37, 0.2, 1e-8))
+    assert same(s, t)
+    yref, rref = E.conv2d_pixelnorm(x, w, b, N, H, H, 3, 1, 0.37, 0.2, 1e-8) if hasattr(E, 'conv2d_pixelnorm') else (None, None)
+    if yref is not None:
+        assert rel_err(s[0], yref) < 2e-5 and rel_err(s[1], rref) < 2e-5
+    ys, rs = s
+    g = rnd(N, H, H, ci, seed=5).cuda()
+    wt = (rnd(3, 3, co, ci, seed=6) * 0.2).cuda()
+    s, t = both(lambda: ops.conv2d_pnbwd(g, wt, ys, rs, N, H, H, 3, 1, 0.3, 0.2))
+    assert same(s, t)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 8, 8), (1, 128, 16, 8), (3, 128, 8, 8), (1, 256, 8, 8)])
+def test_strip_pool_epilogues(case):
+    N, H, ci, co = case
+    x, w, b = rnd(N, H, H, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    other = rnd(N, H // 2, H // 2, co, seed=4).cuda()
+    m = rnd(N, H, H, co, seed=3)
+    md = m.cuda()
+    s, t = both(lambda: ops.conv2d_pool(xd, wd, bd, N, H, H, 3, 1, 0.37, 0.2))
+    assert same(s, t)
+    ref = E.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2)
+    assert rel_err(s[0], ref) < 2e-5 and rel_err(s[1], E.avgpool2_fwd(ref, None, 1.0, 0.0)) < 2e-5
+    s, t = both(lambda: ops.conv2d_pool(xd, wd, bd, N, H, H, 3, 1, 0.37, 0.2, other=other, a=0.3, b=0.7))
+    assert same(s, t) and rel_err(s[1], E.avgpool2_fwd(ref, other.cpu(), 0.3, 0.7)) < 2e-5
+    s, t = both(lambda: ops.conv2d_pool(xd, wd, None, N, H, H, 3, 1, 0.37, 1.0, mask=md, mask_slope=0.2, other=other, a=0.3, b=0.7,
+                                        pool_only=True))
+    assert same(s[1], t[1])
+    tref = E.conv2d(x, w, None, N, H, H, 3, 1, 0.37, mask=m, mask_slope=0.2)
+    assert rel_err(s[1], E.avgpool2_fwd(tref, other.cpu(), 0.3, 0.7)) < 2e-5
+
+
+@pytest.mark.parametrize('case', [(2, 64, 16, 8), (1, 128, 8, 8), (2, 256, 16, 8)])
+def test_strip_upsampled_gather(case):
+    """nearest x2 upsample fused into the row gather (the generator's c1 layers, network.py:62-66)."""
+    N, H, ci, co = case
+    x, w, b = rnd(N, H // 2, H // 2, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    s, t = both(lambda: ops.conv2d(x.cuda(), w.cuda(), b.cuda(), N, H, H, 3, 1, 0.37, slope=0.2, ups=True))
+    assert same(s, t) and rel_err(s, E.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2, ups=True)) < 2e-5
+    s, t = both(lambda: ops.conv2d_pixelnorm(x.cuda(), w.cuda(), b.cuda(), N, H, H, 3, 1, 0.37, 0.2, 1e-8, ups=True))
+    assert same(s, t)
+
+
+def test_strip_segment_geometries(monkeypatch):
+    """The launcher picks 16 / 32 / 64-row segments from the launch size; every choice must give the same result (each image
+    row is the last row of one segment and the halo of the next in one of them)."""
+    N, H, ci, co = 2, 256, 8, 8
+    x, w, b = rnd(N, H, H, ci).cuda(), (rnd(3, 3, co, ci, seed=1) * 0.2).cuda(), rnd(co, seed=2).cuda()
+    with tile_kernel():
+        ref = ops.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2)
+    y = ops.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2)
+    assert last_kernel().startswith('conv_strip_kernel') and same(y, ref)
+    # small launches (few strips) fall to 16-row segments, large ones keep 64: N = 1 @64 (1 strip) .. N = 9 @512 (72 strips)
+    for n, h in ((1, 64), (9, 512)):
+        xx = rnd(n, h, h, ci, seed=7).cuda()
+        with tile_kernel():
+            r = ops.conv2d(xx, w, b, n, h, h, 3, 1, 0.37, slope=0.2)
+        assert same(ops.conv2d(xx, w, b, n, h, h, 3, 1, 0.37, slope=0.2), r)
+
+
+def test_shapes_outside_the_strip_kernel_keep_the_tile_kernel():
+    x, w, b = rnd(2, 32, 32, 8).cuda(), (rnd(3, 3, 8, 8, seed=1) * 0.2).cuda(), rnd(8, seed=2).cuda()
+    ops.conv2d(x, w, b, 2, 32, 32, 3, 1, 0.37, slope=0.2)              # 32 columns: narrower than a strip
+    assert last_kernel().startswith('conv_thin_kernel'), last_kernel()
