@@ -1771,6 +1771,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgP p)
 template <int BPX>
 int launch_wgrad_thin(WgP& p, hipStream_t s)
 {
+    if (g_tune[1] != 20) {                        // row-streaming kernel (conv_strip.hip) where the shape allows; 20: tile kernel (A/B)
+        const int rc = pgk::launch_wgrad_strip(p, s, g_last_kernel, sizeof(g_last_kernel));
+        if (rc != PG_E_UNSUP) return rc;
+    }
     TileGeom g = make_geom(p.N, p.Hout, p.Wout, BPX);
     p.lgTW = g.lgTW; p.lgTH = g.lgTH; p.TN = g.TN; p.tilesW = g.tilesW; p.tilesH = g.tilesH; p.ntiles = g.ntiles;
     const int HT = (1 << g.lgTH) + 2, WT = (1 << g.lgTW) + 2;

@@ -391,6 +391,192 @@ int launch_strip_epi(const SArgs& a, int epi, int N, hipStream_t s, char* name, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight (+ bias) gradient of the same layers, row-streaming form:  dW[tap][co][ci] += scale * sum_pixels gz[p][co] x[p + tap][ci]
+// (the autograd of F.conv2d network.py:34 wrt its weight; replaces conv_wgrad_thin_kernel where the shape allows).
+// The tile kernel stages 16 x 4-pixel tiles (2.25x halo over-fetch of x from L2, ~8000 cycles per tile for ~1200 of MFMA work, the
+// k-step -> LDS address map re-derived per tile).  Here a workgroup walks down a strip of 64 columns: x rows (with the one-column
+// halo) and gz rows enter LDS once through LDS-DMA rings, wave w contracts row w of the step with v_mfma_f32_4x4x1_16B_f32
+// (block = (cout quad, cin quad, pixel slot), 16 / NB pixels per instruction), and the nine tap accumulators stay in registers
+// for the WHOLE strip: one cross-wave reduction and one atomic commit per workgroup.
+//   * pixel slots walk CONSECUTIVE pixels of their 16- (32-) pixel range of the row, so of the nine x operands of a k-step six
+//     are the previous k-steps' registers: 4 ds_read_b32 per 9 MFMAs instead of 10;
+//   * LDS: plane q = channels 4q..4q+3; inside a plane row the ranges are interleaved (slot = PPM * u + s, each range with its own
+//     two halo pixels: the DMA source address is per lane, duplicates cost nothing) and the plane stride is 32 bytes off a
+//     multiple of 128: the 32-lane groups of every ds_read_b32 hit 32 different banks.
+struct WArgs { const float* x; const float* gz; float* dw; float* db; float scale; int H, W, ups, strips, segs, seg_rows; };
+
+template <int CO, int CI>
+__global__ __launch_bounds__(256, 2) void wgrad_strip_kernel(WArgs p)
+{
+    constexpr int TAPS = 9;
+    constexpr int QO = CO / 4, QI = CI / 4, NB = QO * QI, PPM = 16 / NB, RNG = SW / PPM;   // NB blocks per pixel, PPM pixel slots per MFMA
+    static_assert(NB == 4 || NB == 8, "8x8, 16x8 or 8x16 channels");
+    constexpr int XU = RNG + 2, XRS = PPM * XU;              // x: pixels of a range incl. halo; slots of a plane row (72 / 68)
+    constexpr int XBS = 320, GBS = RB * SW;                  // slots of one (plane, block): x 4 XRS <= 5 DMA instructions; gz 4 x 64
+    static_assert(RB * XRS <= XBS, "");
+    constexpr int XRING = 3, GRING = 2;
+    constexpr int XPS = XRING * XBS + 2, GPS = GRING * GBS + 2;   // plane strides (slots): + 32 bytes -> planes 8 banks apart
+    constexpr int XNWI = QI * 5, GNWI = QO * RB, XNI = (XNWI + 3) / 4, GNI = (GNWI + 3) / 4;
+    extern __shared__ __align__(16) float lds[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    constexpr unsigned GLDS = (unsigned)QI * XPS * 16;       // byte offset of the gz ring
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = lane >> 2, i4 = lane & 3;
+    const int hi = blk % QI, ho = (blk / QI) % QO, slot = blk / NB;
+
+    int t = (int)pg_xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = __builtin_amdgcn_readfirstlane(t % p.strips); t /= p.strips;
+    const int seg = __builtin_amdgcn_readfirstlane(t % p.segs), n = __builtin_amdgcn_readfirstlane(t / p.segs);
+    const int r0 = seg * p.seg_rows, ow0 = strip * SW;
+    const int niter = p.seg_rows / RB;
+    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
+
+    // ---- DMA offsets.  x: instruction ii = (plane q, part 0..4) fills slots [part * 64, +64) of the (plane, block) area
+    const unsigned xrowbytes = 4u * (unsigned)(xW * CI), grow = 4u * (unsigned)(p.W * CO);
+    unsigned xvoff[XNI], xvstep[XNI], xdst[XNI], gvoff[GNI], gdst[GNI];
+    const unsigned xblkstep = (p.ups ? 2u : 4u) * xrowbytes;
+#pragma unroll
+    for (int i = 0; i < XNI; ++i) {
+        const int ii = i * 4 + wave, q = ii / 5, part = ii - q * 5;
+        const int idx = part * 64 + lane;
+        const int m = idx / XRS, e = idx - m * XRS, u = e / PPM, s = e - u * PPM;
+        const int col = ow0 + RNG * s + u - 1, row = r0 - 1 + m;
+        const bool ok = ii < XNWI && idx < RB * XRS && (unsigned)col < (unsigned)p.W;
+        xvoff[i] = ok ? (unsigned)(p.ups ? (row >> 1) : row) * xrowbytes + 4u * (unsigned)((p.ups ? (col >> 1) : col) * CI + 4 * q) : PG_OOB;
+        xvstep[i] = ok ? xblkstep : 0u;
+        xdst[i] = lds0 + (unsigned)(q * XPS + part * 64) * 16u;                  // + ring position * XBS * 16 (wave-uniform)
+    }
+#pragma unroll
+    for (int i = 0; i < GNI; ++i) {                              // gz: instruction jj = (plane q, row m): one row of 64 slots
+        const int jj = i * 4 + wave, q = jj / RB, m = jj - q * RB;
+        const int u = lane / PPM, s = lane - u * PPM;
+        const int col = ow0 + RNG * s + u, row = r0 + m;
+        gvoff[i] = jj < GNWI ? (unsigned)row * grow + 4u * (unsigned)(col * CO + 4 * q) : PG_OOB;
+        gdst[i] = lds0 + GLDS + (unsigned)(q * GPS + m * SW) * 16u;
+    }
+    const size_t ximg = (size_t)xH * xW * CI, gimg = (size_t)p.H * p.W * CO;
+    const pg_u32x4 rxs = rsrc_words(p.x + (size_t)n * ximg, (unsigned)(ximg * 4));
+    const pg_u32x4 rgs = rsrc_words(p.gz + (size_t)n * gimg, (unsigned)(gimg * 4));
+    auto dma16 = [&](const pg_u32x4& rs, unsigned vo, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo), "s"(rs), "s"(dst) : "memory");
+    };
+    auto issue_x = [&](int pos) {
+#pragma unroll
+        for (int i = 0; i < XNI; ++i) {
+            if (i * 4 + wave < XNWI) dma16(rxs, xvoff[i], __builtin_amdgcn_readfirstlane(xdst[i]) + (unsigned)pos * (XBS * 16u));
+            xvoff[i] += xvstep[i];
+        }
+    };
+    auto issue_g = [&](int pos) {
+#pragma unroll
+        for (int i = 0; i < GNI; ++i) {
+            if (i * 4 + wave < GNWI) dma16(rgs, gvoff[i], __builtin_amdgcn_readfirstlane(gdst[i]) + (unsigned)pos * (GBS * 16u));
+            gvoff[i] += 4u * grow;
+        }
+    };
+    issue_x(0); issue_g(0);
+    issue_x(1);
+
+    f32x4 acc[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    typedef __attribute__((address_space(3))) const float* lds_fptr;
+    const lds_cptr xl = (lds_cptr)lds + (hi * XPS + slot) * 16 + i4 * 4;
+    const lds_cptr gl = (lds_cptr)lds + GLDS + (ho * GPS + slot) * 16 + i4 * 4;
+
+    for (int it = 0; it < niter; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // x blocks it, it + 1 and gz block it have landed (this wave's share) ...
+        __syncthreads();                                          // ... everyone's; nobody still reads what the next DMAs overwrite
+        if (it + 2 <= niter) issue_x((it + 2) % XRING);
+        if (it + 1 < niter) issue_g((it + 1) % GRING);
+        __builtin_amdgcn_sched_barrier(0);
+        // row w of the step: ring rows of its three x rows (wave-uniform), then lane base + immediate offsets
+        const int rr0 = (RB * (it % XRING) + wave);
+        lds_cptr xb[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            int rr = rr0 + dy; if (rr >= RB * XRING) rr -= RB * XRING;
+            xb[dy] = xl + ((rr / RB) * XBS + (rr % RB) * XRS) * 16;
+        }
+        const lds_cptr gb = gl + ((it % GRING) * GBS + wave * SW) * 16;
+        float bcol[3][3];                                         // bcol[dy][c % 3] = x[row + dy][column c] of this lane's range
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            bcol[dy][0] = *(lds_fptr)(xb[dy] + 0 * PPM * 16);
+            bcol[dy][1] = *(lds_fptr)(xb[dy] + 1 * PPM * 16);
+        }
+#pragma unroll
+        for (int ks = 0; ks < RNG; ++ks) {
+            const float a = *(lds_fptr)(gb + ks * PPM * 16);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) bcol[dy][(ks + 2) % 3] = *(lds_fptr)(xb[dy] + (ks + 2) * PPM * 16);
+            bsum += a;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, bcol[dy][(ks + dx) % 3], acc[dy * 3 + dx], 0, 0, 0);
+        }
+    }
+
+    // ---- sum the pixel slots (lanes 4 NB apart), then the 4 waves through LDS, then ONE commit per workgroup
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[tp][r];
+            v += __shfl_xor(v, 32, 64);
+            if (PPM >= 4) v += __shfl_xor(v, 16, 64);
+            acc[tp][r] = v;
+        }
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (PPM >= 4) bsum += __shfl_xor(bsum, 16, 64);
+    constexpr int NL = 4 * NB, NE = TAPS * 4 + 1;               // lanes holding distinct results; values per lane: [tap * 4 + r | bias]
+    __syncthreads();                                             // (the rings are free: the reduction scratch aliases them)
+    float* red = lds;                                            // [wave][NE][NL]
+    if (lane < NL) {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * NE + tp * 4 + r) * NL + lane] = acc[tp][r];
+        red[(wave * NE + TAPS * 4) * NL + lane] = bsum;
+    }
+    __syncthreads();
+    for (int e = tid; e < NE * NL; e += 256) {
+        const int l = e % NL, ve = e / NL;
+        const float v = (red[e] + red[e + NE * NL]) + (red[e + 2 * NE * NL] + red[e + 3 * NE * NL]);
+        const int b_ = l >> 2, jj = l & 3;
+        const int hi_ = b_ % QI, ho_ = (b_ / QI) % QO;
+        if (ve < TAPS * 4) {                                     // D register r of lane 4 b + j = dW[tap][4 ho + r][4 hi + j]
+            const int tp = ve >> 2, r = ve & 3;
+            atomicAdd(p.dw + ((size_t)(tp * CO + 4 * ho_ + r) * CI + 4 * hi_ + jj), v * p.scale);
+        } else if (p.db && hi_ == 0) {                           // lane (ho, hi = 0, i) carries sum_p gz[p][4 ho + i]
+            atomicAdd(p.db + 4 * ho_ + jj, v);
+        }
+    }
+}
+
+template <int CO, int CI>
+int launch_wgrad_strip_t(const WArgs& a, int N, hipStream_t s, char* name, size_t name_len)
+{
+    constexpr int QO = CO / 4, QI = CI / 4;
+    const size_t smem = ((size_t)QI * (3 * 320 + 2) + (size_t)QO * (2 * RB * SW + 2)) * 16;
+    auto kern = wgrad_strip_kernel<CO, CI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return (int)hipGetLastError();
+        attr_done = true;
+    }
+    snprintf(name, name_len, "wgrad_strip_kernel<%d, %d>", CO, CI);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
@@ -426,4 +612,24 @@ int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
     return launch_strip_epi<8, 16, false>(a, epi, p.N, s, name, name_len);
 }
 
-int pgk::launch_wgrad_strip(WgP&, hipStream_t, char*, size_t) { return PG_E_UNSUP; }
+int pgk::launch_wgrad_strip(WgP& p, hipStream_t s, char* name, size_t name_len)
+{
+    static const int seg_env = getenv("PG_WSTRIP_SEG") ? atoi(getenv("PG_WSTRIP_SEG")) : 0;
+    if (p.pad != 1 || p.gbytes || p.Hout != p.Hin || p.Wout != p.Win) return PG_E_UNSUP;
+    if ((p.Wout % SW) || (p.Hout % 16)) return PG_E_UNSUP;
+    if (!((p.Cout == 8 && p.Cin == 8) || (p.Cout == 16 && p.Cin == 8) || (p.Cout == 8 && p.Cin == 16))) return PG_E_UNSUP;
+    if ((long long)p.Hin * p.Win * 16 * 4 >= (1ll << 31)) return PG_E_UNSUP;     // 32-bit byte offsets inside an image
+    // one commit of |dW| atomics per workgroup: few, long-lived workgroups -- ~1000 of them while the segments stay >= 64 rows
+    // (measured at 1024^2: 9 images 128 rows = 1152 workgroups 143 us, 256 rows 160 us, 64 rows 147 us), >= 512 below that
+    int seg = seg_env > 0 ? seg_env : 256;
+    auto tasks = [&](int sg) { return (long long)p.N * (p.Wout / SW) * (p.Hout / sg); };
+    while (seg > 64 && (seg > p.Hout || (p.Hout % seg) || tasks(seg) < 1024)) seg >>= 1;
+    while (seg > 16 && (seg > p.Hout || (p.Hout % seg) || tasks(seg) < 512)) seg >>= 1;
+    if (seg < 16 || (seg % RB) || (p.Hout % seg)) return PG_E_UNSUP;
+    WArgs a;
+    a.x = p.x; a.gz = p.gz; a.dw = p.dw; a.db = p.db; a.scale = p.scale;
+    a.H = p.Hout; a.W = p.Wout; a.ups = p.ups; a.strips = p.Wout / SW; a.segs = p.Hout / seg; a.seg_rows = seg;
+    if (p.Cout == 8 && p.Cin == 8) return launch_wgrad_strip_t<8, 8>(a, p.N, s, name, name_len);
+    if (p.Cout == 16 && p.Cin == 8) return launch_wgrad_strip_t<16, 8>(a, p.N, s, name, name_len);
+    return launch_wgrad_strip_t<8, 16>(a, p.N, s, name, name_len);
+}

@@ -149,3 +149,40 @@ def test_shapes_outside_the_strip_kernel_keep_the_tile_kernel():
     x, w, b = rnd(2, 32, 32, 8).cuda(), (rnd(3, 3, 8, 8, seed=1) * 0.2).cuda(), rnd(8, seed=2).cuda()
     ops.conv2d(x, w, b, 2, 32, 32, 3, 1, 0.37, slope=0.2)              # 32 columns: narrower than a strip
     assert last_kernel().startswith('conv_thin_kernel'), last_kernel()
+
+
+class tile_wgrad(object):
+    """``with tile_wgrad():`` weight-gradient launches go to conv_wgrad_thin_kernel (A/B switch of the dispatcher)."""
+    def __enter__(self):
+        assert lib.pg_debug_set_tuning(1, 20) == 0
+
+    def __exit__(self, *exc):
+        lib.pg_debug_set_tuning(1, -1)
+        return False
+
+
+@pytest.mark.parametrize('case', [(2, 64, 8, 8, 0), (1, 128, 8, 16, 0), (1, 128, 16, 8, 0), (3, 256, 8, 8, 0), (9, 64, 8, 8, 0),
+                                  (2, 128, 16, 8, 1), (1, 256, 8, 8, 1), (1, 512, 8, 8, 0), (1, 1024, 8, 8, 0)])
+def test_wgrad_strip_against_contract_and_tile_kernel(case):
+    """wgrad_strip_kernel (pg_conv2d_wgrad_nhwc for 3x3 / pad 1 layers with 8 / 16 channels on >= 64-wide maps): accumulates into dW
+    and db like the tile kernel, same result up to the order of the fp32 sums; the x2-upsample gather of the generator's c1 layers."""
+    N, H, ci, co, ups = case
+    hin = H // 2 if ups else H
+    x, gz = rnd(N, hin, hin, ci), rnd(N, H, H, co, seed=1)
+    dw0, db0 = rnd(3, 3, co, ci, seed=2), rnd(co, seed=3)
+    rdw, rdb = dw0.clone(), db0.clone()
+    E.conv2d_wgrad(x, gz, rdw, rdb, N, H, H, 3, 1, 0.41, ups=bool(ups))
+    dw, db = dw0.cuda(), db0.cuda()
+    ops.conv2d_wgrad(x.cuda(), gz.cuda(), dw, db, N, H, H, 3, 1, 0.41, ups=bool(ups))
+    assert last_kernel().startswith('wgrad_strip_kernel'), last_kernel()
+    assert rel_err(dw, rdw) < 2e-5 and rel_err(db, rdb) < 2e-5, (rel_err(dw, rdw), rel_err(db, rdb))
+    tdw, tdb = dw0.cuda(), db0.cuda()
+    with tile_wgrad():
+        ops.conv2d_wgrad(x.cuda(), gz.cuda(), tdw, tdb, N, H, H, 3, 1, 0.41, ups=bool(ups))
+        assert last_kernel().startswith('conv_wgrad_thin_kernel'), last_kernel()
+    assert rel_err(dw, tdw) < 1e-5 and rel_err(db, tdb) < 1e-5
+    # without a bias gradient (the tangent-term launches), accumulating twice
+    dw2 = dw0.cuda()
+    ops.conv2d_wgrad(x.cuda(), gz.cuda(), dw2, None, N, H, H, 3, 1, 0.41, ups=bool(ups))
+    ops.conv2d_wgrad(x.cuda(), gz.cuda(), dw2, None, N, H, H, 3, 1, 0.41, ups=bool(ups))
+    assert rel_err(dw2 - dw0.cuda(), 2 * (rdw - dw0)) < 2e-5
