@@ -62,6 +62,8 @@ struct SArgs {
     float scale, slope, mask_slope, pn_eps, pool_a, pool_b;
     int H, W, ups, mask_bytes, y_bytes, pool_only;
     int strips, segs, seg_rows;
+    // pool adjoint evaluated in the row gather (pg_conv2d_unpooled_nhwc): input[h][w][c] = gmul * x[h/2][w/2][c] * lrelu'(gbytes[h][w][c])
+    const unsigned char* gbytes; float gmul, gslope;
 };
 
 template <int CIN> struct Blk {
@@ -87,8 +89,10 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
                                            r, (int)voff, 0, 0);
 }
 
-template <int COUT, int CIN, int EPI, bool WREG>
-__global__ __launch_bounds__(256, WREG ? 3 : 4) void conv_strip_kernel(SArgs p)
+// GATH: the input rows are not copied but COMPUTED (pool adjoint of a coarser gradient x sign bytes of the finer activation): they
+// are fetched into registers one block ahead (under the MFMAs of the step), multiplied and written to the ring with ds_write_b128.
+template <int COUT, int CIN, int EPI, bool WREG, bool GATH>
+__global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_kernel(SArgs p)
 {
     using B = Blk<CIN>;
     constexpr int C4 = B::C4;
@@ -145,6 +149,48 @@ __global__ __launch_bounds__(256, WREG ? 3 : 4) void conv_strip_kernel(SArgs p)
         }
     };
 
+    // ---- gathered input (GATH): slot sl = i * 256 + tid of a block; running byte offsets into the coarse image and the sign bytes
+    constexpr int NG = GATH ? (B::USED + 255) / 256 : 1;
+    unsigned cvo[NG], cvs[NG], bvo[NG], bvs[NG];
+    float4 gxr[NG];
+    unsigned gbr[NG];
+    __amdgpu_buffer_rsrc_t rgx = pg_make_rsrc(p.x + (size_t)n * ximg, (unsigned)(ximg * 4)), rgb = rgx;
+    if constexpr (GATH) {
+        rgb = pg_make_rsrc(p.gbytes + (size_t)n * npix * C4, npix * C4);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int sl = i * 256 + tid;
+            const int q = sl / (RB * RP), rem = sl - q * (RB * RP);
+            const int m = rem / RP, px = rem - m * RP;
+            const int col = ow0 - 1 + px, row = r0 - 1 + m;
+            const bool ok = sl < B::USED && (unsigned)col < (unsigned)p.W;
+            cvo[i] = ok ? (unsigned)(row >> 1) * rowbytes + 4u * (unsigned)((col >> 1) * CIN + 4 * q) : PG_OOB;
+            cvs[i] = ok ? 2u * rowbytes : 0u;
+            bvo[i] = ok ? (unsigned)(row * p.W + col) * C4 + q : PG_OOB;
+            bvs[i] = ok ? (unsigned)(RB * p.W * C4) : 0u;
+        }
+    }
+    auto gather_load = [&]() {                                // the next block of four fine rows: coarse values + sign bytes -> registers
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            gxr[i] = pg_buf_load4(rgx, cvo[i], 0);
+            gbr[i] = __builtin_amdgcn_raw_buffer_load_b8(rgb, (int)bvo[i], 0, 0);
+            cvo[i] += cvs[i]; bvo[i] += bvs[i];
+        }
+    };
+    auto gather_store = [&](int pos) {                        // x (gmul x LeakyReLU' factor), into ring position pos
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int sl = i * 256 + tid;
+            if (sl < B::SLOTS) {
+                const float4 f = pg_sign_factors((unsigned char)gbr[i], p.gslope);
+                const float4 v = gxr[i];
+                *reinterpret_cast<float4*>(lds + (pos * B::SLOTS + sl) * 4) =
+                    make_float4(v.x * (f.x * p.gmul), v.y * (f.y * p.gmul), v.z * (f.z * p.gmul), v.w * (f.w * p.gmul));
+            }
+        }
+    };
+
     // ---- weights of this lane's cout row (4 qo + j): registers (Cin = 8, optional) or LDS
     float4 wreg[WREG ? 9 : 1][WREG ? C4 : 1];
     if constexpr (WREG) {
@@ -159,8 +205,13 @@ __global__ __launch_bounds__(256, WREG ? 3 : 4) void conv_strip_kernel(SArgs p)
     }
     const float* wrow = wl + (4 * qo + j) * CIN;
 
-    issue_block(0);
-    issue_block(1);
+    if constexpr (GATH) {
+        gather_load(); gather_store(0);
+        gather_load(); gather_store(1);
+    } else {
+        issue_block(0);
+        issue_block(1);
+    }
 
     const int rp = wave >> 1;                                     // row pair of the step owned by this wave
     const int col0 = (wave & 1) * 32;
@@ -344,14 +395,19 @@ __global__ __launch_bounds__(256, WREG ? 3 : 4) void conv_strip_kernel(SArgs p)
     const unsigned pixstep = (unsigned)(RB * p.W);
     auto step = [&](int it, auto ph_) {
         constexpr int PH = decltype(ph_)::value;
-        if (it == 0 || (PG_STRIP_ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else wait_dma();                                          // this wave's share of blocks it, it + 1 has landed ...
+        if constexpr (!GATH) {
+            if (it == 0 || (PG_STRIP_ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else wait_dma();                                      // this wave's share of blocks it, it + 1 has landed ...
+        }
         __syncthreads();                                          // ... everyone's has, and nobody still reads block it - 1
-        if (it + 2 <= niter && !((PG_STRIP_ABL & 1) && it > 0)) issue_block((PH + 2) % NBLK);   // (block niter: the two rows below the segment)
+        const bool more = it + 2 <= niter;                        // (block niter: the two rows below the segment)
+        if constexpr (GATH) { if (more) gather_load(); }
+        else if (more && !((PG_STRIP_ABL & 1) && it > 0)) issue_block((PH + 2) % NBLK);
         prefetch_epilogue(pix);
         __builtin_amdgcn_sched_barrier(0);
         if (rp == 0) compute(ph_, std::integral_constant<int, 0>{});
         else compute(ph_, std::integral_constant<int, 1>{});
+        if constexpr (GATH) { if (more) gather_store((PH + 2) % NBLK); }
         epilogue(pix);
         pix += pixstep;
     };
@@ -362,19 +418,19 @@ __global__ __launch_bounds__(256, WREG ? 3 : 4) void conv_strip_kernel(SArgs p)
     }
 }
 
-template <int COUT, int CIN, int EPI, bool WREG>
+template <int COUT, int CIN, int EPI, bool WREG, bool GATH = false>
 int launch_strip(const SArgs& a, int N, hipStream_t s, char* name, size_t name_len)
 {
     using B = Blk<CIN>;
     const size_t smem = (size_t)NBLK * B::SLOTS * 16 + (WREG ? 0 : (size_t)9 * COUT * CIN * 4);
-    auto kern = conv_strip_kernel<COUT, CIN, EPI, WREG>;
+    auto kern = conv_strip_kernel<COUT, CIN, EPI, WREG, GATH>;
     static bool attr_done = false;                                // (idempotent; a race only repeats the call)
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return (int)hipGetLastError();
         attr_done = true;
     }
-    snprintf(name, name_len, "conv_strip_kernel<%d, %d, %d, %s>", COUT, CIN, EPI, WREG ? "true" : "false");
+    snprintf(name, name_len, "conv_strip_kernel<%d, %d, %d, %s, %s>", COUT, CIN, EPI, WREG ? "true" : "false", GATH ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
     return (int)hipGetLastError();
 }
@@ -404,9 +460,10 @@ int launch_strip_epi(const SArgs& a, int epi, int N, hipStream_t s, char* name, 
 //   * LDS: plane q = channels 4q..4q+3; inside a plane row the ranges are interleaved (slot = PPM * u + s, each range with its own
 //     two halo pixels: the DMA source address is per lane, duplicates cost nothing) and the plane stride is 32 bytes off a
 //     multiple of 128: the 32-lane groups of every ds_read_b32 hit 32 different banks.
-struct WArgs { const float* x; const float* gz; float* dw; float* db; float scale; int H, W, ups, strips, segs, seg_rows; };
+struct WArgs { const float* x; const float* gz; float* dw; float* db; float scale; int H, W, ups, strips, segs, seg_rows;
+               const unsigned char* gbytes; float gmul, gslope; };   // pool adjoint in the gz gather (pg_conv2d_wgrad_unpooled_nhwc)
 
-template <int CO, int CI>
+template <int CO, int CI, bool GATH>
 __global__ __launch_bounds__(256, 2) void wgrad_strip_kernel(WArgs p)
 {
     constexpr int TAPS = 9;
@@ -455,9 +512,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_strip_kernel(WArgs p)
         gvoff[i] = jj < GNWI ? (unsigned)row * grow + 4u * (unsigned)(col * CO + 4 * q) : PG_OOB;
         gdst[i] = lds0 + GLDS + (unsigned)(q * GPS + m * SW) * 16u;
     }
-    const size_t ximg = (size_t)xH * xW * CI, gimg = (size_t)p.H * p.W * CO;
+    const size_t ximg = (size_t)xH * xW * CI, gimg = GATH ? (size_t)(p.H >> 1) * (p.W >> 1) * CO : (size_t)p.H * p.W * CO;
     const pg_u32x4 rxs = rsrc_words(p.x + (size_t)n * ximg, (unsigned)(ximg * 4));
     const pg_u32x4 rgs = rsrc_words(p.gz + (size_t)n * gimg, (unsigned)(gimg * 4));
+    // GATH: gz[h][w][c] = gmul * g[h/2][w/2][c] * lrelu'(sign byte of a2[h][w][c]) is computed on the way into the ring: thread tid
+    // owns slot tid of every (plane, block) area; values are fetched one block ahead and written with ds_write_b128 after the MFMAs
+    constexpr int NGZ = GATH ? QO : 1;
+    unsigned cvo[NGZ], bvo[NGZ];
+    float4 gxr[NGZ];
+    unsigned gbr[NGZ];
+    __amdgpu_buffer_rsrc_t rgc = pg_make_rsrc(p.gz + (size_t)n * gimg, (unsigned)(gimg * 4)), rgb = rgc;
+    if constexpr (GATH) {
+        rgb = pg_make_rsrc(p.gbytes + (size_t)n * p.H * p.W * QO, (unsigned)(p.H * p.W * QO));
+        const int m = tid >> 6, e = tid & 63, u = e / PPM, s = e - u * PPM;
+        const int col = ow0 + RNG * s + u, row = r0 + m;
+#pragma unroll
+        for (int q = 0; q < NGZ; ++q) {
+            cvo[q] = 4u * (unsigned)(((row >> 1) * (p.W >> 1) + (col >> 1)) * CO + 4 * q);
+            bvo[q] = (unsigned)(row * p.W + col) * QO + q;
+        }
+    }
+    auto gather_load = [&]() {
+#pragma unroll
+        for (int q = 0; q < NGZ; ++q) {
+            gxr[q] = pg_buf_load4(rgc, cvo[q], 0);
+            gbr[q] = __builtin_amdgcn_raw_buffer_load_b8(rgb, (int)bvo[q], 0, 0);
+            cvo[q] += 2u * 4u * (unsigned)((p.W >> 1) * CO); bvo[q] += (unsigned)(RB * p.W * QO);
+        }
+    };
+    auto gather_store = [&](int pos) {
+#pragma unroll
+        for (int q = 0; q < NGZ; ++q) {
+            const float4 f = pg_sign_factors((unsigned char)gbr[q], p.gslope);
+            const float4 v = gxr[q];
+            *reinterpret_cast<float4*>(lds + GLDS / 4 + ((q * GPS + pos * GBS) + tid) * 4) =
+                make_float4(v.x * (f.x * p.gmul), v.y * (f.y * p.gmul), v.z * (f.z * p.gmul), v.w * (f.w * p.gmul));
+        }
+    };
     auto dma16 = [&](const pg_u32x4& rs, unsigned vo, unsigned dst) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -477,7 +568,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_strip_kernel(WArgs p)
             gvoff[i] += 4u * grow;
         }
     };
-    issue_x(0); issue_g(0);
+    issue_x(0);
+    if constexpr (GATH) { gather_load(); gather_store(0); } else issue_g(0);
     issue_x(1);
 
     f32x4 acc[TAPS];
@@ -492,7 +584,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_strip_kernel(WArgs p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // x blocks it, it + 1 and gz block it have landed (this wave's share) ...
         __syncthreads();                                          // ... everyone's; nobody still reads what the next DMAs overwrite
         if (it + 2 <= niter) issue_x((it + 2) % XRING);
-        if (it + 1 < niter) issue_g((it + 1) % GRING);
+        if constexpr (GATH) { if (it + 1 < niter) gather_load(); }
+        else if (it + 1 < niter) issue_g((it + 1) % GRING);
         __builtin_amdgcn_sched_barrier(0);
         // row w of the step: ring rows of its three x rows (wave-uniform), then lane base + immediate offsets
         const int rr0 = (RB * (it % XRING) + wave);
@@ -521,6 +614,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_strip_kernel(WArgs p)
                 for (int dx = 0; dx < 3; ++dx)
                     acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, bcol[dy][(ks + dx) % 3], acc[dy * 3 + dx], 0, 0, 0);
         }
+        if constexpr (GATH) { if (it + 1 < niter) gather_store((it + 1) % GRING); }
     }
 
     // ---- sum the pixel slots (lanes 4 NB apart), then the 4 waves through LDS, then ONE commit per workgroup
@@ -560,19 +654,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_strip_kernel(WArgs p)
     }
 }
 
-template <int CO, int CI>
+template <int CO, int CI, bool GATH = false>
 int launch_wgrad_strip_t(const WArgs& a, int N, hipStream_t s, char* name, size_t name_len)
 {
     constexpr int QO = CO / 4, QI = CI / 4;
     const size_t smem = ((size_t)QI * (3 * 320 + 2) + (size_t)QO * (2 * RB * SW + 2)) * 16;
-    auto kern = wgrad_strip_kernel<CO, CI>;
+    auto kern = wgrad_strip_kernel<CO, CI, GATH>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return (int)hipGetLastError();
         attr_done = true;
     }
-    snprintf(name, name_len, "wgrad_strip_kernel<%d, %d>", CO, CI);
+    snprintf(name, name_len, "wgrad_strip_kernel<%d, %d, %s>", CO, CI, GATH ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
     return (int)hipGetLastError();
 }
@@ -584,7 +678,7 @@ int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
     static const int seg_env = getenv("PG_STRIP_SEG") ? atoi(getenv("PG_STRIP_SEG")) : 0;
     static const int wreg_env = getenv("PG_STRIP_WREG") ? atoi(getenv("PG_STRIP_WREG")) : 0;
     static const int epi_env = getenv("PG_STRIP_EPI") ? atoi(getenv("PG_STRIP_EPI")) : -1;      // 0: always the generic epilogue (A/B)
-    if (p.KS != 3 || p.pad != 1 || p.gbytes || p.yup || p.ksplit != 1) return PG_E_UNSUP;
+    if (p.KS != 3 || p.pad != 1 || p.yup || p.ksplit != 1) return PG_E_UNSUP;
     if ((p.Wout % SW) || (p.Hout % 16) || p.Hout != p.Hin || p.Wout != p.Win) return PG_E_UNSUP;
     if (!(p.Cout == 8 && (p.Cin == 8 || p.Cin == 16))) return PG_E_UNSUP;       // (16 couts: the tile / Winograd kernels keep those layers)
     if ((long long)p.Hin * p.Win * 16 * 4 >= (1ll << 31)) return PG_E_UNSUP;     // 32-bit byte offsets inside an image
@@ -598,6 +692,14 @@ int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
     a.scale = p.scale; a.slope = p.slope; a.mask_slope = p.mask_slope; a.pn_eps = p.pn_eps; a.pool_a = p.pool_a; a.pool_b = p.pool_b;
     a.H = p.Hout; a.W = p.Wout; a.ups = p.ups; a.mask_bytes = p.mask_bytes; a.y_bytes = p.y_bytes; a.pool_only = p.pool_only;
     a.strips = p.Wout / SW; a.segs = p.Hout / seg; a.seg_rows = seg;
+    a.gbytes = p.gbytes; a.gmul = p.gmul; a.gslope = p.gslope;
+    if (p.gbytes) {                              // pool adjoint in the gather (backward-data conv of a DBlock's c2): masked or plain
+        if (!p.ups || p.bias || p.ypool || p.y_bytes || p.pnb_y || p.pn_r || p.ysigns) return PG_E_UNSUP;
+        if (p.Cin == 8) return p.mask ? launch_strip<8, 8, EPI_MASK, false, true>(a, p.N, s, name, name_len)
+                                      : launch_strip<8, 8, EPI_FWD, false, true>(a, p.N, s, name, name_len);
+        return p.mask ? launch_strip<8, 16, EPI_MASK, false, true>(a, p.N, s, name, name_len)
+                      : launch_strip<8, 16, EPI_FWD, false, true>(a, p.N, s, name, name_len);
+    }
     int epi = EPI_GENERIC;
     if (!p.ypool && !p.y_bytes) {
         if (p.pnb_y && !p.mask && !p.pn_r && !p.ysigns) epi = EPI_PNB;
@@ -615,7 +717,7 @@ int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
 int pgk::launch_wgrad_strip(WgP& p, hipStream_t s, char* name, size_t name_len)
 {
     static const int seg_env = getenv("PG_WSTRIP_SEG") ? atoi(getenv("PG_WSTRIP_SEG")) : 0;
-    if (p.pad != 1 || p.gbytes || p.Hout != p.Hin || p.Wout != p.Win) return PG_E_UNSUP;
+    if (p.pad != 1 || p.Hout != p.Hin || p.Wout != p.Win || (p.gbytes && p.ups)) return PG_E_UNSUP;
     if ((p.Wout % SW) || (p.Hout % 16)) return PG_E_UNSUP;
     if (!((p.Cout == 8 && p.Cin == 8) || (p.Cout == 16 && p.Cin == 8) || (p.Cout == 8 && p.Cin == 16))) return PG_E_UNSUP;
     if ((long long)p.Hin * p.Win * 16 * 4 >= (1ll << 31)) return PG_E_UNSUP;     // 32-bit byte offsets inside an image
@@ -629,6 +731,12 @@ int pgk::launch_wgrad_strip(WgP& p, hipStream_t s, char* name, size_t name_len)
     WArgs a;
     a.x = p.x; a.gz = p.gz; a.dw = p.dw; a.db = p.db; a.scale = p.scale;
     a.H = p.Hout; a.W = p.Wout; a.ups = p.ups; a.strips = p.Wout / SW; a.segs = p.Hout / seg; a.seg_rows = seg;
+    a.gbytes = p.gbytes; a.gmul = p.gmul; a.gslope = p.gslope;
+    if (p.gbytes) {
+        if (p.Cout == 8 && p.Cin == 8) return launch_wgrad_strip_t<8, 8, true>(a, p.N, s, name, name_len);
+        if (p.Cout == 16 && p.Cin == 8) return launch_wgrad_strip_t<16, 8, true>(a, p.N, s, name, name_len);
+        return launch_wgrad_strip_t<8, 16, true>(a, p.N, s, name, name_len);
+    }
     if (p.Cout == 8 && p.Cin == 8) return launch_wgrad_strip_t<8, 8>(a, p.N, s, name, name_len);
     if (p.Cout == 16 && p.Cin == 8) return launch_wgrad_strip_t<16, 8>(a, p.N, s, name, name_len);
     return launch_wgrad_strip_t<8, 16>(a, p.N, s, name, name_len);

@@ -186,3 +186,34 @@ def test_wgrad_strip_against_contract_and_tile_kernel(case):
     ops.conv2d_wgrad(x.cuda(), gz.cuda(), dw2, None, N, H, H, 3, 1, 0.41, ups=bool(ups))
     ops.conv2d_wgrad(x.cuda(), gz.cuda(), dw2, None, N, H, H, 3, 1, 0.41, ups=bool(ups))
     assert rel_err(dw2 - dw0.cuda(), 2 * (rdw - dw0)) < 2e-5
+
+
+@pytest.mark.parametrize('case', [(2, 64, 16, 8), (1, 128, 8, 8), (2, 128, 16, 8), (1, 256, 16, 8), (3, 256, 8, 8)])
+def test_strip_pool_adjoint_in_the_gather(case):
+    """pg_conv2d_unpooled_nhwc / pg_conv2d_wgrad_unpooled_nhwc on the row-streaming kernels: the pool adjoint (x 1/4 x mul x
+    LeakyReLU' sign byte) of the coarse gradient is evaluated on the way into the LDS ring (registers -> ds_write) instead of
+    being materialised at the fine resolution; against the materialised form (emu) and the tile kernels."""
+    N, H, cg, co = case                                  # g has cg channels at H/2; backward-data conv cg -> co
+    g, a2 = rnd(N, H // 2, H // 2, cg), rnd(N, H, H, cg, seed=1)
+    gb = E.signbytes_of(a2).cuda()
+    wt, a1 = rnd(3, 3, co, cg, seed=2) * 0.2, rnd(N, H, H, co, seed=3)
+    gz2 = E.avgpool2_bwd(g, a2, 0.7, 0.2)
+    ref = E.conv2d(gz2, wt, None, N, H, H, 3, 1, 0.3, mask=a1, mask_slope=0.2)
+    gd, wtd, a1b = g.cuda(), wt.cuda(), E.signbytes_of(a1).cuda()
+    s, t = both(lambda: ops.conv2d_unpooled(gd, wtd, gb, 0.25 * 0.7, 0.2, N, H, H, 0.3, mask=a1b, mask_slope=0.2))
+    assert same(s, t) and rel_err(s, ref) < 2e-5
+    s, t = both(lambda: ops.conv2d_unpooled(gd, wtd, gb, 0.25 * 0.7, 0.2, N, H, H, 0.3, mask=a1.cuda(), mask_slope=0.2))
+    assert same(s, t) and rel_err(s, ref) < 2e-5
+    # weight gradient of the forward conv co -> cg:  dw [3,3,cg,co] += sum gz2 (x) a1
+    dw0, db0 = rnd(3, 3, cg, co, seed=4), rnd(cg, seed=5)
+    rdw, rdb = dw0.clone(), db0.clone()
+    E.conv2d_wgrad(a1, gz2, rdw, rdb, N, H, H, 3, 1, 0.41)
+    dw, db = dw0.cuda(), db0.cuda()
+    ops.conv2d_wgrad_unpooled(a1.cuda(), gd, gb, 0.25 * 0.7, 0.2, dw, db, N, H, H, 0.41)
+    assert last_kernel().startswith('wgrad_strip_kernel'), last_kernel()
+    assert rel_err(dw, rdw) < 2e-5 and rel_err(db, rdb) < 2e-5
+    tdw, tdb = dw0.cuda(), db0.cuda()
+    with tile_wgrad():
+        ops.conv2d_wgrad_unpooled(a1.cuda(), gd, gb, 0.25 * 0.7, 0.2, tdw, tdb, N, H, H, 0.41)
+        assert last_kernel().startswith('conv_wgrad_thin_kernel'), last_kernel()
+    assert rel_err(dw, tdw) < 1e-5 and rel_err(db, tdb) < 1e-5
