@@ -387,6 +387,9 @@ int pg_allreduce_sum_f32(void* comm, float* buf, int64_t count, pg_stream_t stre
 
 /* Utility: async fill with zero bytes.                                                         */
 int pg_zero(void* p, int64_t bytes, pg_stream_t stream);
+/* n draws of U[0,1): replaces torch.cuda.FloatTensor(n, 1).uniform_() wgan_gp_loss.py:15-17 (the mixing factors of the gradient
+ * penalty).  Counter-based (Philox4x32-10): out[i] is a pure function of (seed, offset, i); the caller advances `offset` per draw. */
+int pg_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, pg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class PgganLibraryError(RuntimeError):
@@ -74,6 +74,7 @@ SIGNATURES = {
     'pg_image_grid_u8': [P, P, I, I, I, I, I, F, F, P],
     'pg_pyramid_level_u8': [P, P, L, I, I, I, F, F, P],
     'pg_zero': [P, L, P],
+    'pg_uniform_f32': [P, L, ctypes.c_uint64, ctypes.c_uint64, P],
     'pg_stft_abslog': [P, L, I, P, I, I, I, I, P],
     'pg_stft_image': [P, L, I, P, I, I, I, I, I, P],
     'pg_mono_f32': [P, L, I, P, L, P],

@@ -618,7 +618,7 @@ extern "C" int pg_signbytes_to_mask(const unsigned char* bytes, float* mask, int
     return (int)hipGetLastError();
 }
 
-extern "C" int pg_abi_version(void) { return 21; }
+extern "C" int pg_abi_version(void) { return 22; }
 
 extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
                                float a, float b, pg_stream_t stream)
@@ -820,6 +820,37 @@ extern "C" int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, 
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return PG_E_ALIGN;
     LAUNCH(adam_kernel, dim3(grid_for(((size_t)n + 3) >> 2, 256, 2048)), dim3(256), 0, stream, p, g, m, v, (size_t)n,
            lr / bc1, beta1, beta2, eps, 1.f / bc2_sqrt, grad_scale);
+}
+
+// U[0,1) draws for the gradient-penalty mixing factors (reference wgan_gp_loss.py:15-17: torch.cuda.FloatTensor(n, 1).uniform_()).
+// Counter-based Philox4x32-10 (Salmon et al. 2011): element i of draw number `offset` under `seed` is a pure function of (seed,
+// offset, i), so a step can be replayed and every rank draws its own stream; 24 random bits -> [0, 1) like torch's uniform_.
+__global__ void uniform_kernel(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long offset)
+{
+    const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one Philox block = 4 floats
+    if (4 * i4 >= n) return;
+    unsigned c0 = (unsigned)i4, c1 = (unsigned)((unsigned long long)i4 >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const unsigned c[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * i4 + j < n) out[4 * i4 + j] = (float)(c[j] >> 8) * (1.0f / 16777216.0f);
+}
+
+extern "C" int pg_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, pg_stream_t stream)
+{
+    if (!out || n <= 0) return PG_E_ARG;
+    const long long blocks = ((n + 3) / 4 + 255) / 256;
+    hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, (long long)n,
+                       (unsigned long long)seed, (unsigned long long)offset);
+    return (int)hipGetLastError();
 }
 
 extern "C" int pg_zero(void* p, int64_t bytes, pg_stream_t stream)

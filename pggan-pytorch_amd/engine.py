@@ -81,17 +81,35 @@ def _derived(net):
     base = net._flat_param.data_ptr()
     live = set(id(m) for m in _live_conv_layers(net))
     todo = [m for m in net._layers() if m.kind == 'conv' and m._wt is not None and id(m) in live]
-    ops.pack_dgrad_weights_batched(net._flat_param, net._flat_wt,
-                                   [((m.conv.weight.data_ptr() - base) // 4, m.ksize, m.conv.weight.shape[2],
-                                     m.conv.weight.shape[3]) for m in todo])
+    packs = [((m.conv.weight.data_ptr() - base) // 4, m.ksize, m.conv.weight.shape[2], m.conv.weight.shape[3]) for m in todo]
     # ... and of those only the layers the Winograd path has actually asked for (_wino marks them): the 512-channel layers of the
     # 4x4 / 8x8 stages never reach the workgroup threshold at the reference minibatches, yet are half of all Winograd-domain bytes
     wl = [(m, woff, uoff) for m, woff, uoff in (net._wino_layers or []) if id(m) in live and getattr(m, '_wino_wanted', False)]
-    if USE_WINOGRAD and wl:
+    wl = wl if USE_WINOGRAD else []
+
+    def backward_copies():                       # what only the backward-data convs read: flipped / transposed weights and their Winograd form
+        ops.pack_dgrad_weights_batched(net._flat_param, net._flat_wt, packs)
+        if wl:
+            ops.wino_transform_weights_batched(net._flat_wt, net._flat_wtu,
+                                               [(woff, uoff, m.conv.weight.shape[3], m.conv.weight.shape[2]) for m, woff, uoff in wl])
+    if wl:                                       # the forward convs' Winograd-domain weights: needed by the very next launch
         ops.wino_transform_weights_batched(net._flat_param, net._flat_wu,
                                            [(woff, uoff, m.conv.weight.shape[2], m.conv.weight.shape[3]) for m, woff, uoff in wl])
-        ops.wino_transform_weights_batched(net._flat_wt, net._flat_wtu,
-                                           [(woff, uoff, m.conv.weight.shape[3], m.conv.weight.shape[2]) for m, woff, uoff in wl])
+    # The backward copies are not needed before the network's next backward sweep (milliseconds away): off the critical path, onto
+    # the weight-gradient stream, unless this already IS that stream (the deferred D update) or a hipGraph is being captured
+    net._derived_bwd_ev = None
+    dev = torch.cuda.current_device() if net._flat_param.is_cuda else None
+    cur = torch.cuda.current_stream(torch._C._cuda_getDevice()) if dev is not None else None
+    if (ASYNC_WGRAD and ASYNC_DERIVED and dev is not None and cur != _SIDE.get(dev) and not torch.cuda.is_current_stream_capturing()):
+        side = _side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            backward_copies()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        net._derived_bwd_ev = ev
+    else:
+        backward_copies()
     net._derived_ver = key
     net._derived_live = live
 
@@ -103,10 +121,18 @@ def _assert_live(net, layer):
         raise RuntimeError('derived weights requested for a conv layer that is not live at depth %d' % int(net.depth))
 
 
+def _await_backward_copies(net):
+    ev = net.__dict__.get('_derived_bwd_ev')
+    if ev is not None:
+        torch.cuda.current_stream(torch._C._cuda_getDevice()).wait_event(ev)
+        net._derived_bwd_ev = None
+
+
 def _wt(net, layer):
     """Backward-data (flipped/transposed) copy of a conv layer's weights, refreshed lazily."""
     _derived(net)
     _assert_live(net, layer)
+    _await_backward_copies(net)
     return layer._wt
 
 
@@ -125,6 +151,8 @@ def _wino(layer, N, H, cout, transposed=False):
         net._derived_ver = None
     _derived(net)
     _assert_live(net, layer)
+    if transposed:
+        _await_backward_copies(net)
     return layer._wtu if transposed else layer._wu
 
 
@@ -248,6 +276,7 @@ def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
 # they are launched on a second HIP stream and overlap the backward-data chain on the main stream: two
 # half-occupancy MFMA kernels share the CUs instead of running back to back.
 ASYNC_WGRAD = True
+ASYNC_DERIVED = _os.environ.get('PGGAN_ASYNC_DERIVED', '1') != '0'
 _SIDE = {}
 
 

@@ -297,6 +297,7 @@ class _FlatParamsMixin(object):
         d['_lin_gw'] = d['_lin_gb'] = d['_lin_layer'] = None
         d['_grad_hook'] = d['_grad_exchange'] = None
         d['_plist'] = None
+        d['_derived_bwd_ev'] = None
         return d
 
     def __setstate__(self, state):

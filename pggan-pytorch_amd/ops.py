@@ -466,6 +466,13 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale=1.0):
     _lib.call('pg_adam', _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, _stream())
 
 
+def uniform_(t, seed, offset):
+    """Fill the fp32 device tensor with U[0,1) draws: element i = Philox4x32-10(seed, offset, i) (wgan_gp_loss.py:15-17)."""
+    require_gpu()
+    _lib.call('pg_uniform_f32', _p(t), t.numel(), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _stream())
+    return t
+
+
 def zero_(t):
     _lib.call('pg_zero', _p(t), t.numel() * 4, _stream())
     return t

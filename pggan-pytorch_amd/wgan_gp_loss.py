@@ -11,7 +11,7 @@ from . import engine
 
 # wgan_gp_loss.py:4-5 keeps module-global scratch; the only state kept here is the injectable RNG.
 mixing_factors = None
-_generator = None
+_seed = None                # (seed, number of draws so far) of the mixing-factor stream; None: seeded from torch's RNG at first use
 _use_graphs = 'auto'        # 'auto': replay only where the step is launch-bound (the 4x4 stage); True / False force it
 
 
@@ -40,10 +40,24 @@ def set_mixing_factors(m):
 
 
 def manual_seed(seed, device='cuda'):
-    """Seed the device generator the mixing factors are drawn from."""
-    global _generator
-    _generator = torch.Generator(device=device)
-    _generator.manual_seed(int(seed))
+    """Seed the stream the mixing factors are drawn from (counter-based: ``pg_uniform_f32(seed, draw number, element)``)."""
+    global _seed
+    _seed = [int(seed), 0]
+
+
+def _draw_mixing_factors(n, device):
+    """U[0,1) [n, 1] on the device (wgan_gp_loss.py:15-17) by the library's own generator: no ATen RNG launch inside the step."""
+    global _seed
+    if _seed is None:
+        _seed = [int(torch.initial_seed()), 0]
+    mix = torch.empty((n, 1), device=device, dtype=torch.float32)
+    if mix.is_cuda:
+        from . import ops
+        ops.uniform_(mix, _seed[0], _seed[1])
+    else:                                                                # (host emulation in the CPU test-suite only)
+        mix.copy_(torch.rand((n, 1), generator=torch.Generator().manual_seed(_seed[0] * 1000003 + _seed[1])))
+    _seed[1] += 1
+    return mix
 
 
 class LossTensor(torch.Tensor):
@@ -92,7 +106,7 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
         mix = mixing_factors.to(device=real_images_in.device, dtype=torch.float32).reshape(n, 1)
         mixing_factors = None
     else:                                                                # :15-17 (device RNG)
-        mix = torch.rand((n, 1), device=real_images_in.device, dtype=torch.float32, generator=_generator)
+        mix = _draw_mixing_factors(n, real_images_in.device)
     if _graphs_on(D) and float(D.alpha) >= 1.0 and real_images_in.is_cuda:
         from . import graphs
         real_c = engine._check_dev(real_images_in, 'real images')

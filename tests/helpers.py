@@ -75,12 +75,18 @@ def grads_by_name(net):
     return {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
 
 
-def assert_same_contributions(ga, gb, tol=5e-3):
+def assert_same_contributions(ga, gb, tol=0.1, total=5e-3):
     """Two runs of the same backward pass that differ only in stream placement / launch grouping: every parameter must have
     received the same contributions.  Not bit-wise: small layers take split-K forward launches whose atomic order flips a few
     LeakyReLU branches (1e-5 .. 3e-4 on a gradient tensor, measured), but a DROPPED or doubled contribution of one layer is an
     O(1) relative error of that layer's tensor, which a bound on the whole buffer would hide for a bias or an RGB layer."""
     assert sorted(ga) == sorted(gb)
+    num = den = 0.0
     for k in ga:
         a, b = ga[k].double(), gb[k].double()
+        # per tensor: a missing / doubled contribution is an error of ~1; a flipped branch below a small tensor (a bias of the
+        # 4x4 block) has been seen at 2e-2
         assert float((a - b).norm()) <= tol * float(b.norm()) + 1e-12, (k, float((a - b).norm() / (b.norm() + 1e-30)))
+        num += float((a - b).norm()) ** 2
+        den += float(b.norm()) ** 2
+    assert (num / max(den, 1e-300)) ** 0.5 <= total, (num / max(den, 1e-300)) ** 0.5

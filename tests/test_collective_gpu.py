@@ -145,4 +145,4 @@ def test_trainer_with_one_rank_communicator_matches_plain_trainer(dp, monkeypatc
     for other in (gr1, gr2):                     # first iteration: every layer received the same contributions
         assert_same_contributions(other[0][0], gr0[0][0])
         # (G's gradients go through D AFTER its first update, where a sign-like Adam has turned round-off noise into +-lr)
-        assert_same_contributions(other[0][1], gr0[0][1], tol=5e-2)
+        assert_same_contributions(other[0][1], gr0[0][1], tol=0.3, total=5e-2)

@@ -550,7 +550,7 @@ def test_deferred_d_update_matches_inline(monkeypatch):
     # (D's gradients: computed at identical weights.  G's are computed through D AFTER its first update, where a sign-like Adam
     #  has already turned the atomic-order noise of near-zero gradient elements into +-lr weight differences: loose bound)
     assert_same_contributions(f1[0], f0[0])
-    assert_same_contributions(f1[1], f0[1], tol=5e-2)
+    assert_same_contributions(f1[1], f0[1], tol=0.3, total=5e-2)
     for a, b in ((g1, g0), (d1, d0)):
         for k, v in a.items():
             if torch.is_tensor(v):
@@ -607,7 +607,7 @@ def test_prefetched_g_forward_matches_inline(monkeypatch):
         # D's gradients of the first iteration: identical weights, only stream placement differs.  G's are computed through D after
         # its first update (sign-like Adam: atomic-order noise of near-zero gradient elements is already +-lr in the weights)
         assert_same_contributions(f1[0], f0[0])
-        assert_same_contributions(f1[1], f0[1], tol=5e-2)
+        assert_same_contributions(f1[1], f0[1], tol=0.3, total=5e-2)
         for name, a, b in (('G', g1, g0), ('D', d1, d0)):
             assert float((a - b).abs().max()) <= 2 * 0.001 * 3 + 1e-6, (mode, name)
             assert float((a - b).norm() / b.norm()) < 1e-3, (mode, name)

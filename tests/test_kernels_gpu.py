@@ -454,3 +454,28 @@ def test_pool_adjoint_in_the_gather(case):
     dw, db = dw0.cuda(), db0.cuda()
     ops.conv2d_wgrad_unpooled(a1.cuda(), g.cuda(), gb.cuda(), 0.25 * 0.7, 0.2, dw, db, N, H, H, 0.41)
     assert rel_err(dw, rdw) < 2e-5 and rel_err(db, rdb) < 2e-5
+
+
+from philox_ref import _philox4x32_10  # noqa: E402
+
+
+@pytest.mark.parametrize('n,seed,offset', [(4, 0, 0), (3, 1337, 0), (16, 1337, 7), (4099, (5 << 40) + 3, (9 << 33) + 1)])
+def test_uniform_f32_is_philox_bit_for_bit(n, seed, offset):
+    """pg_uniform_f32 (the gradient-penalty mixing factors, wgan_gp_loss.py:15-17): element i = word (i % 4) of
+    Philox4x32-10(counter = (i / 4, offset), key = seed), top 24 bits / 2^24 -- bit-exact integer work -- and a U[0,1) sample."""
+    out = torch.empty(n, device='cuda')
+    ops.uniform_(out, seed, offset)
+    got = out.cpu().numpy()
+    for i in sorted(set(list(range(min(n, 12))) + [n - 1, n // 2])):
+        w = _philox4x32_10([(i // 4) & 0xffffffff, (i // 4) >> 32, offset & 0xffffffff, offset >> 32], [seed & 0xffffffff, seed >> 32])[i % 4]
+        assert got[i] == np.float32((w >> 8) / 16777216.0), (i, got[i])
+    assert got.min() >= 0.0 and got.max() < 1.0
+    big = torch.empty(1 << 20, device='cuda')
+    ops.uniform_(big, seed, offset)
+    b = big.double()
+    assert abs(float(b.mean()) - 0.5) < 2e-3 and abs(float(b.var()) - 1.0 / 12) < 2e-3
+    again = torch.empty(1 << 20, device='cuda')
+    ops.uniform_(again, seed, offset)
+    assert torch.equal(big, again)
+    ops.uniform_(again, seed, offset + 1)
+    assert not torch.equal(big, again) and abs(float((big * again).mean()) - 0.25) < 2e-3       # next draw: independent

@@ -23,8 +23,25 @@ nsteps = 10
 first = adam[-per_step * nsteps - 1] + 1 if len(adam) > per_step * nsteps else 0
 last = adam[-1]
 win = rows[first:last + 1]
-t0, t1 = win[0][0], max(r[1] for r in win)
-wall = t1 - t0
+# rocprofv3 flushes its buffers every few thousand records: the device then idles for milliseconds inside ONE step.  Steps with a
+# hole > 1.5 ms anywhere are the tracer's, not the product's: they are reported and left out of the window statistics.
+bounds = [adam[-per_step * (nsteps - k) - 1] + 1 if len(adam) > per_step * (nsteps - k) else 0 for k in range(nsteps)] + [last + 1]
+good = []
+for k in range(nsteps):
+    st = sorted(rows[bounds[k]:bounds[k + 1]])
+    hole, end = 0, st[0][1]
+    for s_, e_, _, _ in st[1:]:
+        hole = max(hole, s_ - end)
+        end = max(end, e_)
+    span = max(r[1] for r in st) - st[0][0]
+    print('step %d: %.3f ms%s' % (k, span / 1e6, '   (largest hole %.2f ms: tracer flush, excluded)' % (hole / 1e6) if hole > 1.5e6 else ''))
+    if hole <= 1.5e6:
+        good.append(st)
+if not good:
+    good = [sorted(win)]
+win = [r for st in good for r in st]
+nsteps = len(good)
+wall = sum(max(r[1] for r in st) - st[0][0] for st in good)          # (sum of the kept steps' spans)
 
 
 def union(intervals):
@@ -46,22 +63,23 @@ for s, e, q, name in win:
     byq[q].append((s, e))
 print('window: %d kernels, %.2f ms wall = %.3f ms per step (%d steps)' % (len(win), wall / 1e6, wall / 1e6 / nsteps, nsteps))
 for q, iv in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
-    busy = union(iv)
+    busy = sum(union([(s, e) for s, e, qq, _ in st if qq == q]) for st in good)
     print('queue %s: %5d kernels, busy %.2f ms (%.1f %% of wall), sum of durations %.2f ms' % (
         q, len(iv), busy / 1e6, 100.0 * busy / wall, sum(e - s for s, e in iv) / 1e6))
-allbusy = union([(s, e) for s, e, _, _ in win])
+allbusy = sum(union([(s, e) for s, e, _, _ in st]) for st in good)
 print('any queue busy: %.1f %% of wall; sum of all kernel durations %.3f ms per step (%.2fx the wall time)' % (
     100.0 * allbusy / wall, sum(e - s for s, e, _, _ in win) / 1e6 / nsteps, sum(e - s for s, e, _, _ in win) / wall))
 
 # where nothing runs: the largest gaps of the union, with the kernels on either side, and the gap histogram
-iv = sorted((s, e, name) for s, e, _, name in win)
 gaps = []
-cur_e, cur_name = iv[0][1], iv[0][2]
-for s, e, name in iv[1:]:
-    if s > cur_e:
-        gaps.append((s - cur_e, cur_name, name))
-    if e > cur_e:
-        cur_e, cur_name = e, name
+for st in good:
+    iv = sorted((s, e, name) for s, e, _, name in st)
+    cur_e, cur_name = iv[0][1], iv[0][2]
+    for s, e, name in iv[1:]:
+        if s > cur_e:
+            gaps.append((s - cur_e, cur_name, name))
+        if e > cur_e:
+            cur_e, cur_name = e, name
 
 
 def short(n):

@@ -78,3 +78,29 @@ json.dump({'tag': tag, 'per_kernel': roof,
           open(os.path.join(out, tag + '_roofline.json'), 'w'), indent=1)
 for r in rows[:14]:
     print(r)
+
+# ---- bench.py <-> rocprofv3 attribution check: every conv symbol the bench line times must be launched exactly as often per
+# step as the kernel trace of the same workload says (a wrapper missing from bench.KernelTimer shows up here)
+bench_json = os.path.join(out, 'bench_kernels.json')
+steps_traced = int(os.environ.get('PG_TRACED_STEPS', '23'))            # profile_round.sh: --prime 10 --warmup 3 --steps 10
+if os.path.exists(bench_json) and os.path.exists(ks):
+    line = [l for l in open(bench_json).read().splitlines() if l.startswith('{')][-1]
+    bk = json.loads(line).get('kernels', {})
+    traced = {}
+    with open(ks) as f:
+        for row in csv.DictReader(f):
+            traced[short(row['Name'])] = int(row['Calls']) / float(steps_traced)
+    bad = []
+    conv_syms = [k for k in traced if k.startswith(('conv_', 'wgrad_strip')) and 'epilogue' not in k]
+    for k in sorted(set(bk) | set(conv_syms)):
+        kb = k if k in traced else next((t for t in traced if t.startswith(k.rstrip('>') + ',') or t == k), None)    # (a trailing template flag the bench name omits)
+        b, r = bk.get(k, {}).get('launches_per_step', 0.0), traced.get(kb, 0.0) if kb else 0.0
+        if k not in bk and any(k.startswith(x.rstrip('>') + ',') for x in bk):
+            continue
+        print('%-58s bench %6.2f  rocprofv3 %6.2f launches per step%s' % (k, b, r, '' if abs(b - r) < 0.02 else '   <-- MISMATCH'))
+        if abs(b - r) >= 0.02:
+            bad.append(k)
+    if bad:
+        print('ATTRIBUTION MISMATCH for: %s' % ', '.join(bad))
+        sys.exit(1)
+    print('attribution check: %d conv symbols agree between bench.py and rocprofv3' % len(set(bk) | set(conv_syms)))
