@@ -101,7 +101,10 @@ __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_ker
     constexpr int BLKB = B::SLOTS * 16;                                   // bytes of a ring block
     constexpr bool GEN = EPI == EPI_GENERIC;
     extern __shared__ __align__(16) float lds[];
-    float* wl = lds + NBLK * B::SLOTS * 4;                                // [9][COUT][CIN] (only when the weights are not in registers)
+    // weights in LDS (when not in registers): [9][COUT][WS]; the lanes of a ds_read_b128 group read 8 different cout rows, which a
+    // 64-byte row stride (Cin = 16) would put on the same banks two by two (SQ_LDS_BANK_CONFLICT 0.28-0.30 of the LDS cycles, round 3)
+    constexpr int WS = CIN == 16 ? CIN + 4 : CIN;
+    float* wl = lds + NBLK * B::SLOTS * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = lane >> 2, j = lane & 3, qo = blk % QO, qp = blk / QO;
 
@@ -201,9 +204,9 @@ __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_ker
                 wreg[tp][c4] = *reinterpret_cast<const float4*>(p.w + ((size_t)(tp * COUT + 4 * qo + j) * CIN + 4 * c4));
     } else {
         for (int e = tid; e < 9 * COUT * C4; e += 256)
-            *reinterpret_cast<float4*>(wl + 4 * e) = *reinterpret_cast<const float4*>(p.w + 4 * e);
+            *reinterpret_cast<float4*>(wl + (e / C4) * WS + 4 * (e % C4)) = *reinterpret_cast<const float4*>(p.w + 4 * e);
     }
-    const float* wrow = wl + (4 * qo + j) * CIN;
+    const float* wrow = wl + (4 * qo + j) * WS;
 
     if constexpr (GATH) {
         gather_load(); gather_store(0);
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_ker
             for (int c4 = 0; c4 < C4; ++c4) {
                 float4 a;
                 if constexpr (WREG) a = wreg[tp][c4];
-                else a = *reinterpret_cast<const float4*>(wrow + tp * COUT * CIN + 4 * c4);
+                else a = *reinterpret_cast<const float4*>(wrow + tp * COUT * WS + 4 * c4);
                 f32x4 bq[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -422,7 +425,7 @@ template <int COUT, int CIN, int EPI, bool WREG, bool GATH = false>
 int launch_strip(const SArgs& a, int N, hipStream_t s, char* name, size_t name_len)
 {
     using B = Blk<CIN>;
-    const size_t smem = (size_t)NBLK * B::SLOTS * 16 + (WREG ? 0 : (size_t)9 * COUT * CIN * 4);
+    const size_t smem = (size_t)NBLK * B::SLOTS * 16 + (WREG ? 0 : (size_t)9 * COUT * (CIN == 16 ? CIN + 4 : CIN) * 4);
     auto kern = conv_strip_kernel<COUT, CIN, EPI, WREG, GATH>;
     static bool attr_done = false;                                // (idempotent; a race only repeats the call)
     if (!attr_done) {
