@@ -46,7 +46,7 @@ import torch  # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12          # gfx950 f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 REF_MINIBATCH = {6: 14, 7: 6, 8: 3}          # reference plugins.py:19-20 (default 16)
-PROFILE_TAG = 'r02'                           # profiles/<tag>_roofline.json: PMC pass the traffic / MFMA-busy figures come from
+PROFILE_TAG = 'r03'                           # profiles/<tag>_roofline.json: PMC pass the traffic / MFMA-busy figures come from
 
 
 def forward_flops(G, D, depth, alpha):

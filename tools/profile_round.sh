@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+python $R/bench.py --no-cpu --no-per-depth --no-configs --prime 10 --steps 10 --warmup 3 > $OUT/bench_kernels.json 2> $OUT/bench_kernels.err      # un-traced, FIRST (after PMC passes the clocks stay low for a while): its per-symbol launch counts are checked against the trace
 BENCH="python $R/bench.py --no-cpu --no-per-depth --no-configs --no-kernel-timing --prime 10 --steps 10 --warmup 3"      # (no instrumented passes after the timed loop: the trace ends with the timed steps)
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $BENCH > $OUT/bench_kt.log 2>&1
 PMCB="python $R/bench.py --no-cpu --no-per-depth --no-kernel-timing --no-configs --prime 0 --steps 2 --warmup 1"
@@ -13,8 +14,6 @@ timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --o
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $PMCB > $OUT/pmc_write.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq -o p --output-format csv -- $PMCB > $OUT/pmc_sq.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p --output-format csv -- $PMCB > $OUT/pmc_lds.log 2>&1
-# the same workload un-traced, with bench.py's own per-symbol launch counts (summarize_profile.py checks them against the trace)
-python $R/bench.py --no-cpu --no-per-depth --no-configs --prime 10 --steps 10 --warmup 3 > $OUT/bench_kernels.json 2> $OUT/bench_kernels.err
 # keep only the small summaries (the raw traces are large)
 python $R/tools/summarize_profile.py $OUT $TAG > $OUT/summary.log 2>&1
 python $R/tools/stream_overlap.py "$OUT/kt/**/kt_kernel_trace.csv" > $OUT/${TAG}_stream_overlap.txt 2>&1
