@@ -346,63 +346,6 @@ def wait_pending(net):
         net._pending = None
 
 
-# The generator forward that opens the G step (wgan_gp_loss.py:70) depends on G's weights and the new latents only -- not on
-# anything the D step computes -- so Trainer launches it early, on a third stream, where it fills the gaps the D step's
-# dependent n = 3 launch chains leave on the chip; g_loss_forward picks the result up instead of recomputing it.
-_PREFETCH = {}
-
-
-def _prefetch_stream():
-    dev = torch.cuda.current_device()
-    if dev not in _PREFETCH:
-        prio = int(_os.environ.get('PGGAN_PREFETCH_PRIO', '0'))
-        _PREFETCH[dev] = torch.cuda.Stream(device=dev, priority=prio)
-    return _PREFETCH[dev]
-
-
-def _tensors_of(obj, out):
-    if torch.is_tensor(obj):
-        out.append(obj)
-    elif isinstance(obj, dict):
-        for v in obj.values():
-            _tensors_of(v, out)
-    elif isinstance(obj, (list, tuple)):
-        for v in obj:
-            _tensors_of(v, out)
-    return out
-
-
-def prefetch_generator(G, latents, on_side=False):
-    """``generator_forward(G, latents, save=True)`` on the prefetch stream (``on_side``: on the weight-gradient stream), behind
-    everything queued so far on the current stream.  The result waits on ``G`` for the ``g_loss_forward`` call with the same
-    latents tensor; a call with anything else (other latents, changed weights / depth / alpha) ignores and drops it."""
-    G._sync_version()
-    latents = _check_dev(latents, 'latents')
-    main = torch.cuda.current_stream(torch._C._cuda_getDevice())
-    pre = _side_stream() if on_side else _prefetch_stream()
-    pre.wait_stream(main)
-    with torch.cuda.stream(pre):
-        fake, gctx = generator_forward(G, latents, save=True)
-        ev = torch.cuda.Event()
-        ev.record(pre)
-    latents.record_stream(pre)
-    for t in _tensors_of(gctx, [fake]):              # allocated on the prefetch stream, consumed on the main / side streams
-        t.record_stream(main)
-        if torch.cuda.current_device() in _SIDE:
-            t.record_stream(_SIDE[torch.cuda.current_device()])
-    G._prefetched = (latents, fake, gctx, ev, (G._param_version, int(G.depth), float(G.alpha)))
-
-
-def _take_prefetched(G, latents):
-    pre = G.__dict__.pop('_prefetched', None)
-    if pre is None:
-        return None
-    if pre[0] is not latents or pre[4] != (G._param_version, int(G.depth), float(G.alpha)):
-        return None
-    torch.cuda.current_stream(torch._C._cuda_getDevice()).wait_event(pre[3])
-    return pre[1], pre[2]
-
-
 def _grads_ready(net, layers):
     """Tell the gradient exchange (``parallel.GradExchange``, installed by ``Trainer`` as ``net._grad_hook`` under data
     parallelism) that every weight-gradient launch of ``layers`` has been enqueued: their spans of the flat gradient
@@ -1112,8 +1055,7 @@ def g_loss_forward(G, D, latents):
     latents = _check_dev(latents, 'latents')
     D._sync_version()
     G._sync_version()
-    pre = _take_prefetched(G, latents)
-    fake, gctx = pre if pre is not None else generator_forward(G, latents, save=True)
+    fake, gctx = generator_forward(G, latents, save=True)
     s, dctx = d_forward(D, fake, 1)
     g_cost, gscore = ops.g_loss(s)
     return g_cost, dict(G=G, D=D, gctx=gctx, dctx=dctx, gscore=gscore)

@@ -19,10 +19,6 @@ import os
 from . import engine
 
 PLUGIN_UNITS = ('iteration', 'epoch', 's', 'end')
-# 0: off; 1 / 3: G(latents) of the G step is launched before D's backward pass on a third stream / on the weight-gradient
-# stream; 2 / 4: the same before the D loss is evaluated (experiment)
-G_PREFETCH = int(os.environ.get("PGGAN_G_PREFETCH", "0"))
-
 
 def _to_device(t):
     return t if getattr(t, 'is_cuda', False) else t.cuda()
@@ -155,17 +151,6 @@ class Trainer(object):
         return (self.G_loss is wgan_gp_loss.wgan_gp_G_loss and hasattr(self.D, '_flat_param')
                 and not wgan_gp_loss._graphs_on(self.D) and not wgan_gp_loss._graphs_on(self.G))
 
-    def _prefetch_g_forward(self, latents):
-        """The G step opens with G(latents) (wgan_gp_loss.py:70), which depends on nothing the D step computes: launch it now,
-        on the prefetch stream, under the D step's backward sweep (``engine.prefetch_generator``).  Only with the product's
-        own G loss on eager launches; PGGAN_G_PREFETCH=0 switches it off."""
-        from . import wgan_gp_loss
-        if not (self.G_loss is wgan_gp_loss.wgan_gp_G_loss and hasattr(self.G, '_flat_param') and self.G._flat_param.is_cuda
-                and not wgan_gp_loss._graphs_on(self.G) and not wgan_gp_loss._graphs_on(self.D)):
-            return False
-        engine.prefetch_generator(self.G, latents, on_side=G_PREFETCH in (3, 4))
-        return True
-
     def train(self):
         """One iteration: ``D_training_repeats`` discriminator updates, then one generator update
         (reference trainer.py:85-115; line numbers below refer to it)."""
@@ -176,19 +161,10 @@ class Trainer(object):
             reals = _to_device(next(self.dataiter))                               # :92
             self.cur_nimg += reals.size(0) * world                                # :93 (global images)
             last = rep == self.D_training_repeats - 1
-            next_latents = None
-            if last and G_PREFETCH in (2, 4):
-                next_latents = _to_device(self.random_latents_generator())        # :103
-                self._prefetch_g_forward(next_latents)
             d_losses = _as_tuple(self.D_loss(self.D, self.G, reals, latents))     # :95
             defer = last and self._can_overlap_d_update()
             self.D._skip_join = defer                # the update runs on the second stream, behind the weight gradients
             self._open_exchange(self.D, engine.d_exchange_layers)
-            if last and G_PREFETCH in (1, 3):
-                # the latents of the G step are drawn here instead of after the update (:103): nothing else draws from the
-                # generator in between, so the sequence is the reference's; G(latents) then runs under D's backward sweep
-                next_latents = _to_device(self.random_latents_generator())        # :103
-                self._prefetch_g_forward(next_latents)
             try:
                 d_losses[0].backward()                                            # :98
             finally:
@@ -200,7 +176,7 @@ class Trainer(object):
                 engine.defer_to_side(self.D, self._d_update)
             else:
                 self._d_update()
-            latents = next_latents if next_latents is not None else _to_device(self.random_latents_generator())   # :103
+            latents = _to_device(self.random_latents_generator())                 # :103
         g_losses = _as_tuple(self.G_loss(self.G, self.D, latents))                # :105-110
         self._open_exchange(self.G, engine.g_exchange_layers)
         try:
