@@ -21,6 +21,7 @@
 #ifndef PGGAN_HIP_H
 #define PGGAN_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -160,6 +161,15 @@ int pg_conv2d_wino_pixelnorm_nhwc(const float* x, const float* u, const float* b
 int pg_conv2d_wino_pnbwd_nhwc(const float* x, const float* u, const float* ysaved, const float* r, float* y,
                               int pool, const float* pool_other, float pool_a, float pool_b,
                               int N, int H, int W, int Cin, int Cout, float scale, float slope, pg_stream_t stream);
+
+/* Scratch for the launches on `stream` (of the current device) that slice their K loop across workgroups: the 3x3 layers of
+ * the 16x16 / 32x32 stages at minibatch 3 give pg_conv2d_wino_nhwc fewer workgroups than the chip has CUs, so up to 8 workgroups
+ * share a (64-tile, 16-cout) block, each leaves its partial outputs in the scratch and the last one to arrive adds them in slice
+ * order (deterministic) and runs the fused epilogue.  The library never allocates device memory: the caller owns `ptr` (16-byte
+ * aligned, ZERO-FILLED once, > 16 KB; 32 MB covers every layer of the 1024x1024 schedule), keeps it alive until it registers
+ * another one or clears the entry (ptr NULL, bytes 0), and uses it for nothing else.  Without a registered scratch, or when a layer
+ * would need more than `bytes`, launches run unsplit -- same results to fp32 summation order.  Thread-safe.                        */
+int pg_set_workspace(pg_stream_t stream, void* ptr, size_t bytes);
 
 /* Winograd weight gradient of the same layers: dW[kh][kw][co][ci] += scale * sum gz*x (3x3, pad 1), db[co] += sum gz, computed as
  * G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G  -- 16 MFMAs per 4 output tiles instead of 36.  H, W powers of two with

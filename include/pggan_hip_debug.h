@@ -23,6 +23,9 @@ const char* pg_debug_last_wino_wgrad_kernel(void);
  * keys: see csrc/conv_igemm.hip); value -1 restores the built-in choice.  pg_debug_set_wino: K-chunk of 4*vec channels. */
 int pg_debug_set_tuning(int key, int value);
 int pg_debug_set_wino(int vec);
+/* K slices per (tile block, cout block) of the second-generation Winograd conv: -1 built-in choice, 0 / 1 never split, n: n slices
+ * wherever a scratch is registered (pg_set_workspace) and the layer has that many 8-channel chunks. */
+int pg_debug_set_wino_ksplit(int n);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 class PgganLibraryError(RuntimeError):
@@ -38,6 +38,7 @@ SIGNATURES = {
     'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wino_pixelnorm_nhwc': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wino_pnbwd_nhwc': [P, P, P, P, P, I, P, F, F, I, I, I, I, I, F, F, P],
+    'pg_set_workspace': [P, P, ctypes.c_size_t],
     'pg_conv2d_wgrad_wino_nhwc': [P, P, P, P, I, I, I, I, I, I, F, P],
     'pg_conv2d_wgrad_wino2_nhwc': [P, P, I, P, P, I, P, P, I, I, I, I, I, I, F, P],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],
@@ -95,6 +96,7 @@ DEBUG_SIGNATURES = {
     'pg_debug_last_wino_wgrad_kernel': [],
     'pg_debug_set_tuning': [I, I],
     'pg_debug_set_wino': [I],
+    'pg_debug_set_wino_ksplit': [I],
 }
 
 _lib = None

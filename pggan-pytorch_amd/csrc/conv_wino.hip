@@ -13,6 +13,8 @@
 // 64 MFMAs; the output transform is lane-local because a lane holds all 16 products of its (tile, 4 couts).
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <mutex>
+#include <vector>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -39,6 +41,10 @@ struct WinoP {
     unsigned char* ysigns;                     // PG_FLAG_SIGNS_OUT
     float* pn_r; float pn_eps;                 // PixelNorm epilogue (pg_conv2d_wino_pixelnorm_nhwc): r[pixel] = rsqrt(mean_c y^2 + eps)
     const float* pnb_y; const float* pnb_r;    // adjoint of (LeakyReLU -> PixelNorm) on the (optionally pooled) result (pg_conv2d_wino_pnbwd_nhwc)
+    // K split across workgroups (small maps at minibatch 3: fewer than one workgroup per CU otherwise): ksplit workgroups share a
+    // (tile block, cout block), each takes kcper chunks; partial 2x2 outputs go to ks_part, the last arriver (ks_count) adds them
+    // in split order and runs the fused epilogue
+    int ksplit, kcper; unsigned mKs; float* ks_part; unsigned* ks_count;
 #ifdef PG_WINO_TRACE
     unsigned long long* trace;                 // [workgroup][wave][chunk][8] s_memtime stamps (tools/exp/wino_trace.py)
 #endif
@@ -104,30 +110,33 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
-// Output transform Y = A^T M A of one lane's (tile, 4 couts) products (lane-local: the lane holds all 16 Winograd positions),
-// then the fused epilogue on the 2x2 outputs of the tile.  cb: first of the lane's 4 couts, ni: image, (oy0, ox0): first output pixel.
-__device__ __forceinline__ void wino_epilogue(const WinoP& p, const f32x4 (&acc)[16], int cb, int ni, int oy0, int ox0)
+// Output transform Y = A^T M A of one lane's (tile, 4 couts) products (lane-local: the lane holds all 16 Winograd positions):
+// yq[2 a + b] = output pixel (a, b) of the tile.
+__device__ __forceinline__ void wino_output_transform(const f32x4 (&acc)[16], f32x4 (&yq)[4])
 {
-    // ---- output transform Y = A^T M A (lane-local), then the fused epilogue on the 2x2 outputs
     f32x4 s[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         s[0][j] = acc[0 + j] + acc[4 + j] + acc[8 + j];
         s[1][j] = acc[4 + j] - acc[8 + j] - acc[12 + j];
     }
-    f32x4 yq[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        yq[a][0] = s[a][0] + s[a][1] + s[a][2];
-        yq[a][1] = s[a][1] - s[a][2] - s[a][3];
+        yq[2 * a + 0] = s[a][0] + s[a][1] + s[a][2];
+        yq[2 * a + 1] = s[a][1] - s[a][2] - s[a][3];
     }
+}
+
+// The fused epilogue on the 2x2 outputs of a tile.  cb: first of the lane's 4 couts, ni: image, (oy0, ox0): first output pixel.
+__device__ __forceinline__ void wino_epilogue_q(const WinoP& p, const f32x4 (&yq)[4], int cb, int ni, int oy0, int ox0)
+{
     if (cb >= p.Cout || ni >= p.N) return;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + cb);
     float4 ov[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 v = yq[q >> 1][q & 1];
+        const f32x4 v = yq[q];
         const size_t off = (((size_t)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1)) * p.Cout + cb;
         float4 o = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
         if (p.mask) {
@@ -186,6 +195,13 @@ __device__ __forceinline__ void wino_epilogue(const WinoP& p, const f32x4 (&acc)
         } else if (p.pool_a != 1.f) { v.x *= p.pool_a; v.y *= p.pool_a; v.z *= p.pool_a; v.w *= p.pool_a; }
         *reinterpret_cast<float4*>(p.ypool + poff) = v;
     }
+}
+
+__device__ __forceinline__ void wino_epilogue(const WinoP& p, const f32x4 (&acc)[16], int cb, int ni, int oy0, int ox0)
+{
+    f32x4 yq[4];
+    wino_output_transform(acc, yq);
+    wino_epilogue_q(p, yq, cb, ni, oy0, ox0);
 }
 
 
@@ -502,9 +518,10 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
 //   * XS: DMA instructions per thread for one input region = 256-slot (4 KB) units of an X buffer.  The usual region (one image,
 //     8 x 8 tiles: 18 x 19 slots x 2 planes = 684) fits XS = 3: 2 x (12 + 8) KB = 40 KB of LDS per workgroup, FOUR workgroups per
 //     CU (124 VGPRs allow four waves per SIMD) instead of three with XS = 4.
-template <int NCB, int XK, int XS>
+template <int NCB, int XK, int XS, bool KSP = false>
 __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 waves per SIMD: <= 256 VGPRs + AGPRs
 {
+    static_assert(!KSP || (NCB == 1 && XK == 1), "K split: 16 couts per workgroup, 8-channel input staging");
     constexpr int KC = 8;
     constexpr int XPL = 2 * XK;                              // channel-quad planes of the staged input region
     static_assert(XK == 1 ? (XS == 3 || XS == 4) : XS == 7, "input region: <= 768 / 1024 slots (XK = 1), 1792 (XK = 2)");
@@ -522,7 +539,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
     if (p.trace && lane == 0 && blockIdx.x < 1024) p.trace[((size_t)(blockIdx.x * 4 + wave) * 8 + 0) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
     int b = (int)pg_xcd_remap(blockIdx.x, gridDim.x);
-    int cob;
+    int cob, ks = 0;
+    if constexpr (KSP) { const int q = (int)__umulhi((unsigned)b, p.mKs); ks = b - q * p.ksplit; b = q; }   // the splits of a block are adjacent
+    const int blk = b;
     // no runtime divisions (five of them were ~100 of the ~450 fixed VALU instructions of a wave): blocksW / blocksH are powers of
     // two, the cout-block split is a magic multiplication (exact for b * divisor < 2^32, checked by the host)
     if (p.ncob == 1) cob = 0;
@@ -602,10 +621,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
             if ((i * 4) * 64 < XPL * npixp) dma16(rxs, xsrc[i], soff, dst + i * 4096);     // (workgroup-uniform: skips unused instructions)
     };
 
-    f32x4 acc[NCB][16];                                      // first written by chunk 0
+    f32x4 acc[NCB][16];                                      // first written by the first chunk
+    const int kbeg = KSP ? ks * p.kcper * KC : 0;
+    const int kend = KSP ? min(p.Cin, kbeg + p.kcper * KC) : p.Cin;
 
-    dma_u(0);
-    dma_x(0);
+    dma_u(kbeg);
+    dma_x(kbeg);
     // One K chunk.  The first one starts its accumulators from the MFMA's constant-zero C operand instead of 64 zeroed registers
     // (the fixed per-workgroup instruction count is what bounds the 16/32-channel layers: rocprofv3 SQ_INSTS_VALU per wave).
     auto chunk = [&](const int k0, auto first) {
@@ -625,8 +646,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
 #pragma unroll
             for (int c = 0; c < 4; ++c) d[a][c] = *(lds_v2ptr)(xb + prow[a] + c * 16);   // volatile: keep ds_read_b64 (a merged ds_read2_b64 is half rate)
         __builtin_amdgcn_sched_barrier(0);
-        if (k0 + KC < p.Cin) dma_u(k0 + KC);                  // in flight under the transform and the MFMAs below
-        if (sub == 0 && k0 + KC * XK < p.Cin) dma_x(k0 + KC * XK);
+        if (k0 + KC < kend) dma_u(k0 + KC);                   // in flight under the transform and the MFMAs below
+        if (sub == 0 && k0 + KC * XK < kend) dma_x(k0 + KC * XK);
         __builtin_amdgcn_sched_barrier(0);
         PG_STAMP(3);
         // V = B^T d B, in place
@@ -663,9 +684,40 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
         PG_STAMP(5);
         PG_STAMP(6);
         };
-    chunk(0, std::true_type{});
-    for (int k0 = KC; k0 < p.Cin; k0 += KC) chunk(k0, std::false_type{});
-    if (p.pn_r) {                                             // (workgroup-uniform; the host launches ncob == 1 then)
+    chunk(kbeg, std::true_type{});
+    for (int k0 = kbeg + KC; k0 < kend; k0 += KC) chunk(k0, std::false_type{});
+    if constexpr (KSP) {
+        // partial sums of this K slice: 2x2 outputs (the output transform is linear) -> slice (blk, ks) of the scratch, one float4
+        // per lane and output pixel; the workgroup that arrives last adds the slices in split order (so the result does not depend
+        // on who was last) and runs the fused epilogue
+        f32x4 yq[4];
+        wino_output_transform(acc[0], yq);
+        // Slices and ticket are exchanged with agent-scope accesses (sc1: coherent across the XCDs' L2s by themselves) instead of
+        // plain stores + __threadfence(): the release fence writes back the WHOLE L2 of the XCD (buffer_wbl2), ~1 us each and
+        // serialised per XCD -- 768 workgroups spent 100+ us in fences (n3 @64 128->128: 141 us against 25 us unsplit).
+        constexpr int SC1 = 16;                               // cache-policy bit 4 of the buffer builtins = sc1 on gfx94x / gfx950
+        const __amdgpu_buffer_rsrc_t rp = pg_make_rsrc(p.ks_part + (size_t)blk * p.ksplit * 4096, (unsigned)p.ksplit * 16384u);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(pg_u32x4{__float_as_uint(yq[q][0]), __float_as_uint(yq[q][1]), __float_as_uint(yq[q][2]),
+                                                            __float_as_uint(yq[q][3])}, rp, ((ks * 4 + q) * 256 + tid) * 16, 0, SC1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the slice has reached the coherence point ...
+        __syncthreads();                                      // ... for every wave of the workgroup, before the ticket is taken
+        __attribute__((address_space(3))) unsigned* const ticket = (__attribute__((address_space(3))) unsigned*)lds;
+        if (tid == 0) *ticket = __hip_atomic_fetch_add(p.ks_count + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*ticket != (unsigned)(p.ksplit - 1)) return;
+        if (tid == 0) __hip_atomic_store(p.ks_count + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < p.ksplit; ++s2)                 // slice order, whoever arrived last: a deterministic sum
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const pg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, ((s2 * 4 + q) * 256 + tid) * 16, 0, SC1);
+                yq[q] += f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+            }
+        wino_epilogue_q(p, yq, co0 + 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
+    } else if (p.pn_r) {                                             // (workgroup-uniform; the host launches ncob == 1 then)
         wino_epilogue_pixelnorm<NCB>(p, acc, 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
     } else if (p.pnb_y) {
         wino_epilogue_pnbwd<NCB>(p, acc, 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
@@ -730,6 +782,24 @@ thread_local char g_wino_last[64] = "";
 #ifdef PG_WINO_TRACE
 thread_local unsigned long long* g_wino_trace = nullptr;
 #endif
+// Scratch for launches that split K across workgroups, registered per (device, stream) by the host layer (pg_set_workspace):
+// [4096 tickets][partial outputs].  The library never allocates device memory itself.
+struct Workspace { int device; hipStream_t stream; char* ptr; size_t bytes; };
+std::mutex g_ws_mutex;
+std::vector<Workspace> g_ws;
+constexpr size_t WS_TICKETS = 4096, WS_HEAD = WS_TICKETS * sizeof(unsigned);
+
+bool find_workspace(hipStream_t s, Workspace& out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (const Workspace& w : g_ws)
+        if (w.device == dev && w.stream == s) { out = w; return true; }
+    return false;
+}
+
+thread_local int g_wino_ksplit = -1;           // -1: built-in choice; 0 / 1: never split K across workgroups; n: n slices where legal
 thread_local int g_wino_vec = 0;               // 2 / 4: first-generation kernel with K chunks of 4*vec channels; 0: second-generation kernel,
                                                // built-in choice of couts per workgroup; 11 / 12: second generation, 16 / 32 couts (pg_debug_set_wino)
 
@@ -739,6 +809,30 @@ extern "C" const char* pg_debug_last_wino_kernel(void) { return g_wino_last; }
 #ifdef PG_WINO_TRACE
 extern "C" int pg_debug_wino_trace(void* buf) { g_wino_trace = (unsigned long long*)buf; return 0; }
 #endif
+extern "C" int pg_set_workspace(pg_stream_t stream, void* ptr, size_t bytes)
+{
+    if ((ptr == nullptr) != (bytes == 0)) return PG_E_ARG;
+    if (ptr && (bytes <= WS_HEAD || ((size_t)ptr & 15))) return PG_E_ARG;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (size_t i = 0; i < g_ws.size(); ++i)
+        if (g_ws[i].device == dev && g_ws[i].stream == (hipStream_t)stream) {
+            if (ptr) { g_ws[i].ptr = (char*)ptr; g_ws[i].bytes = bytes; }
+            else g_ws.erase(g_ws.begin() + i);
+            return 0;
+        }
+    if (ptr) g_ws.push_back(Workspace{dev, (hipStream_t)stream, (char*)ptr, bytes});
+    return 0;
+}
+
+extern "C" int pg_debug_set_wino_ksplit(int n)
+{
+    if (n < -1 || n > 64) return PG_E_ARG;
+    g_wino_ksplit = n;
+    return 0;
+}
+
 extern "C" int pg_debug_set_wino(int vec)
 {
     if (vec != 0 && vec != 2 && vec != 4 && vec != 11 && vec != 12) return PG_E_ARG;
@@ -855,9 +949,33 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
         if ((long long)p.ncob * p.ncob * ntb >= (1ll << 32)) return PG_E_UNSUP;
         p.mDiv = (unsigned)((1ull << 32) / (unsigned)(p.cout_minor ? p.ncob : ntb)) + 1u;
         const size_t smem2 = (size_t)2 * (xs * 256 + 512 * ncb) * 16;
-        dim3 grid2((unsigned)(ntb * p.ncob));
-        snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d>", ncb, xk, xs);
-        void (*fn)(WinoP) = ncb == 2 ? (xs == 3 ? conv_wino2_kernel<2, 1, 3> : conv_wino2_kernel<2, 1, 4>)
+        // Fewer workgroups than the chip holds (four per CU) on a deep K loop -- 16x16 / 32x32 maps at minibatch 3: slice K over
+        // up to 8 workgroups per (tile block, cout block), at least 4 chunks each, through the stream's registered scratch
+        const int nblk = ntb * p.ncob, nch = Cin >> 3;
+        int ks = 1;
+        Workspace ws{};
+        if (ncb == 1 && xk == 1 && !pn_r && !pnb_y && g_wino_ksplit != 0 && g_wino_ksplit != 1 && nblk <= (int)WS_TICKETS &&
+            find_workspace((hipStream_t)stream, ws)) {
+            if (g_wino_ksplit > 1) ks = g_wino_ksplit;
+            else if (nblk <= 432) { ks = 864 / nblk; if (ks > 8) ks = 8; if (ks > nch / 4) ks = nch / 4; }     // measured: tools/bench_ksplit.py
+            if (ks > nch) ks = nch;
+            if (ks > 1) {
+                p.kcper = (nch + ks - 1) / ks;
+                ks = (nch + p.kcper - 1) / p.kcper;
+                if (WS_HEAD + (size_t)nblk * ks * 16384 > ws.bytes || (long long)nblk * ks * ks >= (1ll << 32)) ks = 1;
+            }
+            if (ks < 1) ks = 1;
+        }
+        p.ksplit = ks;
+        if (ks > 1) {
+            p.mKs = (unsigned)((1ull << 32) / (unsigned)ks) + 1u;
+            p.ks_count = reinterpret_cast<unsigned*>(ws.ptr); p.ks_part = reinterpret_cast<float*>(ws.ptr + WS_HEAD);
+        } else { p.kcper = nch; p.mKs = 0; p.ks_count = nullptr; p.ks_part = nullptr; }
+        dim3 grid2((unsigned)(nblk * ks));
+        if (ks > 1) snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d, true>", ncb, xk, xs);
+        else snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d>", ncb, xk, xs);
+        void (*fn)(WinoP) = ks > 1 ? (xs == 3 ? conv_wino2_kernel<1, 1, 3, true> : conv_wino2_kernel<1, 1, 4, true>)
+                          : ncb == 2 ? (xs == 3 ? conv_wino2_kernel<2, 1, 3> : conv_wino2_kernel<2, 1, 4>)
                           : xk == 2 ? conv_wino2_kernel<1, 2, 7> : (xs == 3 ? conv_wino2_kernel<1, 1, 3> : conv_wino2_kernel<1, 1, 4>);
         if (smem2 > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);

@@ -41,7 +41,7 @@ def _check_dev(t, what):
 # (1.16x); 16->8 and 8->8 (half of the cout tile empty) stay on the block-MFMA kernels (0.7-1.0x).
 import os as _os
 USE_WINOGRAD = _os.environ.get('PGGAN_WINOGRAD', '1') != '0'
-WINO_MIN_WORKGROUPS = int(_os.environ.get('PGGAN_WINO_MIN_WG', '256'))
+WINO_MIN_WORKGROUPS = int(_os.environ.get('PGGAN_WINO_MIN_WG', '32'))     # (K is sliced across workgroups below ~432: ops._stream_with_workspace)
 WINO_MIN_CHANNELS = int(_os.environ.get('PGGAN_WINO_MIN_C', '8'))
 WINO_MIN_COUT = int(_os.environ.get('PGGAN_WINO_MIN_COUT', '16'))
 USE_WINOGRAD_WGRAD = USE_WINOGRAD and _os.environ.get('PGGAN_WINOGRAD_WGRAD', '1') != '0'

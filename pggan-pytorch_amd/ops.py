@@ -4,6 +4,8 @@ PyTorch is used only as the device allocator and stream provider: every function
 CUDA(HIP) tensors, allocates its output with ``torch.empty`` and launches a hand-written HIP
 kernel on the current stream.  No ATen arithmetic, no CPU fallback.
 Feature tensors are NHWC ``[N,H,W,C]``; image tensors are NCHW ``[N,C,H,W]``."""
+import os as _os
+
 import torch
 
 from . import _lib
@@ -13,6 +15,23 @@ def _stream():
     """Raw HIP stream handle of torch's current stream.  torch.cuda.current_stream() costs ~17 us per call (device
     index resolution through is_available() / os.environ) and this is called once per kernel launch (~400 per step)."""
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+# Scratch of the launches that slice K across workgroups (include/pggan_hip.h: pg_set_workspace), one per (device, stream),
+# zero-filled, registered with the library the first time a Winograd conv is launched on that stream and kept for good.
+WORKSPACE_BYTES = int(_os.environ.get('PGGAN_WORKSPACE_MB', '32')) << 20
+_workspaces = {}
+
+
+def _stream_with_workspace():
+    dev = torch._C._cuda_getDevice()
+    s = torch._C._cuda_getCurrentRawStream(dev)
+    if (dev, s) not in _workspaces:
+        ws = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device='cuda:%d' % dev) if WORKSPACE_BYTES > 0 else None
+        if ws is not None:
+            _lib.call('pg_set_workspace', s, ws.data_ptr(), ws.numel())
+        _workspaces[(dev, s)] = ws
+    return s
 
 
 def _p(t):
@@ -113,7 +132,7 @@ def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2
         sb = torch.empty((N, H, W, cout // 4), device=x.device, dtype=torch.uint8)
         mask, flags = sb, flags | FLAG_SIGNS_OUT
     _lib.call('pg_conv2d_wino_nhwc', _p(x), _p(u), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
-              _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, flags, scale, slope, mask_slope, _stream())
+              _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, flags, scale, slope, mask_slope, _stream_with_workspace())
     if signs_out:
         return y, sb
     if pool:

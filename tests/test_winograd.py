@@ -136,6 +136,66 @@ def _wino_kernel_case(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 16, 512, 512, 0), (3, 32, 256, 128, 0), (9, 16, 128, 96, 0), (2, 32, 64, 64, 1), (3, 8, 64, 36, 0),
+                                  (1, 16, 40, 32, 0), (5, 32, 16, 24, 1)])
+@pytest.mark.parametrize('slices', [-1, 2, 3, 8])
+def test_conv2d_wino_k_split(case, slices):
+    """The same contract with the K loop sliced across workgroups (pg_set_workspace + the last-arriver fix-up of conv_wino2_kernel<..,
+    true>): -1 = the built-in choice (splits the 16x16 / 32x32 maps at minibatch 3), n = n slices forced; every fused epilogue; and
+    the result must not depend on which workgroup arrives last (bit-identical repeats)."""
+    lib = pg._lib.load()
+    N, H, ci, co, ups = case
+    assert lib.pg_debug_set_wino_ksplit(slices) == 0
+    try:
+        _wino_kernel_case(case)
+        name = lib.pg_debug_last_wino_kernel().decode()
+        nblk = -(-(N * (H // 2) ** 2) // 64) * -(-co // 16)
+        if (slices > 1 and ci >= 8 * slices) or (slices == -1 and nblk <= 256 and ci >= 64):
+            assert name.endswith('true>'), name
+        x, u = rnd(N, H // 2 if ups else H, H // 2 if ups else H, ci).cuda(), pg.ops.wino_transform_weights((rnd(3, 3, co, ci, seed=1) * 0.2).cuda())
+        ys = [pg.ops.conv2d_wino(x, u, None, N, H, H, 0.37, 0.2, ups=bool(ups)) for _ in range(4)]
+        assert all(torch.equal(ys[0], y) for y in ys[1:])
+    finally:
+        lib.pg_debug_set_wino_ksplit(-1)
+
+
+@pytest.mark.gpu
+def test_workspace_registration_errors_and_unsplit_without_scratch():
+    lib = pg._lib.load()
+    import ctypes
+    s = torch.cuda.Stream()
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device='cuda')
+    h = ctypes.c_void_p(s.cuda_stream)
+    assert lib.pg_set_workspace(h, ctypes.c_void_p(buf.data_ptr()), 0) == -1           # pointer without a size
+    assert lib.pg_set_workspace(h, None, 4096) == -1
+    assert lib.pg_set_workspace(h, ctypes.c_void_p(buf.data_ptr()), 1 << 14) == -1     # no room behind the tickets
+    assert lib.pg_set_workspace(h, ctypes.c_void_p(buf.data_ptr() + 4), 1 << 19) == -1  # alignment
+    assert lib.pg_set_workspace(h, None, 0) == 0                                        # clearing an absent entry is fine
+    x, w = rnd(3, 16, 16, 64).cuda(), (rnd(3, 3, 64, 64, seed=1) * 0.2).cuda()
+    u = pg.ops.wino_transform_weights(w)
+    want = pg.ops.conv2d_wino(x, u, None, 3, 16, 16, 0.37, 0.2)                          # current stream: scratch registered by ops
+    assert lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+    torch.cuda.synchronize()
+    y = torch.empty_like(want)
+    args = [ctypes.c_void_p(t.data_ptr()) for t in (x, u)] + [None, None, ctypes.c_void_p(y.data_ptr()), None, None, 1.0, 0.0, 0, None, None, 1.0,
+                                                              3, 16, 16, 64, 64, 0, 0.37, 0.2, 0.2, h]
+    assert lib.pg_conv2d_wino_nhwc(*args) == 0                                          # a stream without scratch: unsplit launch
+    assert not lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+    s.synchronize()
+    assert rel_err(y, want) < 1e-6
+    small = torch.zeros((1 << 14) + (1 << 15), dtype=torch.uint8, device='cuda')        # room for two slices of ONE block only
+    assert lib.pg_set_workspace(h, ctypes.c_void_p(small.data_ptr()), small.numel()) == 0
+    assert lib.pg_conv2d_wino_nhwc(*args) == 0                                          # 12 blocks x 8 slices do not fit: unsplit
+    assert not lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+    assert lib.pg_set_workspace(h, ctypes.c_void_p(buf.data_ptr()), buf.numel()) == 0   # re-registering replaces the entry
+    assert lib.pg_conv2d_wino_nhwc(*args) == 0
+    assert lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+    s.synchronize()
+    assert rel_err(y, want) < 1e-6
+    assert lib.pg_set_workspace(h, None, 0) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', [(3, 64, 16, 16, 0), (2, 32, 32, 32, 1), (1, 16, 64, 24, 0), (5, 8, 8, 16, 0), (3, 128, 32, 16, 1),
                                   (2, 16, 16, 8, 0), (1, 32, 128, 32, 0)])
 def test_conv2d_wino_pixelnorm_kernel(case):
