@@ -30,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 thread_local char g_last_kernel[96] = "";     // symbol of the last conv kernel launched by this thread
-thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling, 10: unfused unpooling, 11 / 12: unfused PixelNorm forward / adjoint
+thread_local int g_tune[4] = {-1, -1, -1, -1}; // tuning overrides (pg_debug_set_tuning): [0] conv tile, [1] wgrad config, [2] conv split-K, [3] 1: generic path for the 4x4 boundary layers, 2: generic path for the 8/16-cout layers, 3: unfused pooling, 10: unfused unpooling, 11 / 12: unfused PixelNorm forward / adjoint, 20: tile kernels instead of the row-streaming ones, 21: 4x4 -> 1x1 layer on one workgroup per cout block
 
 template <typename K>
 inline int set_smem(K kern, size_t smem)
@@ -706,17 +706,48 @@ __device__ __forceinline__ void k4_epilogue(const ConvP& p, const f32x4& acc, si
     *reinterpret_cast<float4*>(p.y + off) = o;
 }
 
+// Both layers stream 16*Cout*Cin weights (16.8 MB at 512 channels) against a handful of samples: what bounds them is how many
+// bytes are in flight, not MFMA or bandwidth.  With one wave per 16-cout weight row block walking its Cin (or its pixel's Cin)
+// 16 channels at a time, 512 waves kept ~2 MB in flight: 24 / 36 us per launch (1.2 TFLOP/s).  Now the waves of a workgroup
+// split Cin, every wave issues all the loads of an 8-step group before the first MFMA, and the partial sums meet in LDS.
+constexpr int K4_DEPTH = 8;                     // 16-channel steps whose loads are issued together
+
+template <int NT>
+__device__ __forceinline__ void k4_dot(const float* wrow, const float* const (&xrow)[NT], const bool (&ok)[NT], int cbeg, int cend, f32x4 (&acc)[NT])
+{
+    for (int c0 = cbeg; c0 < cend; c0 += 16 * K4_DEPTH) {
+        float4 a[K4_DEPTH], b[NT][K4_DEPTH];
+#pragma unroll
+        for (int i = 0; i < K4_DEPTH; ++i) {
+            const int c = c0 + 16 * i;
+            const bool in = c < cend;
+            a[i] = in ? *reinterpret_cast<const float4*>(wrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                b[t][i] = (in && ok[t]) ? *reinterpret_cast<const float4*>(xrow[t] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < K4_DEPTH; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = MFMA16(a[i].x, b[t][i].x, acc[t]); acc[t] = MFMA16(a[i].y, b[t][i].y, acc[t]);
+                acc[t] = MFMA16(a[i].z, b[t][i].z, acc[t]); acc[t] = MFMA16(a[i].w, b[t][i].w, acc[t]);
+            }
+    }
+}
+
 // 1x1 -> 4x4 (KS 4, pad 3):  y[n][pix][co] = epi(scale * sum_ci w[15-pix][co][ci] * x[n][ci]).
-// One wave per (pixel, 16 couts); NT tiles of 16 samples share the weight fragment.
+// One workgroup per (pixel, 16 couts): its four waves take a quarter of Cin each; NT tiles of 16 samples share the weight fragment.
 template <int NT>
 __global__ __launch_bounds__(256) void conv_k4_expand_kernel(ConvP p)
 {
+    __shared__ float red[4 * NT * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kk = lane >> 4;
     const int tiles_co = p.Cout >> 4;
-    const int wid = blockIdx.x * 4 + wave;
-    const int pix = wid / tiles_co, co0 = (wid - pix * tiles_co) << 4;
-    if (pix >= 16) return;
+    const int pix = blockIdx.x / tiles_co, co0 = (blockIdx.x - pix * tiles_co) << 4;
+    const int cper = (((p.Cin >> 4) + 3) >> 2) << 4;             // channels per wave, whole 16-channel steps
+    const int cbeg = wave * cper, cend = min(p.Cin, cbeg + cper);
     const float* wrow = p.w + ((size_t)(15 - pix) * p.Cout + co0 + li) * p.Cin + 4 * kk;
     for (int nb = blockIdx.y * 16 * NT; nb < p.N; nb += gridDim.y * 16 * NT) {
         f32x4 acc[NT];
@@ -729,24 +760,23 @@ __global__ __launch_bounds__(256) void conv_k4_expand_kernel(ConvP p)
             ok[t] = n < p.N;
             xrow[t] = p.x + (size_t)(ok[t] ? n : 0) * p.Cin + 4 * kk;
         }
-#pragma unroll 4
-        for (int c = 0; c < p.Cin; c += 16) {
-            const float4 a = *reinterpret_cast<const float4*>(wrow + c);
-            float4 b[NT];
+        k4_dot<NT>(wrow, xrow, ok, cbeg, cend, acc);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                b[t] = ok[t] ? *reinterpret_cast<const float4*>(xrow[t] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < NT; ++t)
+            *reinterpret_cast<float4*>(red + ((wave * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        __syncthreads();
+        if (wave < NT) {                              // wave t finishes tile t (fixed summation order)
+            const int t = wave;
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = MFMA16(a.x, b[t].x, acc[t]); acc[t] = MFMA16(a.y, b[t].y, acc[t]);
-                acc[t] = MFMA16(a.z, b[t].z, acc[t]); acc[t] = MFMA16(a.w, b[t].w, acc[t]);
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(red + ((q * NT + t) * 64 + lane) * 4);
+                sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
             }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
             const int n = nb + 16 * t + li;
-            if (n < p.N) k4_epilogue(p, acc[t], ((size_t)n * 16 + pix) * p.Cout + co0 + 4 * kk, co0 + 4 * kk);
+            if (n < p.N) k4_epilogue(p, sum, ((size_t)n * 16 + pix) * p.Cout + co0 + 4 * kk, co0 + 4 * kk);
         }
+        __syncthreads();
     }
 }
 
@@ -771,19 +801,7 @@ __global__ __launch_bounds__(1024) void conv_k4_reduce_kernel(ConvP p)
         ok[t] = n < p.N;
         xrow[t] = p.x + ((size_t)(ok[t] ? n : 0) * 16 + pix) * p.Cin + 4 * kk;
     }
-#pragma unroll 4
-    for (int c = 0; c < p.Cin; c += 16) {
-        const float4 a = *reinterpret_cast<const float4*>(wrow + c);
-        float4 b[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            b[t] = ok[t] ? *reinterpret_cast<const float4*>(xrow[t] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = MFMA16(a.x, b[t].x, acc[t]); acc[t] = MFMA16(a.y, b[t].y, acc[t]);
-            acc[t] = MFMA16(a.z, b[t].z, acc[t]); acc[t] = MFMA16(a.w, b[t].w, acc[t]);
-        }
-    }
+    k4_dot<NT>(wrow, xrow, ok, 0, p.Cin, acc);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         *reinterpret_cast<float4*>(red + ((pix * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
@@ -794,6 +812,69 @@ __global__ __launch_bounds__(1024) void conv_k4_reduce_kernel(ConvP p)
         for (int q = 0; q < 16; ++q) {
             const float4 v = *reinterpret_cast<const float4*>(red + ((q * NT + t) * 64 + lane) * 4);
             sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+        }
+        const int n = nb + 16 * t + li;
+        if (n < p.N) k4_epilogue(p, sum, (size_t)n * p.Cout + co0 + 4 * kk, co0 + 4 * kk);
+    }
+}
+
+// The same layer with the 16 input pixels on 16 workgroups (512 instead of 32 workgroups at 512 couts), the four waves of each on a
+// quarter of Cin: partial sums through the stream's scratch (pg_set_workspace), the workgroup that takes the last of a cout block's 16
+// tickets adds them in pixel order and runs the epilogue.  Agent-scope (sc1) accesses instead of fences: see conv_wino2_kernel.
+template <int NT>
+__global__ __launch_bounds__(256) void conv_k4_reduce_split_kernel(ConvP p, float* part, unsigned* count)
+{
+    __shared__ float red[4 * NT * 256];
+    __shared__ unsigned ticket;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int pix = blockIdx.x & 15, cot = blockIdx.x >> 4;
+    const int co0 = cot << 4, nb = blockIdx.y * 16 * NT;
+    const int blk = blockIdx.y * (p.Cout >> 4) + cot;
+    const int cper = (((p.Cin >> 4) + 3) >> 2) << 4;
+    const int cbeg = wave * cper, cend = min(p.Cin, cbeg + cper);
+    const float* wrow = p.w + ((size_t)pix * p.Cout + co0 + li) * p.Cin + 4 * kk;
+    f32x4 acc[NT];
+    const float* xrow[NT];
+    bool ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = nb + 16 * t + li;
+        ok[t] = n < p.N;
+        xrow[t] = p.x + ((size_t)(ok[t] ? n : 0) * 16 + pix) * p.Cin + 4 * kk;
+    }
+    k4_dot<NT>(wrow, xrow, ok, cbeg, cend, acc);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        *reinterpret_cast<float4*>(red + ((wave * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    constexpr int SC1 = 16;
+    const __amdgpu_buffer_rsrc_t rp = pg_make_rsrc(part + (size_t)blk * 16 * NT * 256, 16u * NT * 1024u);
+    if (wave < NT) {
+        const int t = wave;
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(red + ((q * NT + t) * 64 + lane) * 4);
+            sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(pg_u32x4{__float_as_uint(sum[0]), __float_as_uint(sum[1]), __float_as_uint(sum[2]), __float_as_uint(sum[3])},
+                                               rp, ((pix * NT + t) * 64 + lane) * 16, 0, SC1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(count + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != 15u) return;
+    if (threadIdx.x == 0) __hip_atomic_store(count + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave < NT) {
+        const int t = wave;
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const pg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, ((q * NT + t) * 64 + lane) * 16, 0, SC1);
+            sum[0] += __uint_as_float(v[0]); sum[1] += __uint_as_float(v[1]); sum[2] += __uint_as_float(v[2]); sum[3] += __uint_as_float(v[3]);
         }
         const int n = nb + 16 * t + li;
         if (n < p.N) k4_epilogue(p, sum, (size_t)n * p.Cout + co0 + 4 * kk, co0 + 4 * kk);
@@ -1045,7 +1126,7 @@ int launch_k4_conv(ConvP& p, hipStream_t s)
     if (p.pad == 3) {                                        // 1x1 -> 4x4
         const int nt = p.N <= 16 ? 1 : (p.N <= 32 ? 2 : 4);
         int gy = (p.N + 16 * nt - 1) / (16 * nt); if (gy > 8) gy = 8;
-        dim3 grid((16 * (p.Cout >> 4) + 3) / 4, gy);
+        dim3 grid(16 * (p.Cout >> 4), gy);
         snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_k4_expand_kernel<%d>", nt);
         if (nt == 1) hipLaunchKernelGGL(conv_k4_expand_kernel<1>, grid, dim3(256), 0, s, p);
         else if (nt == 2) hipLaunchKernelGGL(conv_k4_expand_kernel<2>, grid, dim3(256), 0, s, p);
@@ -1053,6 +1134,18 @@ int launch_k4_conv(ConvP& p, hipStream_t s)
     } else {                                                 // 4x4 -> 1x1
         const int nt = p.N <= 16 ? 1 : 2;
         dim3 grid(p.Cout >> 4, (p.N + 16 * nt - 1) / (16 * nt));
+        pgk::Workspace ws{};
+        const size_t nblk = (size_t)grid.x * grid.y;
+        if (g_tune[3] != 21 && nblk <= 256 && nblk <= pgk::WS_TICKETS && pgk::find_workspace(s, ws) &&
+            pgk::WS_HEAD + nblk * 16 * nt * 1024 <= ws.bytes) {          // few cout blocks: one workgroup per (block, input pixel)
+            dim3 sgrid(grid.x * 16, grid.y);
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_k4_reduce_split_kernel<%d>", nt);
+            float* part = reinterpret_cast<float*>(ws.ptr + pgk::WS_HEAD);
+            unsigned* count = reinterpret_cast<unsigned*>(ws.ptr);
+            if (nt == 1) hipLaunchKernelGGL(conv_k4_reduce_split_kernel<1>, sgrid, dim3(256), 0, s, p, part, count);
+            else hipLaunchKernelGGL(conv_k4_reduce_split_kernel<2>, sgrid, dim3(256), 0, s, p, part, count);
+            return (int)hipGetLastError();
+        }
         snprintf(g_last_kernel, sizeof(g_last_kernel), "conv_k4_reduce_kernel<%d>", nt);
         if (nt == 1) hipLaunchKernelGGL(conv_k4_reduce_kernel<1>, grid, dim3(1024), 0, s, p);
         else hipLaunchKernelGGL(conv_k4_reduce_kernel<2>, grid, dim3(1024), 0, s, p);

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include "pggan_hip.h"
 #include "bufload.h"
+#include "convp.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -783,21 +784,10 @@ thread_local char g_wino_last[64] = "";
 thread_local unsigned long long* g_wino_trace = nullptr;
 #endif
 // Scratch for launches that split K across workgroups, registered per (device, stream) by the host layer (pg_set_workspace):
-// [4096 tickets][partial outputs].  The library never allocates device memory itself.
-struct Workspace { int device; hipStream_t stream; char* ptr; size_t bytes; };
+// layout in convp.h.  The library never allocates device memory itself.
+using pgk::Workspace; using pgk::WS_TICKETS; using pgk::WS_HEAD; using pgk::find_workspace;
 std::mutex g_ws_mutex;
 std::vector<Workspace> g_ws;
-constexpr size_t WS_TICKETS = 4096, WS_HEAD = WS_TICKETS * sizeof(unsigned);
-
-bool find_workspace(hipStream_t s, Workspace& out)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    for (const Workspace& w : g_ws)
-        if (w.device == dev && w.stream == s) { out = w; return true; }
-    return false;
-}
 
 thread_local int g_wino_ksplit = -1;           // -1: built-in choice; 0 / 1: never split K across workgroups; n: n slices where legal
 thread_local int g_wino_vec = 0;               // 2 / 4: first-generation kernel with K chunks of 4*vec channels; 0: second-generation kernel,
@@ -809,6 +799,16 @@ extern "C" const char* pg_debug_last_wino_kernel(void) { return g_wino_last; }
 #ifdef PG_WINO_TRACE
 extern "C" int pg_debug_wino_trace(void* buf) { g_wino_trace = (unsigned long long*)buf; return 0; }
 #endif
+bool pgk::find_workspace(hipStream_t s, pgk::Workspace& out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (const Workspace& w : g_ws)
+        if (w.device == dev && w.stream == s) { out = w; return true; }
+    return false;
+}
+
 extern "C" int pg_set_workspace(pg_stream_t stream, void* ptr, size_t bytes)
 {
     if ((ptr == nullptr) != (bytes == 0)) return PG_E_ARG;

@@ -54,6 +54,12 @@ struct WgP {
 #endif
 };
 
+// Scratch registered for a stream by pg_set_workspace (conv_wino.hip): [WS_TICKETS zero-initialised, self-resetting tickets][partial sums].
+// Launches on one stream are ordered, so every kernel that slices a reduction across workgroups may use the whole of it.
+struct Workspace { int device; hipStream_t stream; char* ptr; size_t bytes; };
+constexpr size_t WS_TICKETS = 4096, WS_HEAD = WS_TICKETS * sizeof(unsigned);
+bool find_workspace(hipStream_t s, Workspace& out);
+
 // Row-streaming kernels (conv_strip.hip).  PG_E_UNSUP = "not this shape": the caller keeps its tile kernel.  ``name`` receives the
 // kernel symbol for pg_debug_last_conv_kernel.
 int launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len);

@@ -72,7 +72,7 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
         sb = torch.empty((N, ho, wo, cout // 4), device=x.device, dtype=torch.uint8)
         mask, flags = sb, flags | FLAG_SIGNS_OUT
     _lib.call('pg_conv2d_nhwc', _p(x), _p(w), _p(bias), _p(mask), _p(y), N, Hin, Win, cin, cout, ks, pad,
-              flags, scale, slope, mask_slope, _stream())
+              flags, scale, slope, mask_slope, _stream_with_workspace() if ks == 4 else _stream())
     return (y, sb) if signs_out else y
 
 

@@ -60,6 +60,26 @@ def test_conv2d_fwd_and_masked(case):
     check('conv linear %s' % (case,), y, E.conv2d(x, w, b, N, H, H, ks, pad, 1.0, slope=1.0, ups=bool(ups)))
 
 
+@pytest.mark.parametrize('case', [(3, 512, 512), (9, 80, 32), (48, 64, 64), (130, 16, 16)])
+def test_conv_4x4_to_1x1_split_over_pixels(case):
+    """D's last conv (4x4 -> 1x1, network.py:213-221) with one workgroup per (cout block, input pixel) and the last-arriver
+    fix-up through the stream's scratch (conv_k4_reduce_split_kernel) against the one-workgroup-per-cout-block kernel
+    (pg_debug_set_tuning(3, 21)); repeats are bit-identical (the 16 partial sums are added in pixel order)."""
+    N, ci, co = case
+    lib = pg._lib.load()
+    x, w, b = dev(rnd(N, 4, 4, ci)), dev(rnd(4, 4, co, ci, seed=1) * 0.2), dev(rnd(co, seed=2))
+    ys = [ops.conv2d(x, w, b, N, 4, 4, 4, 0, 0.37, slope=0.2) for _ in range(3)]
+    assert lib.pg_debug_last_conv_kernel().decode().startswith('conv_k4_reduce_split_kernel')
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    assert lib.pg_debug_set_tuning(3, 21) == 0
+    try:
+        ref = ops.conv2d(x, w, b, N, 4, 4, 4, 0, 0.37, slope=0.2)
+        assert lib.pg_debug_last_conv_kernel().decode().startswith('conv_k4_reduce_kernel')
+    finally:
+        lib.pg_debug_set_tuning(3, -1)
+    assert rel_err(ys[0], ref) < 1e-6
+
+
 POOL_CASES = [(2, 32, 64, 64), (3, 16, 128, 96), (2, 64, 16, 16), (1, 64, 8, 8), (2, 32, 8, 16), (2, 16, 12, 20), (5, 4, 32, 16),
               (3, 8, 528, 512), (1, 256, 8, 16), (3, 128, 16, 32), (2, 64, 32, 64), (9, 16, 256, 256), (3, 32, 256, 512), (1, 8, 64, 32),
               (2, 2, 16, 16), (2, 32, 16, 16), (1, 64, 32, 16), (3, 32, 8, 16)]
