@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 pg = importlib.import_module('pggan-pytorch_amd')
 ops, lib = pg.ops, pg._lib.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-CASES = [(3, 8, 512, 512), (9, 8, 512, 512), (3, 16, 512, 512), (9, 16, 512, 512), (3, 32, 512, 256), (3, 32, 256, 256), (3, 32, 256, 512),
+CASES = [(3, 8, 512, 512), (3, 8, 256, 512), (9, 8, 512, 512), (3, 16, 512, 512), (9, 16, 512, 512), (3, 32, 512, 256), (3, 32, 256, 256), (3, 32, 256, 512),
          (3, 32, 512, 512), (9, 32, 512, 512), (9, 32, 256, 256), (3, 64, 128, 128), (3, 64, 256, 128), (3, 64, 128, 256), (3, 128, 64, 64)]
 
 
@@ -37,7 +37,7 @@ for N, H, ci, co in CASES:
     row = []
     t = timed(lambda: ops.conv2d(x, w, bias, N, H, H, 3, 1, 0.5, 0.2))
     row.append('direct %6.1f us %5.1f TF (%s)' % (t, flop / t * 1e-6, lib.pg_debug_last_conv_kernel().decode()[5:28]))
-    for ks in (0, -1, 2, 3, 4, 6, 8):
+    for ks in [int(v) for v in os.environ.get('KS', '0,-1,2,3,4,6,8').split(',')]:
         lib.pg_debug_set_wino_ksplit(ks)
         t = timed(lambda: ops.conv2d_wino(x, u, bias, N, H, H, 0.5, 0.2))
         split = lib.pg_debug_last_wino_kernel().decode().endswith('true>')
