@@ -973,7 +973,7 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
         } else { p.kcper = nch; p.mKs = 0; p.ks_count = nullptr; p.ks_part = nullptr; }
         dim3 grid2((unsigned)(nblk * ks));
         if (ks > 1) snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d, true>", ncb, xk, xs);
-        else snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d>", ncb, xk, xs);
+        else snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d, false>", ncb, xk, xs);   // (as the profiler demangles it)
         void (*fn)(WinoP) = ks > 1 ? (xs == 3 ? conv_wino2_kernel<1, 1, 3, true> : conv_wino2_kernel<1, 1, 4, true>)
                           : ncb == 2 ? (xs == 3 ? conv_wino2_kernel<2, 1, 3> : conv_wino2_kernel<2, 1, 4>)
                           : xk == 2 ? conv_wino2_kernel<1, 2, 7> : (xs == 3 ? conv_wino2_kernel<1, 1, 3> : conv_wino2_kernel<1, 1, 4>);
