@@ -957,7 +957,13 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
         if (ncb == 1 && xk == 1 && !pn_r && !pnb_y && g_wino_ksplit != 0 && g_wino_ksplit != 1 && nblk <= (int)WS_TICKETS &&
             find_workspace((hipStream_t)stream, ws)) {
             if (g_wino_ksplit > 1) ks = g_wino_ksplit;
-            else if (nblk <= 432) { ks = 864 / nblk; if (ks > 8) ks = 8; if (ks > nch / 4) ks = nch / 4; }     // measured: tools/bench_ksplit.py
+            else {                                            // measured: tools/bench_ksplit.py (isolated) and in-step sweeps of the three constants
+                static const int ks_pairs = getenv("PG_WINO_KS_PAIRS") ? atoi(getenv("PG_WINO_KS_PAIRS")) : 432;
+                static const int ks_target = getenv("PG_WINO_KS_TARGET") ? atoi(getenv("PG_WINO_KS_TARGET")) : 864;
+                static const int ks_max = getenv("PG_WINO_KS_MAX") ? atoi(getenv("PG_WINO_KS_MAX")) : 8;
+                static const int ks_minch = getenv("PG_WINO_KS_MINCH") ? atoi(getenv("PG_WINO_KS_MINCH")) : 4;
+                if (nblk <= ks_pairs) { ks = ks_target / nblk; if (ks > ks_max) ks = ks_max; if (ks > nch / ks_minch) ks = nch / ks_minch; }
+            }
             if (ks > nch) ks = nch;
             if (ks > 1) {
                 p.kcper = (nch + ks - 1) / ks;
