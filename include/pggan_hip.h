@@ -140,8 +140,13 @@ int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, const unsigned
  *   epilogues of pg_conv2d_pool_nhwc (ypool/pool_other/pool_a/pool_b/pool_only) and pg_conv2d_unpool_nhwc
  *   (yup/upmask/up_mul); pass NULL for the ones not wanted.  Returns PG_E_UNSUP for shapes it does not take.      */
 int pg_wino_transform_weights(const float* w, float* u, int Cout, int Cin, pg_stream_t stream);
+/* ... for nlayers layers in one launch (layer i: weights at wbase + woff[i], result at ubase + uoff[i]).  transposed (may be NULL):
+ * non-zero = layer i is the BACKWARD-DATA form of a forward layer taken straight from that layer's parameter: cout[i] / cin[i] are the
+ * channel counts of the backward-data conv (= the forward layer's Cin / Cout), the source is the forward w[3][3][cin[i]][cout[i]], and
+ * the result equals pg_wino_transform_weights of pg_pack_dgrad_weights of it -- without the intermediate copy.                     */
 int pg_wino_transform_weights_batched(const float* wbase, float* ubase, int nlayers, const int64_t* woff,
-                                      const int64_t* uoff, const int* cout, const int* cin, pg_stream_t stream);
+                                      const int64_t* uoff, const int* cout, const int* cin, const int* transposed,
+                                      pg_stream_t stream);
 int pg_conv2d_wino_nhwc(const float* x, const float* u, const float* bias, const float* mask, float* y,
                         float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
                         float* yup, const float* upmask, float up_mul,

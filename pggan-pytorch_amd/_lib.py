@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 class PgganLibraryError(RuntimeError):
@@ -34,7 +34,7 @@ SIGNATURES = {
     'pg_conv2d_unpooled_nhwc': [P, P, P, F, F, P, P, I, I, I, I, I, I, F, F, P],
     'pg_conv2d_wgrad_unpooled_nhwc': [P, P, P, F, F, P, P, I, I, I, I, I, F, P],
     'pg_wino_transform_weights': [P, P, I, I, P],
-    'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P],
+    'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P, P],
     'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wino_pixelnorm_nhwc': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wino_pnbwd_nhwc': [P, P, P, P, P, I, P, F, F, I, I, I, I, I, F, F, P],

@@ -740,6 +740,7 @@ struct WinoBatch {
     int first_block[WB_MAX + 1];
     long long woff[WB_MAX], uoff[WB_MAX];
     int cout[WB_MAX], cin[WB_MAX];
+    unsigned transposed;                        // bit l: layer l is a backward-data form (see pg_wino_transform_weights_batched)
 };
 
 __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* __restrict__ wbase, float* __restrict__ ubase, WinoBatch d)
@@ -750,6 +751,49 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
     float* u = ubase + d.uoff[l];
     const size_t n = (size_t)d.cout[l] * d.cin[l];
     const size_t i = (size_t)(blockIdx.x - d.first_block[l]) * 256 + threadIdx.x;
+    const size_t xs = (size_t)d.cout[l] * 8;               // stride between Winograd positions inside a pack
+    if ((d.transposed >> l) & 1u) {
+        // Backward-data form straight from the forward parameter w[3][3][Cin'][Cout'] (flipped taps, channels swapped): the element
+        // (co', ci') reads w[8 - tap][ci'][co'], i.e. the contiguous direction of the SOURCE is co' while the packs want ci'
+        // contiguous.  A block covers 32 co' x 8 ci' (one pack): read with co' fastest (128-byte rows), transpose through LDS, write
+        // with the pack order.  (Replaces pg_pack_dgrad_weights + a forward-form transform of its output: one read of w less and no
+        // intermediate copy for the layers whose backward-data conv always runs Winograd.)
+        __shared__ float tile[16][32 * 9];
+        const int cout = d.cout[l];
+        const size_t blk = blockIdx.x - d.first_block[l];
+        const size_t ncob = (size_t)(cout + 31) / 32, cob = blk % ncob, pk = blk / ncob;
+        const int rc = threadIdx.x & 31, rk = threadIdx.x >> 5;                 // read mapping: co' = 32 cob + rc, ci' = 8 pk + rk
+        const size_t co = 32 * cob + rc, ci = 8 * pk + rk;
+        float g[3][3], t[4][3];
+        const bool live = co < (size_t)cout && ci < (size_t)d.cin[l];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = live ? w[(size_t)(8 - (a * 3 + b)) * n + ci * cout + co] : 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
+            t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            tile[4 * a + 0][rc * 9 + rk] = t[a][0];
+            tile[4 * a + 1][rc * 9 + rk] = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]);
+            tile[4 * a + 2][rc * 9 + rk] = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]);
+            tile[4 * a + 3][rc * 9 + rk] = t[a][2];
+        }
+        __syncthreads();
+        const int wc = threadIdx.x >> 3, wk = threadIdx.x & 7;                  // write mapping: pack order
+        const size_t wco = 32 * cob + wc, wci = 8 * pk + wk;
+        if (wco < (size_t)cout && wci < (size_t)d.cin[l]) {
+            float* ub = u + wino_u_index(0, wco, wci, cout);
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) ub[(size_t)xi * xs] = tile[xi][wc * 9 + wk];
+        }
+        return;
+    }
     if (i >= n) return;
     const size_t pk = i / ((size_t)8 * d.cout[l]), rr = i - pk * 8 * d.cout[l];      // see wino_weights_kernel
     const size_t co = rr >> 3, ci = 8 * pk + (rr & 7), src = co * d.cin[l] + ci;
@@ -766,7 +810,6 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
         t[3][b] = g[2][b];
     }
     float* ub = u + wino_u_index(0, co, ci, d.cout[l]);
-    const size_t xs = (size_t)d.cout[l] * 8;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         ub[(size_t)(4 * a + 0) * xs] = t[a][0];
@@ -850,12 +893,14 @@ extern "C" int pg_wino_transform_weights(const float* w, float* u, int Cout, int
 }
 
 extern "C" int pg_wino_transform_weights_batched(const float* wbase, float* ubase, int nlayers, const int64_t* woff,
-                                                 const int64_t* uoff, const int* cout, const int* cin, pg_stream_t stream)
+                                                 const int64_t* uoff, const int* cout, const int* cin, const int* transposed,
+                                                 pg_stream_t stream)
 {
     if (!wbase || !ubase || nlayers <= 0 || !woff || !uoff || !cout || !cin) return PG_E_ARG;
     for (int l0 = 0; l0 < nlayers; l0 += WB_MAX) {
         WinoBatch d;
         d.n = nlayers - l0 < WB_MAX ? nlayers - l0 : WB_MAX;
+        d.transposed = 0;
         int total = 0;
         for (int l = 0; l < d.n; ++l) {
             const int i = l0 + l;
@@ -863,7 +908,10 @@ extern "C" int pg_wino_transform_weights_batched(const float* wbase, float* ubas
             if (cin[i] & 7) return PG_E_ALIGN;
             d.first_block[l] = total;
             d.woff[l] = woff[i]; d.uoff[l] = uoff[i]; d.cout[l] = cout[i]; d.cin[l] = cin[i];
-            total += (int)(((size_t)cout[i] * cin[i] + 255) / 256);
+            if (transposed && transposed[i]) {
+                d.transposed |= 1u << l;
+                total += ((cout[i] + 31) / 32) * (cin[i] / 8);               // one block per (32 couts, 8-channel pack)
+            } else total += (int)(((size_t)cout[i] * cin[i] + 255) / 256);
         }
         d.first_block[d.n] = total;
         hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, wbase, ubase, d);

@@ -80,18 +80,22 @@ def _derived(net):
         return
     base = net._flat_param.data_ptr()
     live = set(id(m) for m in _live_conv_layers(net))
-    todo = [m for m in net._layers() if m.kind == 'conv' and m._wt is not None and id(m) in live]
+    # flipped / transposed copies: only for the layers whose backward-data conv has asked for one (_wt marks them) -- the layers that
+    # always run Winograd there get their backward-data form straight from the parameter (transposed=True below)
+    todo = [m for m in net._layers() if m.kind == 'conv' and m._wt is not None and id(m) in live and (getattr(m, '_wt_wanted', False) or not WTU_FROM_PARAM)]
     packs = [((m.conv.weight.data_ptr() - base) // 4, m.ksize, m.conv.weight.shape[2], m.conv.weight.shape[3]) for m in todo]
     # ... and of those only the layers the Winograd path has actually asked for (_wino marks them): the 512-channel layers of the
-    # 4x4 / 8x8 stages never reach the workgroup threshold at the reference minibatches, yet are half of all Winograd-domain bytes
+    # 4x4 stage never reach it, yet are a large part of all Winograd-domain bytes
     wl = [(m, woff, uoff) for m, woff, uoff in (net._wino_layers or []) if id(m) in live and getattr(m, '_wino_wanted', False)]
     wl = wl if USE_WINOGRAD else []
 
-    def backward_copies():                       # what only the backward-data convs read: flipped / transposed weights and their Winograd form
-        ops.pack_dgrad_weights_batched(net._flat_param, net._flat_wt, packs)
+    def backward_copies():                       # what only the backward-data convs read: flipped / transposed weights and the Winograd form of those
+        if packs:
+            ops.pack_dgrad_weights_batched(net._flat_param, net._flat_wt, packs)
         if wl:
-            ops.wino_transform_weights_batched(net._flat_wt, net._flat_wtu,
-                                               [(woff, uoff, m.conv.weight.shape[3], m.conv.weight.shape[2]) for m, woff, uoff in wl])
+            ops.wino_transform_weights_batched(net._flat_param if WTU_FROM_PARAM else net._flat_wt, net._flat_wtu,
+                                               [(woff, uoff, m.conv.weight.shape[3], m.conv.weight.shape[2]) for m, woff, uoff in wl],
+                                               transposed=WTU_FROM_PARAM)
     if wl:                                       # the forward convs' Winograd-domain weights: needed by the very next launch
         ops.wino_transform_weights_batched(net._flat_param, net._flat_wu,
                                            [(woff, uoff, m.conv.weight.shape[2], m.conv.weight.shape[3]) for m, woff, uoff in wl])
@@ -130,6 +134,9 @@ def _await_backward_copies(net):
 
 def _wt(net, layer):
     """Backward-data (flipped/transposed) copy of a conv layer's weights, refreshed lazily."""
+    if not getattr(layer, '_wt_wanted', False):         # first request: from now on the refresh after every update includes this layer
+        layer._wt_wanted = True
+        net._derived_ver = None
     _derived(net)
     _assert_live(net, layer)
     _await_backward_copies(net)
@@ -277,6 +284,8 @@ def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
 # half-occupancy MFMA kernels share the CUs instead of running back to back.
 ASYNC_WGRAD = True
 ASYNC_DERIVED = _os.environ.get('PGGAN_ASYNC_DERIVED', '1') != '0'
+# 0: every live layer gets a flipped / transposed copy and the backward-data Winograd form is derived from that copy (round 2)
+WTU_FROM_PARAM = _os.environ.get('PGGAN_WTU_FROM_PARAM', '1') != '0'
 _SIDE = {}
 
 

@@ -93,8 +93,10 @@ def wino_transform_weights(w, u=None):
     return u
 
 
-def wino_transform_weights_batched(flat_w, flat_u, layers):
-    """layers: [(w element offset in flat_w, u element offset in flat_u, cout, cin), ...]; one launch."""
+def wino_transform_weights_batched(flat_w, flat_u, layers, transposed=False):
+    """layers: [(w element offset in flat_w, u element offset in flat_u, cout, cin), ...]; one launch.  ``transposed``: every
+    layer is the backward-data form of a forward layer, computed straight from that layer's parameter (cout / cin are those of
+    the backward-data conv, i.e. the forward layer's cin / cout)."""
     import ctypes
     n = len(layers)
     if n == 0:
@@ -103,8 +105,10 @@ def wino_transform_weights_batched(flat_w, flat_u, layers):
     uoff = (ctypes.c_int64 * n)(*[l[1] for l in layers])
     co = (ctypes.c_int * n)(*[l[2] for l in layers])
     ci = (ctypes.c_int * n)(*[l[3] for l in layers])
+    tr = (ctypes.c_int * n)(*([1] * n)) if transposed else None
     _lib.call('pg_wino_transform_weights_batched', _p(flat_w), _p(flat_u), n, ctypes.cast(woff, ctypes.c_void_p),
-              ctypes.cast(uoff, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), ctypes.cast(ci, ctypes.c_void_p), _stream())
+              ctypes.cast(uoff, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), ctypes.cast(ci, ctypes.c_void_p),
+              ctypes.cast(tr, ctypes.c_void_p) if tr is not None else None, _stream())
 
 
 def signbytes_to_mask(b):

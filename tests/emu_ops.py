@@ -118,9 +118,12 @@ def wino_transform_weights(w, u=None):
     return out
 
 
-def wino_transform_weights_batched(flat_w, flat_u, layers):
+def wino_transform_weights_batched(flat_w, flat_u, layers, transposed=False):
     for woff, uoff, co, ci in layers:
-        w = flat_w[woff:woff + 9 * co * ci].view(3, 3, co, ci)
+        if transposed:                                   # backward-data form straight from the forward parameter [3][3][ci][co]
+            w = flat_w[woff:woff + 9 * co * ci].view(3, 3, ci, co).flip(0, 1).permute(0, 1, 3, 2).contiguous()
+        else:
+            w = flat_w[woff:woff + 9 * co * ci].view(3, 3, co, ci)
         flat_u[uoff:uoff + 16 * co * ci].view(16, co, ci).copy_(_wino_of(w))
 
 

@@ -160,6 +160,35 @@ def test_conv2d_wino_k_split(case, slices):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shapes', [[(64, 32), (16, 48), (512, 512)], [(8, 16), (40, 8), (24, 136)]])
+def test_backward_data_form_straight_from_the_parameter(shapes):
+    """pg_wino_transform_weights_batched(transposed): the Winograd form of the flipped / transposed weights computed from the forward
+    parameter in one pass == the forward-form transform of pg_pack_dgrad_weights' output, bit for bit (same arithmetic, another
+    read order), for several layers of one flat buffer; couts that are not multiples of 32, cins of one pack."""
+    ops = pg.ops
+    ws = [rnd(3, 3, co, ci, seed=7 + i) * 0.3 for i, (co, ci) in enumerate(shapes)]
+    flat = torch.cat([w.reshape(-1) for w in ws]).cuda()
+    offs, o = [], 0
+    for w in ws:
+        offs.append(o); o += w.numel()
+    uoffs, uo = [], 0
+    for co, ci in shapes:
+        uoffs.append(uo); uo += 16 * co * ci
+    wt = torch.zeros_like(flat)
+    ops.pack_dgrad_weights_batched(flat, wt, [(offs[i], 3, co, ci) for i, (co, ci) in enumerate(shapes)])
+    want = torch.zeros(uo, device='cuda')
+    ops.wino_transform_weights_batched(wt, want, [(offs[i], uoffs[i], ci, co) for i, (co, ci) in enumerate(shapes)])
+    got = torch.full((uo,), float('nan'), device='cuda')
+    ops.wino_transform_weights_batched(flat, got, [(offs[i], uoffs[i], ci, co) for i, (co, ci) in enumerate(shapes)], transposed=True)
+    assert torch.equal(got, want)
+    host = torch.zeros(uo)
+    E.wino_transform_weights_batched(flat.cpu(), host, [(offs[i], uoffs[i], ci, co) for i, (co, ci) in enumerate(shapes)], transposed=True)
+    for i, (co, ci) in enumerate(shapes):                                    # (the device stores 8-channel packs)
+        u = got[uoffs[i]:uoffs[i] + 16 * co * ci].view(16, ci, co)                # nominal shape of the backward-data form: [16][cout' = ci][cin' = co]
+        assert rel_err(ops.wino_unpack(u), host[uoffs[i]:uoffs[i] + 16 * co * ci].view(16, ci, co)) < 1e-6
+
+
+@pytest.mark.gpu
 def test_workspace_registration_errors_and_unsplit_without_scratch():
     lib = pg._lib.load()
     import ctypes
