@@ -18,16 +18,27 @@ def _stream():
 
 
 # Scratch of the launches that slice K across workgroups (include/pggan_hip.h: pg_set_workspace), one per (device, stream),
-# zero-filled, registered with the library the first time a Winograd conv is launched on that stream and kept for good.
+# zero-filled, registered with the library the first time a conv is launched on that stream and kept for good.  Streams that are
+# being captured into a hipGraph (a new stream per capture) all share ONE more buffer per device, allocated eagerly the first time
+# any eager stream gets its own: the engine replays its graphs one after the other, and a buffer allocated inside a capture would
+# belong to that graph's memory pool.
 WORKSPACE_BYTES = int(_os.environ.get('PGGAN_WORKSPACE_MB', '32')) << 20
 _workspaces = {}
+_capture_workspace = {}
 
 
 def _stream_with_workspace():
     dev = torch._C._cuda_getDevice()
     s = torch._C._cuda_getCurrentRawStream(dev)
     if (dev, s) not in _workspaces:
-        ws = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device='cuda:%d' % dev) if WORKSPACE_BYTES > 0 else None
+        ws = None
+        if WORKSPACE_BYTES > 0:
+            if torch.cuda.is_current_stream_capturing():
+                ws = _capture_workspace.get(dev)             # (None before the first eager launch: those kernels run unsplit)
+            else:
+                ws = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device='cuda:%d' % dev)
+                if dev not in _capture_workspace:
+                    _capture_workspace[dev] = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device='cuda:%d' % dev)
         if ws is not None:
             _lib.call('pg_set_workspace', s, ws.data_ptr(), ws.numel())
         _workspaces[(dev, s)] = ws

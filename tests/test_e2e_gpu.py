@@ -294,6 +294,12 @@ def test_hipgraph_replay_matches_eager():
     assert float((g0 - g1).abs().max()) < 2 * 0.001 * 5 + 1e-4
     assert float((d0 - d1).abs().max()) < 2 * 0.001 * 5 + 1e-4
     assert rel_err(g1, g0) < 2e-2 and rel_err(d1, d0) < 2e-2
+    # every capture runs on a stream of its own: they all share ONE scratch per device (ops._stream_with_workspace), whatever
+    # number of graphs has been captured so far, next to one per eager stream
+    shared = pg.ops._capture_workspace[torch.cuda.current_device()]
+    owners = [k for k, v in pg.ops._workspaces.items() if v is shared]
+    assert owners, 'no captured stream launched a conv that takes the scratch'
+    assert len({id(v) for v in pg.ops._workspaces.values() if v is not None}) <= 4
 
 
 def test_whole_module_pickle_roundtrip(tmp_path):
