@@ -26,6 +26,8 @@ int pg_debug_set_wino(int vec);
 /* K slices per (tile block, cout block) of the second-generation Winograd conv: -1 built-in choice, 0 / 1 never split, n: n slices
  * wherever a scratch is registered (pg_set_workspace) and the layer has that many 8-channel chunks. */
 int pg_debug_set_wino_ksplit(int n);
+/* 0: the general epilogue for every launch of the second-generation Winograd conv (A/B against the specialised ones); -1: built-in choice. */
+int pg_debug_set_wino_epi(int mode);
 
 #ifdef __cplusplus
 }

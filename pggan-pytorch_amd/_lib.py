@@ -97,6 +97,7 @@ DEBUG_SIGNATURES = {
     'pg_debug_set_tuning': [I, I],
     'pg_debug_set_wino': [I],
     'pg_debug_set_wino_ksplit': [I],
+    'pg_debug_set_wino_epi': [I],
 }
 
 _lib = None

@@ -205,6 +205,54 @@ __device__ __forceinline__ void wino_epilogue(const WinoP& p, const f32x4 (&acc)
     wino_epilogue_q(p, yq, cb, ni, oy0, ox0);
 }
 
+// The two epilogues most launches of a train step take, without the run-time option tests and the 64-bit address arithmetic of
+// the general one: EPI_PLAIN = bias + LeakyReLU -> y (forward convs), EPI_MASKB = LeakyReLU' factors from sign bytes -> y
+// (backward-data and tangent convs).  One raw buffer per image, 32-bit offsets; the host picks them when nothing else is asked for.
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_MASKB = 2 };
+
+template <int EPI>
+__device__ __forceinline__ void wino_epilogue_fast(const WinoP& p, const f32x4 (&yq)[4], int cb, int ni, int oy0, int ox0)
+{
+    static_assert(EPI == EPI_PLAIN || EPI == EPI_MASKB, "specialised epilogues");
+    if (cb >= p.Cout || ni >= p.N) return;
+    const unsigned npix = (unsigned)(p.H * p.W);
+    const __amdgpu_buffer_rsrc_t ry = pg_make_rsrc(p.y + (size_t)ni * npix * p.Cout, npix * (unsigned)p.Cout * 4u);
+    const unsigned pix0 = (unsigned)(oy0 * p.W + ox0);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned char mb[4] = {0, 0, 0, 0};
+    if constexpr (EPI == EPI_PLAIN) {
+        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + cb);
+    } else {
+        const __amdgpu_buffer_rsrc_t rm = pg_make_rsrc(reinterpret_cast<const unsigned char*>(p.mask) + (size_t)ni * npix * (p.Cout >> 2),
+                                                       npix * (unsigned)(p.Cout >> 2));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            mb[q] = __builtin_amdgcn_raw_buffer_load_b8(rm, (int)((pix0 + (unsigned)((q >> 1) * p.W + (q & 1))) * (unsigned)(p.Cout >> 2) + (unsigned)(cb >> 2)), 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = yq[q];
+        float4 o = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
+        if constexpr (EPI == EPI_PLAIN) {
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+            o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
+            o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
+        } else {
+            const float4 f = sign_factors(mb[q], p.mask_slope);
+            o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(pg_u32x4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)},
+                                               ry, (int)(((pix0 + (unsigned)((q >> 1) * p.W + (q & 1))) * (unsigned)p.Cout + (unsigned)cb) * 4u), 0, 0);
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void wino_epilogue_sel(const WinoP& p, const f32x4 (&yq)[4], int cb, int ni, int oy0, int ox0)
+{
+    if constexpr (EPI == EPI_GENERIC) wino_epilogue_q(p, yq, cb, ni, oy0, ox0);
+    else wino_epilogue_fast<EPI>(p, yq, cb, ni, oy0, ox0);
+}
+
 
 // conv -> bias -> LeakyReLU -> PixelNorm (network.py:44-52 after :32-41) for a workgroup that holds ALL couts of its tiles (Cout <=
 // 16 NCB): the lane's 4 couts per block are squared and summed lane-locally, the four lanes of a tile (li + 16 kk) fold with two
@@ -519,10 +567,11 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
 //   * XS: DMA instructions per thread for one input region = 256-slot (4 KB) units of an X buffer.  The usual region (one image,
 //     8 x 8 tiles: 18 x 19 slots x 2 planes = 684) fits XS = 3: 2 x (12 + 8) KB = 40 KB of LDS per workgroup, FOUR workgroups per
 //     CU (124 VGPRs allow four waves per SIMD) instead of three with XS = 4.
-template <int NCB, int XK, int XS, bool KSP = false>
+template <int NCB, int XK, int XS, bool KSP = false, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 waves per SIMD: <= 256 VGPRs + AGPRs
 {
     static_assert(!KSP || (NCB == 1 && XK == 1), "K split: 16 couts per workgroup, 8-channel input staging");
+    static_assert(EPI == EPI_GENERIC || (NCB == 1 && XK == 1), "specialised epilogues: 16 couts per workgroup");
     constexpr int KC = 8;
     constexpr int XPL = 2 * XK;                              // channel-quad planes of the staged input region
     static_assert(XK == 1 ? (XS == 3 || XS == 4) : XS == 7, "input region: <= 768 / 1024 slots (XK = 1), 1792 (XK = 2)");
@@ -717,7 +766,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
                 const pg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rp, ((s2 * 4 + q) * 256 + tid) * 16, 0, SC1);
                 yq[q] += f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
             }
-        wino_epilogue_q(p, yq, co0 + 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
+        wino_epilogue_sel<EPI>(p, yq, co0 + 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
+    } else if constexpr (EPI != EPI_GENERIC) {
+        f32x4 yq[4];
+        wino_output_transform(acc[0], yq);
+        wino_epilogue_fast<EPI>(p, yq, co0 + 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
     } else if (p.pn_r) {                                             // (workgroup-uniform; the host launches ncob == 1 then)
         wino_epilogue_pixelnorm<NCB>(p, acc, 4 * kk, n0 + ttn, 2 * (ty0 + tty), 2 * (tx0 + ttx));
     } else if (p.pnb_y) {
@@ -832,6 +885,7 @@ using pgk::Workspace; using pgk::WS_TICKETS; using pgk::WS_HEAD; using pgk::find
 std::mutex g_ws_mutex;
 std::vector<Workspace> g_ws;
 
+thread_local int g_wino_epi = -1;              // 0: general epilogue everywhere (pg_debug_set_wino_epi)
 thread_local int g_wino_ksplit = -1;           // -1: built-in choice; 0 / 1: never split K across workgroups; n: n slices where legal
 thread_local int g_wino_vec = 0;               // 2 / 4: first-generation kernel with K chunks of 4*vec channels; 0: second-generation kernel,
                                                // built-in choice of couts per workgroup; 11 / 12: second generation, 16 / 32 couts (pg_debug_set_wino)
@@ -866,6 +920,13 @@ extern "C" int pg_set_workspace(pg_stream_t stream, void* ptr, size_t bytes)
             return 0;
         }
     if (ptr) g_ws.push_back(Workspace{dev, (hipStream_t)stream, (char*)ptr, bytes});
+    return 0;
+}
+
+extern "C" int pg_debug_set_wino_epi(int mode)
+{
+    if (mode != -1 && mode != 0) return PG_E_ARG;
+    g_wino_epi = mode;
     return 0;
 }
 
@@ -1026,11 +1087,24 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
             p.ks_count = reinterpret_cast<unsigned*>(ws.ptr); p.ks_part = reinterpret_cast<float*>(ws.ptr + WS_HEAD);
         } else { p.kcper = nch; p.mKs = 0; p.ks_count = nullptr; p.ks_part = nullptr; }
         dim3 grid2((unsigned)(nblk * ks));
-        if (ks > 1) snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d, true>", ncb, xk, xs);
-        else snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d, false>", ncb, xk, xs);   // (as the profiler demangles it)
-        void (*fn)(WinoP) = ks > 1 ? (xs == 3 ? conv_wino2_kernel<1, 1, 3, true> : conv_wino2_kernel<1, 1, 4, true>)
-                          : ncb == 2 ? (xs == 3 ? conv_wino2_kernel<2, 1, 3> : conv_wino2_kernel<2, 1, 4>)
-                          : xk == 2 ? conv_wino2_kernel<1, 2, 7> : (xs == 3 ? conv_wino2_kernel<1, 1, 3> : conv_wino2_kernel<1, 1, 4>);
+
+        // the two specialised epilogues (see wino_epilogue_fast) when the launch asks for nothing else
+        static const int epi_env = getenv("PG_WINO_EPI") ? atoi(getenv("PG_WINO_EPI")) : 1;              // 0: general epilogue everywhere (A/B)
+        int epi = EPI_GENERIC;
+        if (ncb == 1 && xk == 1 && g_wino_epi != 0 && epi_env != 0 && !ypool && !yup && !p.y_bytes && !p.ysigns && !pn_r && !pnb_y &&
+            (long long)H * W * Cout * 4 < (1ll << 31)) {
+            if (!p.mask) epi = EPI_PLAIN;
+            else if (p.mask_bytes) epi = EPI_MASKB;
+        }
+        void (*fn)(WinoP);
+#define PG_W2(XS_, KSP_) (epi == EPI_PLAIN ? conv_wino2_kernel<1, 1, XS_, KSP_, EPI_PLAIN> : epi == EPI_MASKB ? conv_wino2_kernel<1, 1, XS_, KSP_, EPI_MASKB> \
+                                                                                                             : conv_wino2_kernel<1, 1, XS_, KSP_, EPI_GENERIC>)
+        if (ncb == 2) fn = xs == 3 ? conv_wino2_kernel<2, 1, 3> : conv_wino2_kernel<2, 1, 4>;
+        else if (xk == 2) fn = conv_wino2_kernel<1, 2, 7>;
+        else if (ks > 1) fn = xs == 3 ? PG_W2(3, true) : PG_W2(4, true);
+        else fn = xs == 3 ? PG_W2(3, false) : PG_W2(4, false);
+#undef PG_W2
+        snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino2_kernel<%d, %d, %d, %s, %d>", ncb, xk, xs, ks > 1 ? "true" : "false", epi);   // (as the profiler demangles it)
         if (smem2 > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
             if (e != hipSuccess) return (int)e;

@@ -151,7 +151,7 @@ def test_conv2d_wino_k_split(case, slices):
         name = lib.pg_debug_last_wino_kernel().decode()
         nblk = -(-(N * (H // 2) ** 2) // 64) * -(-co // 16)
         if (slices > 1 and ci >= 8 * slices) or (slices == -1 and nblk <= 256 and ci >= 64):
-            assert name.endswith('true>'), name
+            assert name.count(', true, ') == 1, name
         x, u = rnd(N, H // 2 if ups else H, H // 2 if ups else H, ci).cuda(), pg.ops.wino_transform_weights((rnd(3, 3, co, ci, seed=1) * 0.2).cuda())
         ys = [pg.ops.conv2d_wino(x, u, None, N, H, H, 0.37, 0.2, ups=bool(ups)) for _ in range(4)]
         assert all(torch.equal(ys[0], y) for y in ys[1:])
@@ -189,6 +189,38 @@ def test_backward_data_form_straight_from_the_parameter(shapes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 64, 128, 128, 0), (2, 32, 64, 48, 1), (3, 16, 512, 512, 0), (1, 128, 16, 32, 0), (2, 8, 64, 36, 0)])
+def test_specialised_epilogues_match_the_general_one(case):
+    """conv_wino2_kernel<.., EPI_PLAIN / EPI_MASKB> (bias + LeakyReLU -> y; sign-byte LeakyReLU' factors -> y: 32-bit offsets, no
+    option tests) against the general epilogue of the same kernel (pg_debug_set_wino_epi(0)), with and without K slices, and against
+    the torch restatement; couts that are not a multiple of 16 (dead lanes), fused-upsample input."""
+    N, H, ci, co, ups = case
+    lib, ops = pg._lib.load(), pg.ops
+    hin = H // 2 if ups else H
+    x, w, b = rnd(N, hin, hin, ci), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2)
+    m = rnd(N, H, H, co, seed=3)
+    mb = E.signbytes_of(m).cuda()
+    u = ops.wino_transform_weights(w.cuda())
+
+    def run():
+        y = ops.conv2d_wino(x.cuda(), u, b.cuda(), N, H, H, 0.37, 0.2, ups=bool(ups))
+        n1 = lib.pg_debug_last_wino_kernel().decode()
+        ym = ops.conv2d_wino(x.cuda(), u, None, N, H, H, 0.37, mask=mb, mask_slope=0.2, ups=bool(ups))
+        return y, ym, n1, lib.pg_debug_last_wino_kernel().decode()
+    y, ym, n1, n2 = run()
+    assert n1.endswith(', 1>') and n2.endswith(', 2>'), (n1, n2)
+    assert lib.pg_debug_set_wino_epi(0) == 0
+    try:
+        gy, gym, g1, g2 = run()
+        assert g1.endswith(', 0>') and g2.endswith(', 0>'), (g1, g2)
+    finally:
+        lib.pg_debug_set_wino_epi(-1)
+    assert rel_err(y, gy) < 1e-6 and rel_err(ym, gym) < 1e-6
+    assert rel_err(y, E.conv2d(x, w, b, N, H, H, 3, 1, 0.37, slope=0.2, ups=bool(ups))) < 2e-5
+    assert rel_err(ym, E.conv2d(x, w, None, N, H, H, 3, 1, 0.37, mask=m, mask_slope=0.2, ups=bool(ups))) < 2e-5
+
+
+@pytest.mark.gpu
 def test_workspace_registration_errors_and_unsplit_without_scratch():
     lib = pg._lib.load()
     import ctypes
@@ -203,22 +235,22 @@ def test_workspace_registration_errors_and_unsplit_without_scratch():
     x, w = rnd(3, 16, 16, 64).cuda(), (rnd(3, 3, 64, 64, seed=1) * 0.2).cuda()
     u = pg.ops.wino_transform_weights(w)
     want = pg.ops.conv2d_wino(x, u, None, 3, 16, 16, 0.37, 0.2)                          # current stream: scratch registered by ops
-    assert lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+    assert lib.pg_debug_last_wino_kernel().decode().count(', true, ') == 1
     torch.cuda.synchronize()
     y = torch.empty_like(want)
     args = [ctypes.c_void_p(t.data_ptr()) for t in (x, u)] + [None, None, ctypes.c_void_p(y.data_ptr()), None, None, 1.0, 0.0, 0, None, None, 1.0,
                                                               3, 16, 16, 64, 64, 0, 0.37, 0.2, 0.2, h]
     assert lib.pg_conv2d_wino_nhwc(*args) == 0                                          # a stream without scratch: unsplit launch
-    assert not lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+    assert not lib.pg_debug_last_wino_kernel().decode().count(', true, ') == 1
     s.synchronize()
     assert rel_err(y, want) < 1e-6
     small = torch.zeros((1 << 14) + (1 << 15), dtype=torch.uint8, device='cuda')        # room for two slices of ONE block only
     assert lib.pg_set_workspace(h, ctypes.c_void_p(small.data_ptr()), small.numel()) == 0
     assert lib.pg_conv2d_wino_nhwc(*args) == 0                                          # 12 blocks x 8 slices do not fit: unsplit
-    assert not lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+    assert not lib.pg_debug_last_wino_kernel().decode().count(', true, ') == 1
     assert lib.pg_set_workspace(h, ctypes.c_void_p(buf.data_ptr()), buf.numel()) == 0   # re-registering replaces the entry
     assert lib.pg_conv2d_wino_nhwc(*args) == 0
-    assert lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+    assert lib.pg_debug_last_wino_kernel().decode().count(', true, ') == 1
     s.synchronize()
     assert rel_err(y, want) < 1e-6
     assert lib.pg_set_workspace(h, None, 0) == 0

@@ -40,7 +40,7 @@ for N, H, ci, co in CASES:
     for ks in [int(v) for v in os.environ.get('KS', '0,-1,2,3,4,6,8').split(',')]:
         lib.pg_debug_set_wino_ksplit(ks)
         t = timed(lambda: ops.conv2d_wino(x, u, bias, N, H, H, 0.5, 0.2))
-        split = lib.pg_debug_last_wino_kernel().decode().endswith('true>')
+        split = ', true, ' in lib.pg_debug_last_wino_kernel().decode()
         row.append('ks%2d%s %6.1f us %5.1f TF' % (ks, '*' if split else ' ', t, flop / t * 1e-6))
     lib.pg_debug_set_wino_ksplit(-1)
     print('n%d @%d %d->%d: ' % (N, H, ci, co) + ' | '.join(row), flush=True)
