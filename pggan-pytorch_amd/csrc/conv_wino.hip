@@ -149,8 +149,8 @@ __device__ __forceinline__ void wino_epilogue_q(const WinoP& p, const f32x4 (&yq
                                 mk.z > 0.f ? 1.f : p.mask_slope, mk.w > 0.f ? 1.f : p.mask_slope);
             }
             o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
-        } else {
-            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+        } else {                                             // (explicit fma: the same rounding in every epilogue variant, whatever hipcc contracts)
+            o = make_float4(fmaf(v[0], p.scale, bv.x), fmaf(v[1], p.scale, bv.y), fmaf(v[2], p.scale, bv.z), fmaf(v[3], p.scale, bv.w));
             o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
             o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
         }
@@ -234,7 +234,7 @@ __device__ __forceinline__ void wino_epilogue_fast(const WinoP& p, const f32x4 (
         const f32x4 v = yq[q];
         float4 o = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
         if constexpr (EPI == EPI_PLAIN) {
-            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+            o = make_float4(fmaf(v[0], p.scale, bv.x), fmaf(v[1], p.scale, bv.y), fmaf(v[2], p.scale, bv.z), fmaf(v[3], p.scale, bv.w));
             o.x = o.x > 0.f ? o.x : o.x * p.slope; o.y = o.y > 0.f ? o.y : o.y * p.slope;
             o.z = o.z > 0.f ? o.z : o.z * p.slope; o.w = o.w > 0.f ? o.w : o.w * p.slope;
         } else {
