@@ -138,7 +138,8 @@ __device__ __forceinline__ void wino_epilogue_q(const WinoP& p, const f32x4 (&yq
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 v = yq[q];
-        const size_t off = (((size_t)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1)) * p.Cout + cb;
+        // 32-bit element offsets (the host refuses tensors of 2^29 elements and more; yup has four times the pixels: < 2^31)
+        const unsigned off = (((unsigned)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1)) * p.Cout + cb;
         float4 o = make_float4(v[0] * p.scale, v[1] * p.scale, v[2] * p.scale, v[3] * p.scale);
         if (p.mask) {
             float4 f;
@@ -157,11 +158,11 @@ __device__ __forceinline__ void wino_epilogue_q(const WinoP& p, const f32x4 (&yq
         ov[q] = o;
         if (p.yup) {                                         // pool adjoint: four masked copies of every output
             const float k = p.up_mul * 0.25f;
-            const size_t W2 = (size_t)2 * p.W;
-            const size_t ubase = (((size_t)ni * 2 * p.H + 2 * (oy0 + (q >> 1))) * W2 + 2 * (ox0 + (q & 1))) * p.Cout + cb;
+            const unsigned W2 = 2u * p.W;
+            const unsigned ubase = (((unsigned)ni * 2 * p.H + 2 * (oy0 + (q >> 1))) * W2 + 2 * (ox0 + (q & 1))) * p.Cout + cb;
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
-                const size_t uo = ubase + ((size_t)(dd >> 1) * W2 + (dd & 1)) * p.Cout;
+                const unsigned uo = ubase + ((unsigned)(dd >> 1) * W2 + (dd & 1)) * p.Cout;
                 float4 w4 = make_float4(o.x * k, o.y * k, o.z * k, o.w * k);
                 if (p.upmask) {
                     float4 f;
@@ -188,7 +189,7 @@ __device__ __forceinline__ void wino_epilogue_q(const WinoP& p, const f32x4 (&yq
         float4 v;
         v.x = ((ov[0].x + ov[1].x) + (ov[2].x + ov[3].x)) * 0.25f; v.y = ((ov[0].y + ov[1].y) + (ov[2].y + ov[3].y)) * 0.25f;
         v.z = ((ov[0].z + ov[1].z) + (ov[2].z + ov[3].z)) * 0.25f; v.w = ((ov[0].w + ov[1].w) + (ov[2].w + ov[3].w)) * 0.25f;
-        const size_t poff = (((size_t)ni * (p.H >> 1) + (oy0 >> 1)) * (p.W >> 1) + (ox0 >> 1)) * p.Cout + cb;
+        const unsigned poff = (((unsigned)ni * (p.H >> 1) + (oy0 >> 1)) * (p.W >> 1) + (ox0 >> 1)) * p.Cout + cb;
         if (p.pool_other) {
             const float4 q = *reinterpret_cast<const float4*>(p.pool_other + poff);
             v.x = fmaf(v.x, p.pool_a, p.pool_b * q.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * q.y);
@@ -295,7 +296,7 @@ __device__ __forceinline__ void wino_epilogue_pixelnorm(const WinoP& p, const f3
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float rr = rsqrtf(ss[q] / (float)p.Cout + p.pn_eps);
-        const size_t pix = ((size_t)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1);
+        const unsigned pix = ((unsigned)ni * p.H + oy0 + (q >> 1)) * p.W + ox0 + (q & 1);       // (32-bit: < 2^29 elements per tensor)
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
             const int cb = cb0 + 16 * c;
@@ -342,7 +343,7 @@ __device__ __forceinline__ void wino_epilogue_pnbwd(const WinoP& p, const f32x4 
             v.x = ((g[c][0].x + g[c][1].x) + (g[c][2].x + g[c][3].x)) * 0.25f; v.y = ((g[c][0].y + g[c][1].y) + (g[c][2].y + g[c][3].y)) * 0.25f;
             v.z = ((g[c][0].z + g[c][1].z) + (g[c][2].z + g[c][3].z)) * 0.25f; v.w = ((g[c][0].w + g[c][1].w) + (g[c][2].w + g[c][3].w)) * 0.25f;
             if (p.pool_other && cb < p.Cout && ni < p.N) {
-                const size_t poff = (((size_t)ni * Ho + (oy0 >> 1)) * Wo + (ox0 >> 1)) * p.Cout + cb;
+                const unsigned poff = (((unsigned)ni * Ho + (oy0 >> 1)) * Wo + (ox0 >> 1)) * p.Cout + cb;
                 const float4 o = *reinterpret_cast<const float4*>(p.pool_other + poff);
                 v.x = fmaf(v.x, p.pool_a, p.pool_b * o.x); v.y = fmaf(v.y, p.pool_a, p.pool_b * o.y);
                 v.z = fmaf(v.z, p.pool_a, p.pool_b * o.z); v.w = fmaf(v.w, p.pool_a, p.pool_b * o.w);
@@ -355,7 +356,7 @@ __device__ __forceinline__ void wino_epilogue_pnbwd(const WinoP& p, const f32x4 
     for (int q = 0; q < 4; ++q) {
         if (q >= nq) break;
         const int oy = pooled ? (oy0 >> 1) : oy0 + (q >> 1), ox = pooled ? (ox0 >> 1) : ox0 + (q & 1);
-        const size_t pix = ((size_t)ni * Ho + oy) * Wo + ox;
+        const unsigned pix = ((unsigned)ni * Ho + oy) * Wo + ox;
         float4 yv[NCB];
         float dot = 0.f;
 #pragma unroll
