@@ -33,6 +33,7 @@ struct WWP {
     int N, H, W, Cin, Cout, ups;
     float scale;
     int blocksW, blocksH, nregions, regions_per_block;     // region = one image x 4 x 8 tiles (8 x 16 pixels)
+    int lgBW, lgBH;                                         // log2 of blocksW / blocksH (H, W are powers of two)
 #ifdef PG_WINO_TRACE
     unsigned long long* trace;                             // [workgroup][wave][region < 8][8] s_memtime stamps (tools/exp/wgrad_trace.py)
 #endif
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
         int r = second ? region - p.nregions1 : region;
         const float* xb = second ? p.x2 : p.x;
         const float* gb = second ? p.gz2 : p.gz;
-        const int bw = r % p.blocksW; r /= p.blocksW;
-        const int bh = r % p.blocksH; const int n = r / p.blocksH;
+        const int bw = r & (p.blocksW - 1); r >>= p.lgBW;          // (powers of two: no runtime divisions per region)
+        const int bh = r & (p.blocksH - 1); const int n = r >> p.lgBH;
         const int oy0 = bh * PH, ox0 = bw * PW;
         const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(gb + (size_t)n * p.H * p.W * p.Cout + co0, zimg - 4u * (unsigned)co0);
         const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(xb + (size_t)n * xH * xW * p.Cin + ci0, ximg - 4u * (unsigned)ci0);
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
         int r = second ? region - p.nregions1 : region;
         const float* xb = second ? p.x2 : p.x;
         const float* gb = second ? p.gz2 : p.gz;
-        const int bw = r % p.blocksW; r /= p.blocksW;
-        const int bh = r % p.blocksH; const int n = r / p.blocksH;
+        const int bw = r & (p.blocksW - 1); r >>= p.lgBW;          // (powers of two: no runtime divisions per region)
+        const int bh = r & (p.blocksH - 1); const int n = r >> p.lgBH;
         const int oy0 = bh * PH, ox0 = bw * PW;
         const __amdgpu_buffer_rsrc_t rz = pg_make_rsrc(gb + (size_t)n * p.H * p.W * p.Cout + co0, zimg - 4u * (unsigned)co0);
         const __amdgpu_buffer_rsrc_t rx = pg_make_rsrc(xb + (size_t)n * xH * xW * p.Cin + ci0, ximg - 4u * (unsigned)ci0);
@@ -463,6 +464,8 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
     p.x2 = N2 > 0 ? x2 : x; p.gz2 = N2 > 0 ? gz2 : gz; p.db_batches = db_batches;
     p.N = N + N2; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = ups; p.scale = scale;
     p.blocksW = W / PW; p.blocksH = H / PH;
+    p.lgBW = 0; while ((1 << p.lgBW) < p.blocksW) ++p.lgBW;
+    p.lgBH = 0; while ((1 << p.lgBH) < p.blocksH) ++p.lgBH;
     p.nregions1 = N * p.blocksW * p.blocksH;
     p.nregions = (N + N2) * p.blocksW * p.blocksH;
 #ifdef PG_WINO_TRACE
