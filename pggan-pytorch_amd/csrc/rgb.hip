@@ -3,6 +3,7 @@
 // traffic on the NHWC feature side, row-contiguous traffic on the NCHW image side, the
 // fade-in blend / 2x2 pooling of the image fused so the image is touched exactly once.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "pggan_hip.h"
 
@@ -599,6 +600,22 @@ __global__ __launch_bounds__(256) void fromrgb_bwd_data_wide_kernel(
     }
 }
 
+// Workgroups of the narrow-layer weight gradients (thread -> pixel, (features + 1) x C partial sums per thread, one shuffle + LDS fold
+// and features x C atomics per workgroup): the fold is a fixed cost per workgroup that grows with the feature count, so a thread
+// should see 192 / features pixels -- swept per shape with tools/bench_rgb_wgrad.py (n3 @512 16 features: 58 -> 35 us against the
+// former flat cap of 1024 workgroups, n3 @256 32 features: 83 -> 44 us, n3 @1024 8 features: 42 -> 36 us, n9 unchanged).
+inline int small_wgrad_grid(size_t total, int features)
+{
+    static const int forced = getenv("PG_RGB_WGRAD_GRID") ? atoi(getenv("PG_RGB_WGRAD_GRID")) : 0;       // sweeps
+    if (forced > 0) return (int)((total + 255) / 256 < (size_t)forced ? (total + 255) / 256 : (size_t)forced);
+    const size_t per_thread = (size_t)(192 / features < 1 ? 1 : 192 / features);
+    size_t g = (total + 256 * per_thread - 1) / (256 * per_thread);
+    if (g < 128) g = 128;
+    if (g > 1024) g = 1024;
+    if (g > (total + 255) / 256) g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : g);
+}
+
 inline int grid_for(size_t total, int block = 256, int cap = 256 * 16)
 {
     size_t g = (total + block - 1) / block;
@@ -665,7 +682,7 @@ extern "C" int pg_fromrgb_wgrad(const float* gz, const float* img, float* dw, fl
     if (Cout & 3) return PG_E_ALIGN;
     const size_t total = (size_t)N * H * W;
     if (total >= 65536 && (Cout == 8 || Cout == 16 || Cout == 32)) {
-        const int g = grid_for(total, 256, 1024);
+        const int g = small_wgrad_grid(total, Cout);
         hipStream_t s = (hipStream_t)stream;
         if (Cout == 8) hipLaunchKernelGGL(fromrgb_wgrad_small_kernel<8>, dim3(g), dim3(256), 0, s, gz, img, dw, db, N, C, H, W, pool, scale);
         else if (Cout == 16) hipLaunchKernelGGL(fromrgb_wgrad_small_kernel<16>, dim3(g), dim3(256), 0, s, gz, img, dw, db, N, C, H, W, pool, scale);
@@ -743,7 +760,7 @@ extern "C" int pg_torgb_wgrad(const float* g, const float* x, float* dw, float* 
     if (Cin & 3) return PG_E_ALIGN;
     const size_t total = (size_t)N * H * W;
     if (total >= 65536 && total < (1ull << 31) && (Cin == 8 || Cin == 16 || Cin == 32)) {
-        const int gr = grid_for(total, 256, 1024);
+        const int gr = small_wgrad_grid(total, Cin);
         hipStream_t s = (hipStream_t)stream;
         if (Cin == 8) hipLaunchKernelGGL(torgb_wgrad_small_kernel<8>, dim3(gr), dim3(256), 0, s, g, x, dw, db, N, C, H, W, down, mul_scale, mul);
         else if (Cin == 16) hipLaunchKernelGGL(torgb_wgrad_small_kernel<16>, dim3(gr), dim3(256), 0, s, g, x, dw, db, N, C, H, W, down, mul_scale, mul);
