@@ -565,6 +565,9 @@ __global__ __launch_bounds__(64) void g_loss_kernel(const float* __restrict__ s,
 }
 
 // ---------------------------------------------------------------------------------------- Adam
+// B1ZERO: beta1 == 0 (the reference's Adam(0, 0.99), train.py:195): exp_avg = grad, so the old first moment is never read -- one of the
+// seven streams of this bandwidth-bound kernel (it is still written: checkpoints carry it, plugins.SaverPlugin).
+template <bool B1ZERO>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n,
                                                    float step_size, float beta1, float beta2, float eps,
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #define ADAM1(P, G, Mm, V) { const float g_ = (G) * grad_scale; Mm = Mm * beta1 + omb1 * g_; V = V * beta2 + omb2 * g_ * g_; \
                              P -= step_size * Mm / (sqrtf(V) * inv_bc2_sqrt + eps); }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 pp = p4[i], mm = m4[i], vv = v4[i]; const float4 gg = g4[i];
+        float4 pp = p4[i], mm = B1ZERO ? make_float4(0.f, 0.f, 0.f, 0.f) : m4[i], vv = v4[i]; const float4 gg = g4[i];
         ADAM1(pp.x, gg.x, mm.x, vv.x) ADAM1(pp.y, gg.y, mm.y, vv.y) ADAM1(pp.z, gg.z, mm.z, vv.z) ADAM1(pp.w, gg.w, mm.w, vv.w)
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
     }
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const size_t tail0 = n4 << 2;
     if (blockIdx.x == 0 && threadIdx.x < (n - tail0)) {
         const size_t i = tail0 + threadIdx.x;
-        float pp = p[i], mm = m[i], vv = v[i];
+        float pp = p[i], mm = B1ZERO ? 0.f : m[i], vv = v[i];
         ADAM1(pp, g[i], mm, vv)
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
@@ -818,7 +821,11 @@ extern "C" int pg_adam(float* p, const float* g, float* m, float* v, int64_t n, 
 {
     if (!p || !g || !m || !v || n <= 0) return PG_E_ARG;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return PG_E_ALIGN;
-    LAUNCH(adam_kernel, dim3(grid_for(((size_t)n + 3) >> 2, 256, 2048)), dim3(256), 0, stream, p, g, m, v, (size_t)n,
+    if (beta1 == 0.f) {
+        LAUNCH(adam_kernel<true>, dim3(grid_for(((size_t)n + 3) >> 2, 256, 2048)), dim3(256), 0, stream, p, g, m, v, (size_t)n,
+               lr / bc1, beta1, beta2, eps, 1.f / bc2_sqrt, grad_scale);
+    }
+    LAUNCH(adam_kernel<false>, dim3(grid_for(((size_t)n + 3) >> 2, 256, 2048)), dim3(256), 0, stream, p, g, m, v, (size_t)n,
            lr / bc1, beta1, beta2, eps, 1.f / bc2_sqrt, grad_scale);
 }
 
