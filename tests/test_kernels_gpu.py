@@ -359,6 +359,12 @@ def test_linear_gp_loss_adam():
     check('adam p', dp, p)
     check('adam m', dm, mm)
     check('adam v', dv, vv)
+    # beta1 != 0 (the other instantiation: with beta1 == 0 the kernel does not read the old first moment), bias corrections != 1
+    ops.adam(dp, dg, dm, dv, 2e-3, 0.9, 0.999, 1e-8, 0.19, 0.0447, 1.0)
+    E.adam(p, g, mm, vv, 2e-3, 0.9, 0.999, 1e-8, 0.19, 0.0447, 1.0)
+    check('adam p (beta1 0.9)', dp, p)
+    check('adam m (beta1 0.9)', dm, mm)
+    check('adam v (beta1 0.9)', dv, vv)
 
 
 @pytest.mark.gpu
