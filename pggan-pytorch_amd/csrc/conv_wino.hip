@@ -1019,7 +1019,8 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
     p.pnb_y = pnb_y; p.pnb_r = pnb_r;
     if (pnb_y && (!pnb_r || pn_r || Cout > 32 || mask || yup || flags != 0 || (g_wino_vec != 0 && g_wino_vec < 10))) return PG_E_UNSUP;
     const int tilesW = W >> 1, tilesH = H >> 1;
-    int TTW = tilesW < 8 ? tilesW : 8;
+    static const int ttw_env = getenv("PG_WINO_TTW") ? atoi(getenv("PG_WINO_TTW")) : 8;          // tile-block width in tiles (experiment: 16 / 32 = flatter blocks)
+    int TTW = tilesW < ttw_env ? tilesW : ttw_env;
     int TTH = 64 / TTW; if (TTH > tilesH) TTH = tilesH;
     const int TN = 64 / (TTW * TTH);
     p.lgTW = ilog2i(TTW); p.lgTH = ilog2i(TTH); p.TN = TN;
