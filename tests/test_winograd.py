@@ -94,7 +94,8 @@ def test_conv2d_wino_kernel(case, gen):
     try:
         _wino_kernel_case(case)
         want = 'conv_wino_kernel<4>' if gen == 4 else 'conv_wino2_kernel<'
-        assert lib.pg_debug_last_wino_kernel().decode().startswith(want)
+        name = lib.pg_debug_last_wino_kernel().decode()
+        assert name.startswith(want) or (gen == 0 and name.startswith('conv_wino_strip_kernel<')), name
     finally:
         lib.pg_debug_set_wino(0)
 
@@ -493,3 +494,68 @@ def test_torch_adam_keeps_derived_weights_fresh(monkeypatch):
         assert rel_err(G(zt), y1) < 1e-5 and rel_err(D(xt), s1) < 1e-5, 'derived weight copies were stale after torch.optim.Adam.step()'
     used = [m for m in list(D._layers()) + list(G._layers()) if getattr(m, '_wu', None) is not None]
     assert used, 'no layer took the Winograd path'
+
+
+STRIP_CASES = [(2, 128, 8, 16, 0), (1, 128, 16, 32, 1), (2, 128, 32, 32, 0), (1, 256, 16, 16, 0), (1, 128, 32, 64, 0),
+               (1, 128, 8, 32, 0), (1, 256, 32, 16, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', STRIP_CASES)
+def test_conv2d_wino_strip_kernel(case):
+    """The row-streaming Winograd conv (csrc/conv_wino_strip.hip: 64-column strips, ring of five row pairs, weights resident in LDS)
+    against the torch restatement of the conv contract with every fused epilogue (bias + LeakyReLU, fp32 / sign-byte masks, pool +
+    blend, pool only, pool adjoint, sign bytes out), and bit for bit against the tile kernel it replaces (pg_debug_set_wino(20)):
+    same sums in the same order.  Cin 8 / 16 / 32, 16 .. 64 couts (one and two cout blocks per workgroup, cout groups), fused
+    upsample, several segments per image (256 rows)."""
+    lib, ops = pg._lib.load(), pg.ops
+    N, H, ci, co, ups = case
+    assert lib.pg_debug_set_wino(0) == 0
+    _wino_kernel_case(case)
+    name = lib.pg_debug_last_wino_kernel().decode()
+    assert name.startswith('conv_wino_strip_kernel<%d, ' % ci), name
+    hin = H // 2 if ups else H
+    x, w, b = rnd(N, hin, hin, ci).cuda(), rnd(3, 3, co, ci, seed=1) * 0.2, rnd(co, seed=2).cuda()
+    u = ops.wino_transform_weights(w.cuda())
+    mb = E.signbytes_of(rnd(N, H, H, co, seed=3)).cuda()
+
+    m, other, um = rnd(N, H, H, co, seed=3), rnd(N, H // 2, H // 2, co, seed=4).cuda(), rnd(N, 2 * H, 2 * H, co, seed=5)
+    umb = E.signbytes_of(um).cuda()
+    names = []
+
+    def run():
+        out = [ops.conv2d_wino(x, u, b, N, H, H, 0.37, 0.2, ups=bool(ups)),
+               ops.conv2d_wino(x, u, None, N, H, H, 0.37, mask=mb, mask_slope=0.2, ups=bool(ups))]
+        out += list(ops.conv2d_wino(x, u, b, N, H, H, 0.37, 0.2, ups=bool(ups), signs_out=True))
+        names.append(lib.pg_debug_last_wino_kernel().decode())
+        if not ups:
+            out += list(ops.conv2d_wino(x, u, b, N, H, H, 0.37, 0.2, pool=True, y_bytes=True))
+            out += list(ops.conv2d_wino(x, u, b, N, H, H, 0.37, 0.2, pool=True, other=other, a=0.6, b=0.4, y_bytes=True))
+            names.append(lib.pg_debug_last_wino_kernel().decode())
+            out.append(ops.conv2d_wino(x, u, None, N, H, H, 0.37, mask=mb, mask_slope=0.2, pool=True, pool_only=True)[1])
+            out.append(ops.conv2d_wino(x, u, None, N, H, H, 0.37, mask=mb, mask_slope=0.2, pool=True, other=other, a=0.6, b=0.4, pool_only=True)[1])
+            names.append(lib.pg_debug_last_wino_kernel().decode())
+            out.append(ops.conv2d_wino(x, u, None, N, H, H, 0.37, mask_slope=0.2, unpool=True, upmask=umb, up_mul=0.7))
+            names.append(lib.pg_debug_last_wino_kernel().decode())
+        return out
+    got = run()
+    ncb = 2 if (co % 32 == 0 and ci <= 16) else 1
+    want_names = ['<%d, %d, 3>' % (ci, 1)] + ([] if ups else ['<%d, %d, 4>' % (ci, ncb), '<%d, %d, 5>' % (ci, ncb), '<%d, %d, 6>' % (ci, 1)])
+    if ncb == 1:                                           # (two cout blocks per workgroup: only the forms the 16->32 / 8->32 layers launch are specialised)
+        assert [nm[nm.index('<'):] for nm in names] == want_names, names
+    assert lib.pg_debug_set_wino(20) == 0
+    try:
+        want = run()
+    finally:
+        lib.pg_debug_set_wino(0)
+    assert names[-1].startswith('conv_wino2_kernel<'), names
+    for i, (a, b_) in enumerate(zip(got, want)):
+        if i in (8, 9):                                    # masked + pooled: hipcc contracts mul + add of the pooling differently in the two kernels
+            assert rel_err(a, b_) < 1e-6
+        else:
+            assert torch.equal(a, b_), i
+    if not ups:                                            # the specialised forms against the torch restatement
+        ry, ryp = E.conv2d_pool(x.cpu(), w, b.cpu(), N, H, H, 3, 1, 0.37, slope=0.2, other=other.cpu(), a=0.6, b=0.4)
+        assert rel_err(got[7], ryp) < 2e-5 and float((got[6].cpu() == E.signbytes_of(ry)).float().mean()) > 0.9999
+        assert rel_err(got[9], E.conv2d_pool(x.cpu(), w, None, N, H, H, 3, 1, 0.37, mask=m, mask_slope=0.2, other=other.cpu(), a=0.6, b=0.4)[1]) < 2e-5
+        assert rel_err(got[10], E.conv2d_unpool(x.cpu(), w, N, H, H, 3, 1, 0.37, upmask=um, mul=0.7, mask_slope=0.2)) < 2e-5
