@@ -622,7 +622,7 @@ extern "C" int pg_debug_set_wino_ksplit(int n)
 
 extern "C" int pg_debug_set_wino(int vec)
 {
-    if (vec != 0 && vec != 2 && vec != 4 && vec != 11 && vec != 12 && vec != 20) return PG_E_ARG;   // 20: second generation, tile kernels only (no row-streaming form)
+    if (vec != 0 && vec != 2 && vec != 4 && vec != 11 && vec != 12 && vec != 20 && vec != 21) return PG_E_ARG;   // 20: second generation, tile kernels only; 21: the row-streaming form wherever it exists
     g_wino_vec = vec;
     return 0;
 }
@@ -705,8 +705,8 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
     static const int strip_env = getenv("PG_WINO_STRIP") ? atoi(getenv("PG_WINO_STRIP")) : 1;
     static const int strip_minw = getenv("PG_WINO_STRIP_MINW") ? atoi(getenv("PG_WINO_STRIP_MINW")) : 128;
     static const int strip_maxcin = getenv("PG_WINO_STRIP_MAXCIN") ? atoi(getenv("PG_WINO_STRIP_MAXCIN")) : 16;   // (32-channel inputs: the 87 KB ring leaves one workgroup per CU, 0.6-1.0x the tile kernel)
-    if (strip_env && g_wino_vec == 0 && W >= strip_minw && Cin <= strip_maxcin) {
-        const int sepi = g_wino_epi != 0 ? 0 : -1;
+    if ((strip_env && g_wino_vec == 0 && W >= strip_minw && Cin <= strip_maxcin) || g_wino_vec == 21) {
+        const int sepi = (g_wino_epi != 0 ? 1 : 0) | (g_wino_vec == 21 ? 2 : 0);
         p.ksplit = 1; p.kcper = Cin >> 3; p.mKs = 0; p.ks_count = nullptr; p.ks_part = nullptr;
         const int rc = launch_wino_strip(p, sepi, (hipStream_t)stream, g_wino_last, sizeof(g_wino_last));
         if (rc != PG_E_UNSUP) return rc;
@@ -725,7 +725,7 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
         if (xspan >= (1ll << 31) || uspan >= (1ll << 31)) return PG_E_UNSUP;
     }
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
-    const int vec = g_wino_vec == 20 ? 0 : g_wino_vec;
+    const int vec = g_wino_vec >= 20 ? 0 : g_wino_vec;
     const int ntb = ((N + TN - 1) / TN) * p.blocksH * p.blocksW;                 // tile blocks of 64 tiles
     if (vec >= 10 || vec == 0) {
         // second-generation kernel (LDS-DMA, 8-channel chunks, 16*NCB couts per workgroup); two cout blocks per workgroup

@@ -332,9 +332,10 @@ __device__ __forceinline__ void wino_epilogue_pnbwd(const WinoP& p, const f32x4 
     }
 }
 
-// Row-streaming form (conv_wino_strip.hip): a workgroup walks down seg_rows rows of a 64-column strip of one image for ncog-th of
-// the couts.  All four counts are powers of two.
-struct WinoStripGeo { int strips, segs, seg_rows, ncog, lgStrips, lgSegs, lgCog; };
-int launch_wino_strip(WinoP& p, int epi, hipStream_t s, char* name, size_t name_len);
+// Row-streaming form (conv_wino_strip.hip): the steps (two tile rows of a 64-column strip) of all strips form one sequence
+// [image][strip][row step] of `total` steps; workgroup b handles steps [b spw, (b + 1) spw) for one of the ncog cout groups.
+// strips, stepsH and ncog are powers of two.
+struct WinoStripGeo { int strips, stepsH, total, spw, nrun, ncog, lgStrips, lgStepsH, lgCog, stagger; };
+int launch_wino_strip(WinoP& p, int mode, hipStream_t s, char* name, size_t name_len);
 
 }  // namespace pgw
