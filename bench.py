@@ -46,7 +46,7 @@ import torch  # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12          # gfx950 f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 REF_MINIBATCH = {6: 14, 7: 6, 8: 3}          # reference plugins.py:19-20 (default 16)
-PROFILE_TAG = 'r03'                           # profiles/<tag>_roofline.json: PMC pass the traffic / MFMA-busy figures come from
+PROFILE_TAG = 'r04'                           # profiles/<tag>_roofline.json: PMC pass the traffic / MFMA-busy figures come from
 
 
 def forward_flops(G, D, depth, alpha):
@@ -225,7 +225,7 @@ class KernelTimer(object):
 
 
 
-def make_trainer(pg, res, depth, alpha, mb, seed, dp, fmap_base=4096, channels=3, ring=8):
+def make_trainer(pg, res, depth, alpha, mb, seed, dp, fmap_base=4096, channels=3, ring=8, host_data=False, lookahead=False):
     torch.manual_seed(1337)                       # same weights on every rank (train.py:21)
     shape = (1, channels, res, res)
     G = pg.Generator(shape, fmap_base=fmap_base).cuda()
@@ -234,11 +234,11 @@ def make_trainer(pg, res, depth, alpha, mb, seed, dp, fmap_base=4096, channels=3
     G.alpha = D.alpha = alpha
     opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))     # 1/world gradient pre-scale: set by Trainer(parallel=...)
     opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
-    ds = pg.utils.SyntheticDataset(res, channels, seed=seed, ring=ring)   # pre-generated ring: no RNG kernels in the timed steps
+    ds = pg.utils.SyntheticDataset(res, channels, seed=seed, ring=ring, host=host_data)   # pre-generated ring: no RNG kernels in the timed steps
     ds.model_depth = depth
     pg.wgan_gp_loss.manual_seed(seed)
     tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, ds.loader(mb),
-                    pg.utils.device_latents(mb, G.latent_size, seed=seed + 7, ring=2 * ring), parallel=dp)
+                    pg.utils.device_latents(mb, G.latent_size, seed=seed + 7, ring=2 * ring), parallel=dp, prefetch_inputs=lookahead)
     if dp is not None:
         dp.broadcast_params(tr.G, tr.D)
     return tr
@@ -306,11 +306,15 @@ def d_step_fn(tr):
     return one
 
 
-def cpu_baseline(depth, mb):
-    """The CPU oracle (a restatement of the reference's op sequence, pinned to the reference by the
-    golden fixtures) timed on this host: ONE full train iteration of the same workload (bounded sample,
-    ~10 s; torch-CPU/oneDNN degrades with >32 threads on these convolutions, so at most 32 threads are
-    used and that is the core count reported)."""
+CPU_SAMPLE_MAX_MB = 4
+
+
+def cpu_baseline(depth, mb, per_depth=True):
+    """The CPU oracle (a restatement of the reference's op sequence, pinned to the reference by the golden fixtures) timed on
+    this host's cores, as BASELINE.md §3 specifies: per growth stage 1 warm-up + 2 timed full train iterations (the warm-up
+    absorbs oneDNN primitive creation); ``value`` is the headline stage.  Bounded sample: the CPU minibatch is
+    min(reference minibatch, 4) -- torch-CPU convolution throughput per image is flat in N there -- and at most 32 threads are
+    used (torch-CPU/oneDNN degrades beyond that on these convolutions); that is the core count reported."""
     from oracle import pggan_cpu as oc
     cores = os.cpu_count() or 1
     try:
@@ -319,18 +323,35 @@ def cpu_baseline(depth, mb):
         pass
     cores = min(cores, 32)
     torch.set_num_threads(cores)
-    res = 4 * 2 ** depth
     cfg = oc.NetCfg(1024, 3)
-    torch.manual_seed(1337)
-    gp, dp_ = oc.init_generator(cfg), oc.init_discriminator(cfg)
-    real, z_d, z_g, mix = oc.synthetic_batch(1337, mb, 3, res, 512)
-    og, od = oc.AdamState(), oc.AdamState()
-    t0 = time.perf_counter()
-    oc.train_iteration(gp, dp_, cfg, og, od, real, z_d, z_g, mix, depth, 1.0, 1e-3, 1e-3)
-    dt = time.perf_counter() - t0
-    return dict(value=mb / dt, unit='images/sec', cores=cores, kind='port',
-                sample='1 full train iteration (D+GP step, G step, Adam) at depth %d (%dx%d), minibatch %d, '
-                       'torch-CPU fp32 oracle, %d threads, %.1f s' % (depth, res, res, mb, cores, dt))
+
+    def one_depth(d, m):
+        res = 4 * 2 ** d
+        torch.manual_seed(1337)
+        gp, dp_ = oc.init_generator(cfg), oc.init_discriminator(cfg)
+        real, z_d, z_g, mix = oc.synthetic_batch(1337, m, 3, res, 512)
+        og, od = oc.AdamState(), oc.AdamState()
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oc.train_iteration(gp, dp_, cfg, og, od, real, z_d, z_g, mix, d, 1.0, 1e-3, 1e-3)
+            times.append(time.perf_counter() - t0)
+        dt = 0.5 * (times[1] + times[2])
+        return {'depth': d, 'res': res, 'minibatch': m, 'images_per_sec': m / dt, 'ms_per_step': 1e3 * dt,
+                'warmup_iteration_s': times[0], 'timed_iterations_s': times[1:]}
+    t_all = time.perf_counter()
+    stages = []
+    for d in (range(0, 9) if per_depth else [depth]):
+        m = mb if d == depth else REF_MINIBATCH.get(d, 16)
+        stages.append(one_depth(d, min(m, CPU_SAMPLE_MAX_MB)))
+    head = [e for e in stages if e['depth'] == depth][0]
+    out = dict(value=head['images_per_sec'], unit='images/sec', cores=cores, kind='port',
+               sample='per growth stage: 1 warm-up + 2 timed full train iterations (D+GP step, G step, Adam) of the torch-CPU fp32 oracle, '
+                      'minibatch min(reference, %d), %d threads; value = depth %d (%dx%d, minibatch %d); %.0f s in all'
+                      % (CPU_SAMPLE_MAX_MB, cores, depth, head['res'], head['res'], head['minibatch'], time.perf_counter() - t_all))
+    if per_depth:
+        out['per_depth'] = stages
+    return out
 
 
 def relaunch(n):
@@ -454,6 +475,10 @@ def main():
     ap.add_argument('--serial-kernel-timing', action='store_true', help='instrumented passes with the weight-gradient stream off '
                     '(isolated per-kernel durations instead of the durations inside the two-stream step)')
     ap.add_argument('--kernel-table', action='store_true', help='per-layer conv timing table on stderr')
+    ap.add_argument('--host-data', action='store_true', help='the headline loop is fed from PINNED HOST batches (the input step of reference '
+                    'trainer.py:92: the Trainer uploads batch k + 1 on a copy stream under iteration k); the device-resident number stays "value"')
+    ap.add_argument('--d-step-only', action='store_true', help='the timed loop runs the D step + gradient penalty + Adam(D) only (profiling aid: '
+                    'tools/profile_round.sh collects the MFMA-busy counters of that window; the JSON line says so in "metric")')
     args = ap.parse_args()
 
     env_world = os.environ.get('WORLD_SIZE')
@@ -503,14 +528,15 @@ def main():
         tr.train()
     if dp is not None:
         dp.stats.update(collectives=0, bytes=0)
-    dt = timed_steps(tr, args.steps, args.warmup, dp)
+    dt = timed_steps(tr, args.steps, args.warmup, dp, fn=d_step_fn(tr) if args.d_step_only else None)
     ms_per_step = 1e3 * dt / args.steps
     host_ms = HOST_ENQUEUE['ms']
     value = n_gpus * mb * args.steps / dt
     w_d, w = step_flops(tr.G, tr.D, depth, args.alpha)
 
     out = {
-        'metric': 'images/sec, PGGAN full train step (D+GP step + G step + Adam) at %dx%d' % (res, res),
+        'metric': ('images/sec, PGGAN D step + gradient penalty + Adam(D) ONLY (--d-step-only, profiling aid) at %dx%d' if args.d_step_only else
+                   'images/sec, PGGAN full train step (D+GP step + G step + Adam) at %dx%d') % (res, res),
         'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'priming_steps': args.prime,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic (seeded uniform [-1,1) images / normal latents, pre-generated ring of 8 device batches)',
@@ -525,6 +551,20 @@ def main():
         'host_enqueue_ms_per_step': host_ms,       # Python + launch time of one step on the host; the device runs behind it
     }
     out['config']['hip_graphs'] = bool((args.graphs or depth == 0) and args.alpha >= 1.0)
+    if args.host_data or (args.config == 5 and not args.no_configs):
+        # the same step fed from pinned host memory (37.7 MB per step at 1024x1024): never "value" (inputs resident in HBM is the
+        # contract), reported next to it
+        th = make_trainer(pg, net_res, depth, args.alpha, mb, seed, dp, fmap_base=args.fmap_base, channels=c['ch'], host_data=True)
+        for _ in range(max(10, args.prime // 2)):
+            th.train()
+        dth = timed_steps(th, args.steps, args.warmup, dp)
+        out['host_resident_input'] = {'ms_per_step': 1e3 * dth / args.steps, 'images_per_sec': n_gpus * mb * args.steps / dth,
+                                      'vs_device_resident': (dth / args.steps) / (dt / args.steps),
+                                      'h2d_bytes_per_step': int(mb * c['ch'] * res * res * 4),
+                                      'prefetch_hits': th._inputs.hits, 'prefetch_misses': th._inputs.misses,
+                                      'is': 'Trainer.train() fed from a ring of pinned host batches, uploaded on a copy stream where the reference calls .cuda() (the host runs ahead of the device, so the upload overlaps the previous step)'}
+        del th
+        torch.cuda.empty_cache()
     if rccl is not None:
         out.update(rccl)
         steps_counted = args.steps + args.warmup
@@ -574,12 +614,14 @@ def main():
             prof, src = None, None
         if prof is not None and dom in prof:
             traffic = prof[dom]['hbm_bytes_per_launch']
-        out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': MFMA_F32_PEAK / 1e12,
-                           'unit': 'TFLOP/s', 'frac': d['tflops'] * 1e12 / MFMA_F32_PEAK,
-                           'frac_is': 'ALGORITHMIC FLOP of the launches / HIP-event time / nominal peak (not MFMA utilisation)',
-                           'executed_mfma_frac': d['exec_tflops'] * 1e12 / MFMA_F32_PEAK,
+        out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['exec_tflops'], 'peak': MFMA_F32_PEAK / 1e12,
+                           'unit': 'TFLOP/s', 'frac': d['exec_tflops'] * 1e12 / MFMA_F32_PEAK,
+                           'frac_is': 'MFMA FLOP the launches EXECUTE (Winograd F(2x2,3x3): 16/36 of the algorithmic 2*MAC count) / HIP-event time / nominal peak',
+                           'algorithmic_tflops': d['tflops'], 'algorithmic_frac': d['tflops'] * 1e12 / MFMA_F32_PEAK,
+                           'algorithmic_frac_is': '2*MAC FLOP of the reference convolution / HIP-event time / nominal peak (what SURVEY.md 8d calls achieved; exceeds the executed fraction by 36/16 on Winograd launches)',
                            'traffic': traffic, 'traffic_source': src if traffic is not None else None,
                            'mfma_busy_pct': prof[dom]['mfma_busy_pct'] if prof and dom in prof else None,
+                           'valu_per_mfma': prof[dom].get('valu_per_mfma') if prof and dom in prof else None,
                            'avg_launch_us': d['avg_launch_us'], 'launches_per_step': d['launches_per_step'],
                            'ms_per_step_in_kernel': d['ms_per_step'],
                            'algorithmic_gflop_per_step': d['flops_per_step'] / 1e9}
@@ -591,6 +633,32 @@ def main():
             den = sum(v['ms'] for k, v in fam.items() if k in prof)
             out['mfma_busy_pct'] = num / den if den else None
             out['mfma_busy_source'] = src + ' (SQ_VALU_MFMA_BUSY_CYCLES per kernel symbol, weighted by this run\'s time per symbol)'
+        # the north-star window: D step + gradient penalty + Adam(D).  (a) this run's conv launches of that window (HIP events),
+        # weighted with the per-symbol SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC pass; (b) the counter figure of a
+        # --d-step-only PMC pass over ALL kernels of the window (tools/profile_round.sh, profiles/<tag>_roofline.json)
+        pg.wgan_gp_loss.enable_graphs(False)
+        try:
+            with KernelTimer(pg) as ktd:
+                one = d_step_fn(tr)
+                for _ in range(psteps):
+                    one()
+                famd = ktd.summary(psteps)
+        finally:
+            pg.engine.ASYNC_WGRAD = async_wgrad
+        totd = sum(v['ms'] for v in famd.values())
+        out['d_step_gp_executed_mfma_frac'] = sum(v['exec_flops'] for v in famd.values()) / (totd * 1e-3) / MFMA_F32_PEAK if totd else None
+        if prof:
+            num = sum(v['ms'] * prof[k]['mfma_busy_pct'] for k, v in famd.items() if k in prof)
+            den = sum(v['ms'] for k, v in famd.items() if k in prof)
+            out['d_step_gp_mfma_busy_pct'] = num / den if den else None
+            out['d_step_gp_mfma_busy_is'] = 'conv / weight-gradient launches of the D step + gradient penalty window, time-weighted ' + out['mfma_busy_source']
+        try:
+            with open(os.path.join(ROOT, src)) as f:
+                dwin = json.load(f).get('d_step_gp_window')
+        except Exception:
+            dwin = None
+        if dwin:
+            out['d_step_gp_counters'] = dict(dwin, source=src + ' (rocprofv3 --pmc pass of bench.py --d-step-only: every kernel of the window)')
         out['kernels'] = {k: {'tflops': v['tflops'], 'executed_tflops': v['exec_tflops'], 'ms_per_step': v['ms_per_step'],
                               'launches_per_step': v['launches_per_step'], 'avg_launch_us': v['avg_launch_us']}
                           for k, v in fam.items()}
@@ -638,7 +706,14 @@ def main():
         # The CPU baseline is a property of the host, measured once at N = 1 (rank 0's cores all to itself).  At N > 1 the
         # line repeats that measurement when an N = 1 run of this box left it behind (the driver runs N = 1, 2, 4, 8 back to
         # back); otherwise rank 0 measures it now, after the timed region, while the other ranks wait at the closing barrier.
-        cache = os.path.join(tempfile.gettempdir(), 'pggan_cpu_baseline_d%d_mb%d.json' % (depth, mb))
+        import hashlib
+        import socket
+        h = hashlib.sha256()
+        for fn in (os.path.abspath(__file__), os.path.join(ROOT, 'oracle', 'pggan_cpu.py')):
+            with open(fn, 'rb') as f:
+                h.update(f.read())
+        # (keyed by host and by the code that produced it: a stale file of another build or box is never reported as this box's)
+        cache = os.path.join(tempfile.gettempdir(), 'pggan_cpu_baseline_%s_%s_d%d_mb%d.json' % (socket.gethostname(), h.hexdigest()[:12], depth, mb))
         if args.no_cpu or args.config != 5:
             out['cpu_baseline'] = None
         elif n_gpus == 1:

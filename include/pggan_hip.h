@@ -6,11 +6,14 @@
  * file:line it stands in for is cited on every declaration.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the caller owns all
- *     buffers (no allocation, no ownership transfer); the entry points declared in THIS header keep no mutable
- *     global state => re-entrant (the only process-wide datum is the immutable table of RCCL entry points resolved on
- *     first use of the pg_comm_* / pg_allreduce_* calls; the thread-local tuning / attribution aids used by bench.py
- *     and tools/ are declared separately in pggan_hip_debug.h);
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; the caller owns all buffers (no allocation, no
+ *     ownership transfer), including the scratch of the launches that slice a reduction across workgroups: its size is queried
+ *     with pg_workspace_bytes and it is handed over per (device, stream) with pg_set_workspace;
+ *   - process-wide state, all of it: (1) the immutable table of RCCL entry points resolved on first use of the pg_comm_* /
+ *     pg_allreduce_* calls; (2) the mutex-guarded registry of caller-owned scratch buffers that pg_set_workspace fills -- the one
+ *     piece of MUTABLE global state: a launch on a stream reads its entry, nothing else ever writes it.  Everything else is
+ *     re-entrant and callable from any thread (the thread-local tuning / attribution aids used by bench.py and tools/ are
+ *     declared separately in pggan_hip_debug.h);
  *   - "feature" tensors are NHWC  [N][H][W][C]  with C % 4 == 0 and 16-byte aligned bases;
  *   - "image"   tensors are NCHW  [N][C][H][W]  (the reference's layout at the G-output/D-input);
  *   - conv weights are packed  [KH][KW][Cout][Cin]  (the K dimension contiguous);
@@ -173,8 +176,14 @@ int pg_conv2d_wino_pnbwd_nhwc(const float* x, const float* u, const float* ysave
  * order (deterministic) and runs the fused epilogue.  The library never allocates device memory: the caller owns `ptr` (16-byte
  * aligned, ZERO-FILLED once, > 16 KB; 32 MB covers every layer of the 1024x1024 schedule), keeps it alive until it registers
  * another one or clears the entry (ptr NULL, bytes 0), and uses it for nothing else.  Without a registered scratch, or when a layer
- * would need more than `bytes`, launches run unsplit -- same results to fp32 summation order.  Thread-safe.                        */
+ * would need more than `bytes`, launches run unsplit -- same results to fp32 summation order.  Thread-safe.  The scratch carries
+ * self-resetting tickets: it belongs to ONE stream (launches on a stream are ordered); two streams, or two concurrently running
+ * branches of one captured hipGraph, must not share one.                                                                          */
 int pg_set_workspace(pg_stream_t stream, void* ptr, size_t bytes);
+/* Bytes of scratch the launch of that shape uses when at least as much is registered for its stream (0: it never slices).
+ * kind 0: pg_conv2d_wino_nhwc(N, H, W, Cin, Cout); kind 1: pg_conv2d_nhwc with the 4x4 valid kernel on a 4x4 map (H = W = 4).
+ * The maximum over the layers a caller launches is the size to register (1024x1024 schedule at minibatch 3: < 32 MB).            */
+int pg_workspace_bytes(int kind, int N, int H, int W, int Cin, int Cout, size_t* bytes);
 
 /* Winograd weight gradient of the same layers: dW[kh][kw][co][ci] += scale * sum gz*x (3x3, pad 1), db[co] += sum gz, computed as
  * G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G  -- 16 MFMAs per 4 output tiles instead of 36.  H, W powers of two with

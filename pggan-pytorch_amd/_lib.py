@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PGGAN_HIP_LIB') or os.path.join(_HERE, 'libpggan_hip.so')   # env override: kernel A/B experiments
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 class PgganLibraryError(RuntimeError):
@@ -39,6 +39,7 @@ SIGNATURES = {
     'pg_conv2d_wino_pixelnorm_nhwc': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wino_pnbwd_nhwc': [P, P, P, P, P, I, P, F, F, I, I, I, I, I, F, F, P],
     'pg_set_workspace': [P, P, ctypes.c_size_t],
+    'pg_workspace_bytes': [I, I, I, I, I, I, P],
     'pg_conv2d_wgrad_wino_nhwc': [P, P, P, P, I, I, I, I, I, I, F, P],
     'pg_conv2d_wgrad_wino2_nhwc': [P, P, I, P, P, I, P, P, I, I, I, I, I, I, F, P],
     'pg_conv2d_wgrad_nhwc': [P, P, P, P, I, I, I, I, I, I, I, I, F, P],

@@ -421,18 +421,22 @@ __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_ker
     }
 }
 
+// Dynamic LDS above 48 KB needs the function attribute; it is a per-device property of the loaded code object, so it is set on
+// every launch that needs it (an idempotent host-side call: no per-process flag that a second GPU or a second thread could miss).
+inline int strip_set_smem(const void* fn, size_t smem)
+{
+    if (smem <= 48 * 1024) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 template <int COUT, int CIN, int EPI, bool WREG, bool GATH = false>
 int launch_strip(const SArgs& a, int N, hipStream_t s, char* name, size_t name_len)
 {
     using B = Blk<CIN>;
     const size_t smem = (size_t)NBLK * B::SLOTS * 16 + (WREG ? 0 : (size_t)9 * COUT * (CIN == 16 ? CIN + 4 : CIN) * 4);
     auto kern = conv_strip_kernel<COUT, CIN, EPI, WREG, GATH>;
-    static bool attr_done = false;                                // (idempotent; a race only repeats the call)
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return (int)hipGetLastError();
-        attr_done = true;
-    }
+    if (int rc = strip_set_smem(reinterpret_cast<const void*>(kern), smem); rc) return rc;
     snprintf(name, name_len, "conv_strip_kernel<%d, %d, %d, %s, %s>", COUT, CIN, EPI, WREG ? "true" : "false", GATH ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
     return (int)hipGetLastError();
@@ -663,12 +667,7 @@ int launch_wgrad_strip_t(const WArgs& a, int N, hipStream_t s, char* name, size_
     constexpr int QO = CO / 4, QI = CI / 4;
     const size_t smem = ((size_t)QI * (3 * 320 + 2) + (size_t)QO * (2 * RB * SW + 2)) * 16;
     auto kern = wgrad_strip_kernel<CO, CI, GATH>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return (int)hipGetLastError();
-        attr_done = true;
-    }
+    if (int rc = strip_set_smem(reinterpret_cast<const void*>(kern), smem); rc) return rc;
     snprintf(name, name_len, "wgrad_strip_kernel<%d, %d, %s>", CO, CI, GATH ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
     return (int)hipGetLastError();

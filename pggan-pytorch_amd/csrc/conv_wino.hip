@@ -664,6 +664,58 @@ extern "C" int pg_wino_transform_weights_batched(const float* wbase, float* ubas
 }
 
 namespace {
+// K slices of a launch with nblk (64-tile, 16-cout) blocks and nch 8-channel chunks when a scratch is registered (measured:
+// tools/bench_ksplit.py in isolation and in-step sweeps of the constants)
+int wino_default_slices(int nblk, int nch)
+{
+    static const int ks_pairs = getenv("PG_WINO_KS_PAIRS") ? atoi(getenv("PG_WINO_KS_PAIRS")) : 432;
+    static const int ks_target = getenv("PG_WINO_KS_TARGET") ? atoi(getenv("PG_WINO_KS_TARGET")) : 864;
+    static const int ks_max = getenv("PG_WINO_KS_MAX") ? atoi(getenv("PG_WINO_KS_MAX")) : 8;
+    static const int ks_minch = getenv("PG_WINO_KS_MINCH") ? atoi(getenv("PG_WINO_KS_MINCH")) : 4;
+    int ks = 1;
+    if (nblk <= ks_pairs) { ks = ks_target / nblk; if (ks > ks_max) ks = ks_max; if (ks > nch / ks_minch) ks = nch / ks_minch; }
+    return ks < 1 ? 1 : ks;
+}
+
+// tile-block geometry of the tile kernels: 64 tiles = TN images x TTH x TTW tiles
+void wino_block_geometry(int N, int H, int W, int& TTW, int& TTH, int& TN, int& ntb)
+{
+    static const int ttw_env = getenv("PG_WINO_TTW") ? atoi(getenv("PG_WINO_TTW")) : 8;          // tile-block width in tiles (experiment: 16 / 32 = flatter blocks)
+    const int tilesW = W >> 1, tilesH = H >> 1;
+    TTW = tilesW < ttw_env ? tilesW : ttw_env;
+    TTH = 64 / TTW; if (TTH > tilesH) TTH = tilesH;
+    TN = 64 / (TTW * TTH);
+    ntb = ((N + TN - 1) / TN) * (tilesW / TTW) * (tilesH / TTH);
+}
+}  // namespace
+
+extern "C" int pg_workspace_bytes(int kind, int N, int H, int W, int Cin, int Cout, size_t* bytes)
+{
+    if (!bytes || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
+    *bytes = 0;
+    if (kind == 0) {                                         // pg_conv2d_wino_nhwc: K slices of the small maps
+        if ((Cin & 7) || (Cout & 3) || !pow2(H) || !pow2(W) || H < 8 || W < 8) return PG_E_UNSUP;
+        int TTW, TTH, TN, ntb;
+        wino_block_geometry(N, H, W, TTW, TTH, TN, ntb);
+        const int nblk = ntb * ((Cout + 15) / 16), nch = Cin >> 3;
+        if (nblk > (int)WS_TICKETS) return 0;
+        int ks = wino_default_slices(nblk, nch);
+        if (ks > nch) ks = nch;
+        if (ks > 1) { const int kcper = (nch + ks - 1) / ks; ks = (nch + kcper - 1) / kcper; }
+        if (ks > 1) *bytes = WS_HEAD + (size_t)nblk * ks * 16384;
+        return 0;
+    }
+    if (kind == 1) {                                         // pg_conv2d_nhwc, 4x4 valid conv on a 4x4 map (H = W = 4): one workgroup per (cout block, input pixel)
+        if (H != 4 || W != 4 || (Cout & 15)) return PG_E_UNSUP;
+        const int nt = N <= 16 ? 1 : 2;
+        const size_t nblk = (size_t)(Cout >> 4) * ((N + 16 * nt - 1) / (16 * nt));
+        if (nblk <= 256) *bytes = WS_HEAD + nblk * 16 * nt * 1024;
+        return 0;
+    }
+    return PG_E_ARG;
+}
+
+namespace {
 int wino_conv(const float* x, const float* u, const float* bias, const float* mask, float* y,
               float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
               float* yup, const float* upmask, float up_mul,
@@ -712,10 +764,8 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
         if (rc != PG_E_UNSUP) return rc;
     }
     const int tilesW = W >> 1, tilesH = H >> 1;
-    static const int ttw_env = getenv("PG_WINO_TTW") ? atoi(getenv("PG_WINO_TTW")) : 8;          // tile-block width in tiles (experiment: 16 / 32 = flatter blocks)
-    int TTW = tilesW < ttw_env ? tilesW : ttw_env;
-    int TTH = 64 / TTW; if (TTH > tilesH) TTH = tilesH;
-    const int TN = 64 / (TTW * TTH);
+    int TTW, TTH, TN, ntb_geo;
+    wino_block_geometry(N, H, W, TTW, TTH, TN, ntb_geo);
     p.lgTW = ilog2i(TTW); p.lgTH = ilog2i(TTH); p.TN = TN;
     p.blocksW = tilesW / TTW; p.blocksH = tilesH / TTH;
     const int WT = 2 * TTW + 2, HT = 2 * TTH + 2;
@@ -726,7 +776,7 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
     }
     p.mWT = (unsigned)((1ull << 32) / (unsigned)WT) + 1u; p.mHT = (unsigned)((1ull << 32) / (unsigned)HT) + 1u;
     const int vec = g_wino_vec >= 20 ? 0 : g_wino_vec;
-    const int ntb = ((N + TN - 1) / TN) * p.blocksH * p.blocksW;                 // tile blocks of 64 tiles
+    const int ntb = ntb_geo;                                                      // tile blocks of 64 tiles
     if (vec >= 10 || vec == 0) {
         // second-generation kernel (LDS-DMA, 8-channel chunks, 16*NCB couts per workgroup); two cout blocks per workgroup
         // when that still leaves at least two workgroups per CU
@@ -760,14 +810,7 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
         Workspace ws{};
         if (ncb == 1 && xk == 1 && !pn_r && !pnb_y && g_wino_ksplit != 0 && g_wino_ksplit != 1 && nblk <= (int)WS_TICKETS &&
             find_workspace((hipStream_t)stream, ws)) {
-            if (g_wino_ksplit > 1) ks = g_wino_ksplit;
-            else {                                            // measured: tools/bench_ksplit.py (isolated) and in-step sweeps of the three constants
-                static const int ks_pairs = getenv("PG_WINO_KS_PAIRS") ? atoi(getenv("PG_WINO_KS_PAIRS")) : 432;
-                static const int ks_target = getenv("PG_WINO_KS_TARGET") ? atoi(getenv("PG_WINO_KS_TARGET")) : 864;
-                static const int ks_max = getenv("PG_WINO_KS_MAX") ? atoi(getenv("PG_WINO_KS_MAX")) : 8;
-                static const int ks_minch = getenv("PG_WINO_KS_MINCH") ? atoi(getenv("PG_WINO_KS_MINCH")) : 4;
-                if (nblk <= ks_pairs) { ks = ks_target / nblk; if (ks > ks_max) ks = ks_max; if (ks > nch / ks_minch) ks = nch / ks_minch; }
-            }
+            ks = g_wino_ksplit > 1 ? g_wino_ksplit : wino_default_slices(nblk, nch);
             if (ks > nch) ks = nch;
             if (ks > 1) {
                 p.kcper = (nch + ks - 1) / ks;

@@ -621,7 +621,7 @@ extern "C" int pg_signbytes_to_mask(const unsigned char* bytes, float* mask, int
     return (int)hipGetLastError();
 }
 
-extern "C" int pg_abi_version(void) { return 24; }
+extern "C" int pg_abi_version(void) { return 25; }
 
 extern "C" int pg_avgpool2_fwd(const float* x, const float* other, float* y, int N, int H, int W, int C,
                                float a, float b, pg_stream_t stream)

@@ -100,17 +100,25 @@ def _derived(net):
         ops.wino_transform_weights_batched(net._flat_param, net._flat_wu,
                                            [(woff, uoff, m.conv.weight.shape[2], m.conv.weight.shape[3]) for m, woff, uoff in wl])
     # The backward copies are not needed before the network's next backward sweep (milliseconds away): off the critical path, onto
-    # the weight-gradient stream, unless this already IS that stream (the deferred D update) or a hipGraph is being captured
+    # the weight-gradient stream, unless this already IS that stream (the deferred D update) or a hipGraph is being captured.
+    # A network that has never run a backward sweep (an EMA / evaluation copy) gets none: the first request for one
+    # (_wt / _wino(transposed)) invalidates the derived state.
     net._derived_bwd_ev = None
+    net._derived_bwd_waited = set()
     dev = torch.cuda.current_device() if net._flat_param.is_cuda else None
     cur = torch.cuda.current_stream(torch._C._cuda_getDevice()) if dev is not None else None
-    if (ASYNC_WGRAD and ASYNC_DERIVED and dev is not None and cur != _SIDE.get(dev) and not torch.cuda.is_current_stream_capturing()):
+    if not net.__dict__.get('_bwd_wanted', False):
+        pass
+    elif (ASYNC_WGRAD and ASYNC_DERIVED and dev is not None and cur != _SIDE.get(dev) and not torch.cuda.is_current_stream_capturing()):
         side = _side_stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             backward_copies()
             ev = torch.cuda.Event()
             ev.record(side)
+        for buf in (net._flat_wt, net._flat_wtu):  # written on the side stream: the allocator must not hand the block on before that
+            if buf is not None:
+                buf.record_stream(side)
         net._derived_bwd_ev = ev
     else:
         backward_copies()
@@ -126,10 +134,22 @@ def _assert_live(net, layer):
 
 
 def _await_backward_copies(net):
+    """The current stream waits for the side-stream refresh of the backward-only derived weights.  The event stays until the
+    next refresh, so that EVERY stream that consumes (or, for the optimizer, overwrites the source of) the copies is ordered
+    behind it, each once."""
     ev = net.__dict__.get('_derived_bwd_ev')
     if ev is not None:
-        torch.cuda.current_stream(torch._C._cuda_getDevice()).wait_event(ev)
-        net._derived_bwd_ev = None
+        cur = torch.cuda.current_stream(torch._C._cuda_getDevice())
+        waited = net.__dict__.setdefault('_derived_bwd_waited', set())
+        if cur.cuda_stream not in waited:
+            cur.wait_event(ev)
+            waited.add(cur.cuda_stream)
+
+
+def _want_backward_copies(net):
+    if not net.__dict__.get('_bwd_wanted', False):      # first backward sweep of this network: from now on every refresh includes them
+        net._bwd_wanted = True
+        net._derived_ver = None
 
 
 def _wt(net, layer):
@@ -137,6 +157,7 @@ def _wt(net, layer):
     if not getattr(layer, '_wt_wanted', False):         # first request: from now on the refresh after every update includes this layer
         layer._wt_wanted = True
         net._derived_ver = None
+    _want_backward_copies(net)
     _derived(net)
     _assert_live(net, layer)
     _await_backward_copies(net)
@@ -156,6 +177,8 @@ def _wino(layer, N, H, cout, transposed=False):
     if not getattr(layer, '_wino_wanted', False):       # first request: from now on the refresh after every update includes this layer
         layer._wino_wanted = True
         net._derived_ver = None
+    if transposed:
+        _want_backward_copies(net)
     _derived(net)
     _assert_live(net, layer)
     if transposed:
@@ -293,6 +316,7 @@ def _side_stream():
     dev = torch.cuda.current_device()
     if dev not in _SIDE:
         _SIDE[dev] = torch.cuda.Stream(device=dev)
+        ops._no_workspace_streams.add(_SIDE[dev].cuda_stream)      # (ops._stream_with_workspace: no sliced launch on it inside a capture)
     return _SIDE[dev]
 
 

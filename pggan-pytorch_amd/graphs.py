@@ -29,6 +29,7 @@ _CACHE = {}
 
 def clear():
     _CACHE.clear()
+    ops.release_capture_workspaces()          # the capture streams are gone with the graphs
 
 
 def _force_repack(net, layers):

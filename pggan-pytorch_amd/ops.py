@@ -6,6 +6,8 @@ kernel on the current stream.  No ATen arithmetic, no CPU fallback.
 Feature tensors are NHWC ``[N,H,W,C]``; image tensors are NCHW ``[N,C,H,W]``."""
 import os as _os
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -25,31 +27,66 @@ def _stream():
 WORKSPACE_BYTES = int(_os.environ.get('PGGAN_WORKSPACE_MB', '32')) << 20
 _workspaces = {}
 _capture_workspace = {}
+_no_workspace_streams = set()     # raw handles of streams that must never carry a scratch launch while a graph is captured (engine's side stream)
+
+
+def workspace_bytes(kind, N, H, W, cin, cout):
+    """Scratch the launch of that shape uses when at least as much is registered (pg_workspace_bytes; 0: it never slices).
+    kind 0: conv2d_wino, kind 1: the 4x4 valid conv on a 4x4 map."""
+    n = ctypes.c_size_t(0)
+    _lib.call('pg_workspace_bytes', kind, N, H, W, cin, cout, ctypes.addressof(n))
+    return int(n.value)
 
 
 def _stream_with_workspace():
+    """Raw handle of the current stream, with a scratch registered for it (pg_set_workspace).  The scratch carries self-resetting
+    tickets, so it belongs to ONE stream; the streams of hipGraph captures share one more per device, which is correct because a
+    captured graph of this package has a single branch that launches scratch kernels (the main stream: weight gradients, Adam and
+    derived weights on the forked side stream never slice) and graphs replay one after the other -- the first condition is
+    enforced here, the second by the engine replaying on one stream."""
     dev = torch._C._cuda_getDevice()
     s = torch._C._cuda_getCurrentRawStream(dev)
     if (dev, s) not in _workspaces:
         ws = None
+        capturing = torch.cuda.is_current_stream_capturing()
         if WORKSPACE_BYTES > 0:
-            if torch.cuda.is_current_stream_capturing():
-                ws = _capture_workspace.get(dev)             # (None before the first eager launch: those kernels run unsplit)
+            if capturing:
+                if s in _no_workspace_streams:
+                    raise RuntimeError('a scratch (K-sliced) launch on the forked side stream of a hipGraph capture: the capture '
+                                       'streams of a device share one scratch, so only one branch of a graph may slice')
+                ws = _capture_workspace.get(dev)             # (None before the first eager launch: this launch runs unsplit)
             else:
                 ws = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device='cuda:%d' % dev)
                 if dev not in _capture_workspace:
                     _capture_workspace[dev] = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device='cuda:%d' % dev)
         if ws is not None:
             _lib.call('pg_set_workspace', s, ws.data_ptr(), ws.numel())
+        if ws is None and capturing:
+            return s                                         # not cached: a later capture on a stream with this handle gets the scratch
         _workspaces[(dev, s)] = ws
     return s
+
+
+def release_capture_workspaces():
+    """Forget (and unregister) the scratch entries of capture streams: called when the captured graphs are dropped
+    (graphs.clear), whose streams are gone -- a later stream may reuse the raw handle."""
+    shared = set(id(t) for t in _capture_workspace.values())
+    for (dev, s), ws in list(_workspaces.items()):
+        if ws is not None and id(ws) in shared:
+            with torch.cuda.device(dev):
+                _lib.call('pg_set_workspace', s, None, 0)
+            del _workspaces[(dev, s)]
+
+
+_F32, _U8 = torch.float32, torch.uint8
 
 
 def _p(t):
     """Device pointer of a checked tensor (None -> NULL)."""
     if t is None:
         return None
-    if not t.is_cuda or t.dtype not in (torch.float32, torch.uint8) or not t.is_contiguous():
+    dt = t.dtype
+    if not t.is_cuda or (dt is not _F32 and dt is not _U8) or not t.is_contiguous():
         raise ValueError('expected a contiguous fp32 (or sign-byte uint8) device tensor, got %s %s contiguous=%s on %s'
                          % (tuple(t.shape), t.dtype, t.is_contiguous(), t.device))
     return t.data_ptr()

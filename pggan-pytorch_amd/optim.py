@@ -107,6 +107,9 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        from . import engine
+        for net in self._nets:                # (a side-stream refresh of derived weights may still be READING the parameters)
+            engine._await_backward_copies(net)
         for gi, group in enumerate(self.param_groups):
             lr, (b1, b2), eps = float(group['lr']), group['betas'], group['eps']
             base, mflat, vflat = self._flat_state(gi, group)

@@ -39,19 +39,25 @@ class SyntheticDataset(object):
     ``ring`` > 0: a loader pre-generates that many batches and cycles through them, so that no RNG kernel runs inside
     the timed train steps (the reference's DataLoader workers produce batches off the step's critical path too)."""
 
-    def __init__(self, resolution, num_channels=3, seed=1337, device='cuda', ring=0):
+    def __init__(self, resolution, num_channels=3, seed=1337, device='cuda', ring=0, host=False):
         self.shape = (1, num_channels, resolution, resolution)
         self.model_depth = 0
         self.alpha = 1.0
         self.device = device
         self.ring = int(ring)
+        self.host = bool(host)       # batches live in PINNED HOST memory (what a DataLoader with pin_memory hands over): the Trainer uploads them
         self._gen = torch.Generator(device=device)
         self._gen.manual_seed(int(seed))
 
     def batch(self, n):
         r = 4 * 2 ** self.model_depth
         x = torch.rand((n, self.shape[1], r, r), device=self.device, dtype=torch.float32, generator=self._gen)
-        return x.mul_(2).sub_(1)
+        x = x.mul_(2).sub_(1)
+        if self.host:
+            h = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+            h.copy_(x)
+            return h
+        return x
 
     def loader(self, minibatch_size):
         if self.ring > 0:

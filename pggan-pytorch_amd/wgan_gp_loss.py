@@ -11,7 +11,7 @@ from . import engine
 
 # wgan_gp_loss.py:4-5 keeps module-global scratch; the only state kept here is the injectable RNG.
 mixing_factors = None
-_seed = None                # (seed, number of draws so far) of the mixing-factor stream; None: seeded from torch's RNG at first use
+_seed = None                # [seed, draws so far, torch seed it came from] of the mixing-factor stream; None: seeded from torch's RNG at first use
 _use_graphs = 'auto'        # 'auto': replay only where the step is launch-bound (the 4x4 stage); True / False force it
 
 
@@ -40,22 +40,25 @@ def set_mixing_factors(m):
 
 
 def manual_seed(seed, device='cuda'):
-    """Seed the stream the mixing factors are drawn from (counter-based: ``pg_uniform_f32(seed, draw number, element)``)."""
+    """Seed the stream the mixing factors are drawn from (counter-based: ``pg_uniform_f32(seed, draw number, element)``).
+    Without this call the stream follows ``torch.manual_seed``: it is (re)seeded from ``torch.initial_seed()`` at first use and
+    again whenever that value has changed since (two same-seed runs in one process draw the same factors)."""
     global _seed
-    _seed = [int(seed), 0]
+    _seed = [int(seed), 0, None]
 
 
 def _draw_mixing_factors(n, device):
     """U[0,1) [n, 1] on the device (wgan_gp_loss.py:15-17) by the library's own generator: no ATen RNG launch inside the step."""
     global _seed
-    if _seed is None:
-        _seed = [int(torch.initial_seed()), 0]
+    ts = int(torch.initial_seed())
+    if _seed is None or (_seed[2] is not None and _seed[2] != ts):   # [seed, draws so far, torch seed it was derived from (None: manual_seed)]
+        _seed = [ts, 0, ts]
     mix = torch.empty((n, 1), device=device, dtype=torch.float32)
     if mix.is_cuda:
         from . import ops
         ops.uniform_(mix, _seed[0], _seed[1])
     else:                                                                # (host emulation in the CPU test-suite only)
-        mix.copy_(torch.rand((n, 1), generator=torch.Generator().manual_seed(_seed[0] * 1000003 + _seed[1])))
+        mix.copy_(torch.rand((n, 1), generator=torch.Generator().manual_seed((_seed[0] * 1000003 + _seed[1]) % (1 << 63))))
     _seed[1] += 1
     return mix
 

@@ -20,6 +20,8 @@ patterns (``oracle.forced_signs``), on the HIP pass's own fake / interpolated im
 The number of branches on which the HIP pass and an unforced fp64 pass disagree is printed with the per-tensor table
 (pytest -s); DESIGN.md §6 quotes both."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -145,7 +147,10 @@ def test_thin1024_against_fp64(oracle, tag):
 @pytest.mark.parametrize('res,depth,alpha,n,C,fmap_base', [
     (128, 5, 1.0, 2, 3, 4096), (256, 6, 1.0, 2, 1, 4096), (128, 4, 0.5, 3, 3, 4096),
     (1024, 8, 1.0, 3, 3, 4096),        # the BENCHMARKED network (BASELINE config 5): 1024^2 stage, minibatch 3, default widths
-    (1024, 8, 1.0, 2, 3, 8192)])       # the paper's widths at the same stage (bench.py's fmap_base 8192 line)
+    (1024, 7, 1.0, 2, 3, 8192),        # the paper's widths (bench.py's fmap_base 8192 line), 512^2 stage of the 1024^2 network
+    pytest.param(1024, 8, 1.0, 2, 3, 8192, marks=pytest.mark.skipif(os.environ.get('PGGAN_TEST_HEAVY', '') != '1', reason=(
+        'the paper-width 1024^2 stage takes ~130 s of fp64 oracle time (round 3: passed, 8.4e-7 vs 5.6e-6); PGGAN_TEST_HEAVY=1 runs it -- '
+        'the GPU tier has a 1200 s budget and the default suite stays under 600 s')))])
 def test_baseline_widths_against_fp64(oracle, res, depth, alpha, n, C, fmap_base):
     """Default widths (fmap_base 4096): the 128x128 network (config 3, fully grown and in a fade-in), the one-channel
     256x256 network (config 4), and the headline 1024x1024 network at its real minibatch (config 5) and at the paper's widths

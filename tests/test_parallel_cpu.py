@@ -162,3 +162,112 @@ def test_two_rank_data_parallel_matches_oracle(tmp_path, oracle, res, bucket_byt
                 # Adam with beta1=0 is sign-like in its first steps: a gradient within round-off of zero moves
                 # a parameter by up to lr either way per step -> absolute bound 2*lr*steps on the end state
                 assert float((mine[k] - v).abs().max()) < 2 * 0.001 * 2 + 1e-4, (name, k)
+
+
+def _grow_worker(rank, world, port, out_path):
+    """World-size-4 run THROUGH DepthManager stage boundaries: per-rank minibatch 4 -> 3 -> 2 (the reference's 16 -> 14 -> 6 -> 3
+    pattern in small), loader / latent-generator switch, cur_nimg += world * N, fades in between."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import emu_ops
+    import pggan_amd as pg
+    torch.set_num_threads(1)
+    for modname in ('engine', 'optim'):
+        importlib.import_module('pggan-pytorch_amd.' + modname).ops = emu_ops
+    pg.engine._check_dev = lambda t, what: t.contiguous()
+    pg.trainer._to_device = lambda t: t
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dp = pg.DataParallel()
+    torch.manual_seed(7 + rank)
+    shape = (1, 3, 16, 16)
+    kw = dict(fmap_base=32, fmap_max=8)
+    G = pg.Generator(shape, latent_size=8, **kw)
+    D = pg.Discriminator(shape, **kw)
+    dp.broadcast_params(G, D)
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    seed = pg.parallel.shard_seed(50, rank)
+    made = []                                          # (minibatch) of every loader the DepthManager asked for
+
+    class DS(object):
+        model_depth, alpha = 0, 1.0
+
+    ds = DS()
+
+    def loader(n):
+        made.append(n)
+        gen = torch.Generator().manual_seed(seed + 1000 * len(made))
+
+        def it():
+            while True:
+                r = 4 * 2 ** ds.model_depth
+                yield torch.rand(n, 3, r, r, generator=gen) * 2 - 1
+        return it()
+
+    def rlg(n):
+        gen = torch.Generator().manual_seed(seed + 77 + 1000 * len(made))
+        return lambda: torch.randn(n, 8, generator=gen)
+
+    pg.wgan_gp_loss.manual_seed(seed)
+    tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, None, None, parallel=dp)
+    span = 3 * 4 * world                               # three iterations of the first stage per stabilise / fade span
+    dm = pg.DepthManager(loader, rlg, 2, minibatch_default=4, minibatch_overrides={1: 3, 2: 2},
+                         lod_training_nimg=span, lod_transition_nimg=span)
+    tr.register_plugin(dm)
+    log = []                                           # state every iteration RAN with: (cur_nimg before, depth, repr(alpha), minibatch)
+
+    class Rec(pg.Plugin):
+        def __init__(self):
+            super(Rec, self).__init__([(1, 'iteration')])
+
+        def register(self, trainer):
+            pass
+
+        def iteration(self, *a):
+            log.append((tr.cur_nimg, int(tr.D.depth), repr(float(tr.D.alpha)), int(tr.stats['minibatch_size'])))
+    tr.register_plugin(Rec())
+    tr.run(4.6 * span / 1000.0)
+    flat = torch.cat([G._flat_param, D._flat_param]).clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    for g in gathered:
+        assert torch.equal(g, gathered[0]), 'ranks diverged'
+    logs = [None] * world
+    dist.all_gather_object(logs, (log, made, tr.cur_nimg, tr.iterations))
+    if rank == 0:
+        torch.save(dict(logs=logs, span=span), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_run_crosses_growth_stages_in_lockstep(tmp_path):
+    """DP readiness without hardware (unmeasured on a multi-GPU node): four gloo ranks drive Trainer + DepthManager + FusedAdam
+    through two stage changes with fades.  Every rank must see the same (cur_nimg, depth, alpha, minibatch) on every iteration,
+    cur_nimg must advance by world * per-rank minibatch, the schedule must equal growth_stage() of that global counter, and
+    each stage change must build exactly one new loader of the stage's per-rank minibatch on every rank."""
+    world = 4
+    out_path = str(tmp_path / 'grow.pt')
+    mp.spawn(_grow_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    got = torch.load(out_path, weights_only=False)
+    sys.path.insert(0, ROOT)
+    import pggan_amd as pg
+    span = got['span']
+    log0, made0, nimg0, its0 = got['logs'][0]
+    for lg, made, nimg, its in got['logs'][1:]:
+        assert lg == log0 and made == made0 and nimg == nimg0 and its == its0      # lock step, iteration by iteration
+    mb = {0: 4, 1: 3, 2: 2}
+    assert made0 == [4, 3, 2]                          # one loader per stage, with the stage's PER-RANK minibatch
+    depths = [d for _, d, _, _ in log0]
+    assert depths == sorted(depths) and set(depths) == {0, 1, 2}
+    prev = 0
+    for k, (nimg, depth, alpha, m) in enumerate(log0):
+        # the plugin runs after the step: nimg is the counter the NEXT iteration starts from, (depth, alpha) what it will use
+        want_depth, want_alpha = pg.plugins.growth_stage(nimg, span, span, 2)
+        assert (depth, alpha) == (want_depth, repr(float(want_alpha))) and m == mb[depth], (k, nimg, depth, alpha, m)
+        used = mb[log0[k - 1][1]] if k else mb[0]      # minibatch the iteration that just ended ran with
+        assert nimg - prev == world * used, (k, nimg, prev, used)
+        prev = nimg
+    assert any(a not in ('1.0',) for _, _, a, _ in log0)        # fades happened
+    assert nimg0 >= 4.6 * span and its0 == len(log0)

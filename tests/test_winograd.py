@@ -568,3 +568,88 @@ def _strip_vs_tile(case):
         assert rel_err(got[7], ryp) < 2e-5 and float((got[6].cpu() == E.signbytes_of(ry)).float().mean()) > 0.9999
         assert rel_err(got[9], E.conv2d_pool(x.cpu(), w, None, N, H, H, 3, 1, 0.37, mask=m, mask_slope=0.2, other=other.cpu(), a=0.6, b=0.4)[1]) < 2e-5
         assert rel_err(got[10], E.conv2d_unpool(x.cpu(), w, N, H, H, 3, 1, 0.37, upmask=um, mul=0.7, mask_slope=0.2)) < 2e-5
+
+
+@pytest.mark.gpu
+def test_k_sliced_launches_stress_two_streams():
+    """The hand-rolled hand-over of the K-sliced launches (agent-scope sc1 stores of the partial sums, s_waitcnt vmcnt(0), relaxed
+    agent-scope ticket, last arriver reads with sc1 loads: conv_wino.hip) under load: 2 000 launches with 8 forced slices, four
+    shapes round robin on the main stream, while a second stream runs its own K-sliced launches (its own scratch) over the same
+    CUs all the time.  Every result must equal the first result of its shape bit for bit (slices are added in slice order, whoever
+    arrives last) -- a stale read of a slice or of a ticket would show up as a mismatch -- and the unsplit launch to rounding."""
+    lib, ops = pg._lib.load(), pg.ops
+    shapes = [(3, 16, 512, 512), (3, 32, 256, 256), (9, 16, 128, 128), (2, 8, 512, 64)]
+    data = []
+    for i, (N, H, ci, co) in enumerate(shapes):
+        x = rnd(N, H, H, ci, seed=i).cuda()
+        u = ops.wino_transform_weights((rnd(3, 3, co, ci, seed=10 + i) * 0.1).cuda())
+        mb = E.signbytes_of(rnd(N, H, H, co, seed=20 + i)).cuda()
+        data.append((x, u, mb, N, H))
+    assert lib.pg_debug_set_wino_ksplit(0) == 0
+    try:
+        unsplit = [ops.conv2d_wino(x, u, None, N, H, H, 0.37, mask=mb, mask_slope=0.2) for x, u, mb, N, H in data]
+        assert lib.pg_debug_set_wino_ksplit(8) == 0
+        ref = [ops.conv2d_wino(x, u, None, N, H, H, 0.37, mask=mb, mask_slope=0.2) for x, u, mb, N, H in data]
+        assert lib.pg_debug_last_wino_kernel().decode().count(', true, ') == 1
+        for a, b in zip(ref, unsplit):
+            assert rel_err(a, b) < 1e-5
+        bad = torch.zeros((), dtype=torch.int64, device='cuda')
+        bad2 = torch.zeros((), dtype=torch.int64, device='cuda')
+        side = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        for it in range(2000):
+            k = it % len(data)
+            x, u, mb, N, H = data[k]
+            y = ops.conv2d_wino(x, u, None, N, H, H, 0.37, mask=mb, mask_slope=0.2)
+            bad += torch.count_nonzero(y != ref[k])
+            if it % 2 == 0:                                   # the second stream: its own sliced launches, other shape phase
+                with torch.cuda.stream(side):
+                    k2 = (it // 2 + 1) % len(data)
+                    x2, u2, mb2, N2, H2 = data[k2]
+                    assert lib.pg_debug_set_wino_ksplit(8) == 0          # (thread-local, but the setting is per call site: keep it explicit)
+                    y2 = ops.conv2d_wino(x2, u2, None, N2, H2, H2, 0.37, mask=mb2, mask_slope=0.2)
+                    bad2 += torch.count_nonzero(y2 != ref[k2])
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        assert int(bad) == 0 and int(bad2) == 0, (int(bad), int(bad2))
+    finally:
+        lib.pg_debug_set_wino_ksplit(-1)
+
+
+@pytest.mark.gpu
+def test_workspace_bytes_query():
+    """pg_workspace_bytes (scratch sizes are queried, the caller owns the buffer): a scratch of exactly the queried size
+    makes the launch slice, one byte less and it runs unsplit; every layer of the 1024x1024 schedule at minibatch 3 / 9 fits the 32 MB
+    the host layer registers."""
+    import ctypes
+    lib, ops = pg._lib.load(), pg.ops
+    N, H, ci, co = 3, 16, 256, 256
+    need = ops.workspace_bytes(0, N, H, H, ci, co)
+    assert need > 16384 and ops.workspace_bytes(0, 9, 256, 256, 64, 64) == 0            # (a full grid never slices)
+    x, w = rnd(N, H, H, ci).cuda(), (rnd(3, 3, co, ci, seed=1) * 0.2).cuda()
+    u = ops.wino_transform_weights(w)
+    s = torch.cuda.Stream()
+    h = ctypes.c_void_p(s.cuda_stream)
+    buf = torch.zeros(need, dtype=torch.uint8, device='cuda')
+    y = torch.empty(N, H, H, co, device='cuda')
+    args = [ctypes.c_void_p(t.data_ptr()) for t in (x, u)] + [None, None, ctypes.c_void_p(y.data_ptr()), None, None, 1.0, 0.0, 0, None, None, 1.0,
+                                                              N, H, H, ci, co, 0, 0.37, 0.2, 0.2, h]
+    try:
+        assert lib.pg_set_workspace(h, ctypes.c_void_p(buf.data_ptr()), need) == 0
+        assert lib.pg_conv2d_wino_nhwc(*args) == 0
+        assert lib.pg_debug_last_wino_kernel().decode().count(', true, ') == 1
+        assert lib.pg_set_workspace(h, ctypes.c_void_p(buf.data_ptr()), need - 16) == 0
+        assert lib.pg_conv2d_wino_nhwc(*args) == 0
+        assert lib.pg_debug_last_wino_kernel().decode().count(', true, ') == 0
+        s.synchronize()
+    finally:
+        lib.pg_set_workspace(h, None, 0)
+    worst = 0
+    for n in (3, 9):
+        for hh, c_in, c_out in ((8, 512, 512), (16, 512, 512), (32, 512, 256), (32, 256, 512), (64, 256, 128), (64, 128, 256), (128, 128, 64)):
+            worst = max(worst, ops.workspace_bytes(0, n, hh, hh, c_in, c_out))
+        worst = max(worst, ops.workspace_bytes(1, n, 4, 4, 512, 512))
+    assert 0 < worst <= ops.WORKSPACE_BYTES
+    err = ctypes.c_size_t(0)
+    assert lib.pg_workspace_bytes(7, 1, 8, 8, 8, 16, ctypes.addressof(err)) == -1 and lib.pg_workspace_bytes(0, 1, 8, 8, 8, 16, None) == -1

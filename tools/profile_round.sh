@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): rocprofv3 kernel-trace stats of the default bench command plus
 # separate PMC passes (never combined with sys/hip traces).  Outputs under gpurun_out/prof/<tag>/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
@@ -13,7 +13,9 @@ PMCB="python $R/bench.py --no-cpu --no-per-depth --no-kernel-timing --no-configs
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $PMCB > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $PMCB > $OUT/pmc_write.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq -o p --output-format csv -- $PMCB > $OUT/pmc_sq.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p --output-format csv -- $PMCB > $OUT/pmc_lds.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p --output-format csv -- $PMCB > $OUT/pmc_lds.log 2>&1
+# the north-star window by counter: D step + gradient penalty + Adam(D) only (3 passes)
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq_dstep -o p --output-format csv -- $PMCB --d-step-only > $OUT/pmc_sq_dstep.log 2>&1
 # keep only the small summaries (the raw traces are large)
 python $R/tools/summarize_profile.py $OUT $TAG > $OUT/summary.log 2>&1
 python $R/tools/stream_overlap.py "$OUT/kt/**/kt_kernel_trace.csv" > $OUT/${TAG}_stream_overlap.txt 2>&1

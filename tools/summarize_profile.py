@@ -39,6 +39,7 @@ fetch, fd = load_pmc(os.path.join(out, 'pmc_fetch', 'p_counter_collection.csv'))
 write, wd = load_pmc(os.path.join(out, 'pmc_write', 'p_counter_collection.csv'))
 sq, sd = load_pmc(os.path.join(out, 'pmc_sq', 'p_counter_collection.csv'))
 lds, ld = load_pmc(os.path.join(out, 'pmc_lds', 'p_counter_collection.csv'))
+dsq, dsd = load_pmc(os.path.join(out, 'pmc_sq_dstep', 'p_counter_collection.csv'))     # bench.py --d-step-only: the D step + gradient penalty window
 kernels = sorted(set(fetch) | set(write) | set(sq), key=lambda k: -sum(sd.get(k, fd.get(k, {})).values()))
 rows = []
 roof = {}
@@ -59,13 +60,24 @@ for k in kernels:
                  '%.3f' % (sq.get(k, {}).get('SQ_WAIT_INST_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1))),
                  '%.3f' % (sq.get(k, {}).get('SQ_WAIT_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1))),
                  # effective shader clock while the kernel ran: GRBM_GUI_ACTIVE cycles / kernel wall time (MI355X_MICROARCH.md, DVFS)
-                 '%.2f' % (lds.get(k, {}).get('GRBM_GUI_ACTIVE', 0.0) / max(1.0, sum(ld.get(k, {}).values())))])
+                 '%.2f' % (lds.get(k, {}).get('GRBM_GUI_ACTIVE', 0.0) / max(1.0, sum(ld.get(k, {}).values()))),
+                 # round 4: what the waves wait for.  VALU instructions per MFMA (fp32 MFMA time and VALU time of the waves of a SIMD ADD on
+                 # gfx950, tools/exp/mfma_valu_share.hip: MFMA-busy <= 32 / (32 + 4 x this)); LDS pipe active, waves waiting for LDS and
+                 # waves executing VALU / LDS instructions as fractions of the wave cycles of the same pass
+                 '%.2f' % (sq.get(k, {}).get('SQ_INSTS_VALU', 0) / sq.get(k, {}).get('SQ_INSTS_MFMA', 1) - 1.0 if sq.get(k, {}).get('SQ_INSTS_MFMA', 0) else 0.0),
+                 '%.3f' % (lds.get(k, {}).get('SQ_LDS_IDX_ACTIVE', 0) / max(1.0, lds.get(k, {}).get('SQ_WAVE_CYCLES', 0) or 1e30)),
+                 '%.3f' % (lds.get(k, {}).get('SQ_WAIT_INST_LDS', 0) / max(1.0, lds.get(k, {}).get('SQ_WAVE_CYCLES', 0) or 1e30)),
+                 '%.3f' % (lds.get(k, {}).get('SQ_ACTIVE_INST_VALU', 0) / max(1.0, lds.get(k, {}).get('SQ_WAVE_CYCLES', 0) or 1e30)),
+                 '%.3f' % (lds.get(k, {}).get('SQ_ACTIVE_INST_LDS', 0) / max(1.0, lds.get(k, {}).get('SQ_WAVE_CYCLES', 0) or 1e30))])
+    nm, nv = sq.get(k, {}).get('SQ_INSTS_MFMA', 0), sq.get(k, {}).get('SQ_INSTS_VALU', 0)
     roof[k] = {'hbm_bytes_per_launch': fetch_b + write_b, 'fetch_bytes_per_launch': fetch_b,
-               'write_bytes_per_launch': write_b, 'mfma_busy_pct': mfma_pct, 'avg_launch_us': tot_ns / 1e3 / max(1, calls)}
+               'write_bytes_per_launch': write_b, 'mfma_busy_pct': mfma_pct, 'avg_launch_us': tot_ns / 1e3 / max(1, calls),
+               'valu_per_mfma': (nv / nm - 1.0) if nm else None}       # (SQ_INSTS_VALU counts the MFMAs too)
 with open(os.path.join(out, tag + '_pmc_summary.csv'), 'w') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'calls', 'total_ms', 'avg_us', 'hbm_fetch_bytes_per_launch(x2 corrected)', 'hbm_write_bytes_per_launch',
-                'mfma_busy_pct', 'lds_conflict_frac', 'insts_mfma', 'insts_valu', 'wait_inst_frac', 'wait_any_frac', 'eff_clock_ghz'])
+                'mfma_busy_pct', 'lds_conflict_frac', 'insts_mfma', 'insts_valu', 'wait_inst_frac', 'wait_any_frac', 'eff_clock_ghz',
+                'valu_per_mfma', 'lds_idx_active_frac', 'wait_inst_lds_frac', 'active_inst_valu_frac', 'active_inst_lds_frac'])
     w.writerows(rows)
 fam = collections.defaultdict(lambda: dict(bytes=0.0, calls=0, ns=0.0))
 for k, v in roof.items():
@@ -73,7 +85,20 @@ for k, v in roof.items():
     n = len(sd.get(k) or fd.get(k) or {})
     fam[base]['bytes'] += v['hbm_bytes_per_launch'] * n
     fam[base]['calls'] += n
-json.dump({'tag': tag, 'per_kernel': roof,
+# ---- the north-star window by counter: D step + gradient penalty + Adam(D) only (bench.py --d-step-only under --pmc)
+dwin = None
+if dsq:
+    tot = sum(sum(v.values()) for v in dsd.values())
+    conv = [k for k in dsd if k.startswith(('conv_', 'wgrad_strip'))]
+    def busy(keys):
+        t = sum(sum(dsd[k].values()) for k in keys)
+        return 100.0 * sum(dsq[k].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for k in keys) / (t * 2.4 * 1024) if t else 0.0
+    dwin = {'mfma_busy_pct_all_kernels': busy(list(dsd)), 'mfma_busy_pct_conv_kernels': busy(conv),
+            'conv_kernel_time_share': sum(sum(dsd[k].values()) for k in conv) / tot if tot else 0.0,
+            'kernel_time_ms_per_pass': tot / 1e6 / 3.0, 'passes': 3,
+            'is': 'SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs), summed over the kernels of 3 serialised D-step + gradient-penalty passes'}
+    print('D step + GP window:', dwin)
+json.dump({'tag': tag, 'd_step_gp_window': dwin, 'per_kernel': roof,
            'per_family': {b: {'hbm_bytes_per_launch': d['bytes'] / max(1, d['calls']), 'launches': d['calls']} for b, d in fam.items()}},
           open(os.path.join(out, tag + '_roofline.json'), 'w'), indent=1)
 for r in rows[:14]:
