@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(WinoP p)
 //     8 x 8 tiles: 18 x 19 slots x 2 planes = 684) fits XS = 3: 2 x (12 + 8) KB = 40 KB of LDS per workgroup, FOUR workgroups per
 //     CU (124 VGPRs allow four waves per SIMD) instead of three with XS = 4.
 template <int NCB, int XK, int XS, bool KSP = false, int EPI = EPI_GENERIC>
-__global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 waves per SIMD: <= 256 VGPRs + AGPRs
+__global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 waves per SIMD: <= 256 VGPRs + AGPRs (NCB = 4 at one wave per SIMD: 1.2-1.5x slower, tools/exp/rejected/wino2_64_couts_per_workgroup.txt)
 {
     static_assert(!KSP || (NCB == 1 && XK == 1), "K split: 16 couts per workgroup, 8-channel input staging");
     static_assert(EPI == EPI_GENERIC || (NCB == 1 && XK == 1), "specialised epilogues: 16 couts per workgroup");
@@ -780,7 +780,7 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
     if (vec >= 10 || vec == 0) {
         // second-generation kernel (LDS-DMA, 8-channel chunks, 16*NCB couts per workgroup); two cout blocks per workgroup
         // when that still leaves at least two workgroups per CU
-        int ncb = vec >= 10 ? vec - 10 : ((Cin >= 512 && (long long)ntb * ((Cout + 31) / 32) >= 768) ? 2 : 1);   // measured: tools/sweep_wino.py
+        int ncb = (vec >= 10 && vec < 20) ? vec - 10 : ((Cin >= 512 && (long long)ntb * ((Cout + 31) / 32) >= 768) ? 2 : 1);   // measured: tools/sweep_wino.py
         if (ncb != 1 && ncb != 2) return PG_E_ARG;
         if (pn_r || pnb_y) ncb = Cout > 16 ? 2 : 1;           // PixelNorm epilogue / adjoint: all couts of a pixel in one workgroup
         // Staging the input region 16 channels at a time (XK = 2: every activation line comes from L2 twice instead of four times)

@@ -16,6 +16,9 @@ timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p --output-format csv -- $PMCB > $OUT/pmc_lds.log 2>&1
 # the north-star window by counter: D step + gradient penalty + Adam(D) only (3 passes)
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq_dstep -o p --output-format csv -- $PMCB --d-step-only > $OUT/pmc_sq_dstep.log 2>&1
+# per-layer table of the Winograd conv launches of one step, each alone on cold inputs (tools/layer_table.py)
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_layers -o p --output-format csv -- python $R/tools/layer_table.py run $OUT/layers.json > $OUT/pmc_layers.log 2>&1
+python $R/tools/layer_table.py table $OUT/layers.json $(find $OUT/pmc_layers -name p_counter_collection.csv | head -1) $OUT/${TAG}_wino_layer_table.csv >> $OUT/summary_layers.log 2>&1
 # keep only the small summaries (the raw traces are large)
 python $R/tools/summarize_profile.py $OUT $TAG > $OUT/summary.log 2>&1
 python $R/tools/stream_overlap.py "$OUT/kt/**/kt_kernel_trace.csv" > $OUT/${TAG}_stream_overlap.txt 2>&1
