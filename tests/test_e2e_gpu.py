@@ -578,7 +578,7 @@ def test_deferred_d_update_matches_inline(monkeypatch):
         assert_same_contributions(grads_by_name(tra.G), grads_by_name(trb.G), tol=0.3, total=5e-2)
         for a, b in ((tra.G, trb.G), (tra.D, trb.D)):           # this iteration's updates: a flipped element moves by at most 2 lr
             assert float((a._flat_param - b._flat_param).abs().max()) <= 2 * 0.001 + 1e-6
-            assert _l2(a._flat_param, b._flat_param) < 3e-3
+            assert _l2(a._flat_param, b._flat_param.cpu()) < 3e-3
             with torch.no_grad():
                 b._flat_param.copy_(a._flat_param)               # re-synchronise B: the next iteration starts from identical weights ...
             b.mark_params_changed()
@@ -653,14 +653,15 @@ def test_config2_grow_run_against_oracle(oracle):
     og, od = oracle.AdamState(), oracle.AdamState()
     # PRE-ADAM gradients, iteration by iteration, against the oracle evaluated on the HIP run's OWN weights of that iteration (what the
     # round-3 review asked for instead of end-state bounds that have to absorb 14 sign-like Adam steps): one iteration of every stage
-    # and of every fade.  The D weights the G step sees are snapshotted when the G loss is entered (after D's deferred update).
+    # and fade up to 16x16.  The D weights the G step sees are snapshotted when the G loss is entered (after D's deferred update).
     check_at = set()
     seen = set()
     for it in range(ITERS):
         key = (sched[it][0], sched[it][1] < 1.0)
         if key not in seen:
             seen.add(key)
-            check_at.add(it)
+            if key in ((0, False), (1, True), (2, True), (2, False)):     # (the 32x32 iterations at minibatch 64 cost ~40 s of oracle time each:
+                check_at.add(it)                                        #  that stage has its own gradient checks in test_full_width_res32_golden)
     snap = {}
 
     def g_loss(Gm, Dm, z):
