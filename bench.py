@@ -266,16 +266,21 @@ def timed_steps(tr, steps, warmup, dp, fn=None):
         dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    stamps = []
     for _ in range(steps):
         fn()
-    HOST_ENQUEUE['ms'] = 1e3 * (time.perf_counter() - t0) / steps      # host time to ENQUEUE a step (the device is still running)
+        stamps.append(time.perf_counter())
+    HOST_ENQUEUE['ms'] = 1e3 * (stamps[-1] - t0) / steps           # host time to ENQUEUE a step, averaged over the whole loop: includes the time the
+                                                                    # runtime holds the host back once it is a queue's depth ahead of the device
+    head = [b - a for a, b in zip([t0] + stamps[:9], stamps[:10])]
+    HOST_ENQUEUE['free_ms'] = 1e3 * sorted(head)[len(head) // 2]   # median of the first ten steps after the synchronisation: the host running free
     torch.cuda.synchronize()
     if dp is not None:
         dp.barrier()
     return _max_over_ranks(time.perf_counter() - t0, dp)
 
 
-HOST_ENQUEUE = {'ms': None}
+HOST_ENQUEUE = {'ms': None, 'free_ms': None}
 
 
 def robust_ms(tr, dp, fn=None, prime=20, window_s=0.35, windows=3):
@@ -530,7 +535,7 @@ def main():
         dp.stats.update(collectives=0, bytes=0)
     dt = timed_steps(tr, args.steps, args.warmup, dp, fn=d_step_fn(tr) if args.d_step_only else None)
     ms_per_step = 1e3 * dt / args.steps
-    host_ms = HOST_ENQUEUE['ms']
+    host_ms, host_free_ms = HOST_ENQUEUE['ms'], HOST_ENQUEUE['free_ms']
     value = n_gpus * mb * args.steps / dt
     w_d, w = step_flops(tr.G, tr.D, depth, args.alpha)
 
@@ -548,7 +553,9 @@ def main():
                    'parallelism': 'dp%d' % n_gpus, 'fmap_base': args.fmap_base},
         'step_algorithmic_gflop_per_image': w / 1e9,
         'algorithmic_frac': w * (value / n_gpus) / MFMA_F32_PEAK,
-        'host_enqueue_ms_per_step': host_ms,       # Python + launch time of one step on the host; the device runs behind it
+        'host_enqueue_ms_per_step': host_free_ms,  # Python + launch time of one step on the host running free (median of the first ten timed steps)
+        'host_enqueue_ms_per_step_whole_loop': host_ms,   # ... averaged over all timed steps (includes waiting for queue space behind the device)
+        'step_issue': pg.wgan_gp_loss._replay_mode(tr.G) or 'eager',
     }
     out['config']['hip_graphs'] = bool((args.graphs or depth == 0) and args.alpha >= 1.0)
     if args.host_data or (args.config == 5 and not args.no_configs):
@@ -668,6 +675,7 @@ def main():
             tr.train()
     pg.wgan_gp_loss.enable_graphs(True if args.graphs else 'auto')
     del tr
+    pg.plans.clear()
     torch.cuda.empty_cache()
 
     if not args.no_per_depth:
@@ -677,6 +685,8 @@ def main():
             t = make_trainer(pg, 1024, d, 1.0, m, seed, dp, fmap_base=args.fmap_base)
             per.append(stage_entry(pg, t, dp, n_gpus, m, d, 1.0))          # minibatch m PER RANK (weak scaling), max over ranks
             del t
+            pg.plans.clear()                                               # (a plan pins its stage's activations)
+            pg.graphs.clear()
             torch.cuda.empty_cache()
         out['per_depth'] = per
 
@@ -685,18 +695,22 @@ def main():
         t = make_trainer(pg, 1024, 8, 0.5, 3, seed, dp)
         sec['depth8_alpha0.5'] = stage_entry(pg, t, dp, n_gpus, 3, 8, 0.5, {'workload': 'config 5 network, 1024x1024 stage in the middle of its fade-in (alpha 0.5)'})
         del t
+        pg.plans.clear()
         torch.cuda.empty_cache()
         t = make_trainer(pg, 1024, 8, 1.0, 3, seed, dp, fmap_base=8192)
         sec['depth8_fmap8192'] = stage_entry(pg, t, dp, n_gpus, 3, 8, 1.0, {'workload': 'paper widths (fmap_base 8192), 1024x1024 stage, minibatch 3 per GPU'})
         del t
+        pg.plans.clear()
         torch.cuda.empty_cache()
         t = make_trainer(pg, 128, 5, 1.0, 16, seed, dp)
         sec['config3'] = stage_entry(pg, t, dp, n_gpus, 16, 5, 1.0, {'workload': 'config 3: 128x128 network at depth 5, minibatch 16 per GPU (32 global on 2 GPUs)'})
         del t
+        pg.plans.clear()
         torch.cuda.empty_cache()
         t = make_trainer(pg, 256, 6, 1.0, 8, seed, dp, channels=1)
         sec['config4'] = stage_entry(pg, t, dp, n_gpus, 8, 6, 1.0, {'workload': 'config 4: 256x256 C=1 (abslog-spectrogram shape) network at depth 6, minibatch 8 per GPU (32 global on 4 GPUs)'})
         del t
+        pg.plans.clear()
         torch.cuda.empty_cache()
         sec['config2'] = grow_run(pg, dp, n_gpus, rank)
         torch.cuda.empty_cache()

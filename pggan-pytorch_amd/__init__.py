@@ -4,7 +4,7 @@ The reference's Python surface (Generator / Discriminator / wgan_gp_D_loss / wga
 Trainer / DepthManager / LRScheduler) on top of hand-written gfx950 HIP kernels reached through
 the C-ABI of ``libpggan_hip.so`` (``include/pggan_hip.h``).  Import as
 ``importlib.import_module('pggan-pytorch_amd')`` or through the root-level shim ``import pggan_amd``."""
-from . import _lib, ops, engine, network, wgan_gp_loss, trainer, plugins, optim, parallel, utils, graphs, sound  # noqa: F401
+from . import _lib, ops, engine, network, wgan_gp_loss, trainer, plugins, optim, parallel, utils, graphs, plans, sound  # noqa: F401
 from .network import Generator, Discriminator, PGConv2d  # noqa: F401
 from .wgan_gp_loss import wgan_gp_D_loss, wgan_gp_G_loss  # noqa: F401
 from .trainer import Trainer  # noqa: F401

@@ -1045,7 +1045,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     N = real.shape[0]
     D._sync_version()
     x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
-    x3[:N].copy_(real)                                                        # D2D memcpy (plumbing)
+    ops.axpby_mask(real, a=1.0, out=x3[:N])                                   # device copy (plumbing; a C-ABI launch so that plans.py records it)
     generator_forward(G, latents, out=x3[N:2 * N])                            # :51-52  (no graph kept)
     ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                      # :19
     s, ctx = d_forward(D, x3, groups=3)                                       # :47,54,20

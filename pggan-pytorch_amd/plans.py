@@ -1,0 +1,236 @@
+"""Launch-plan replay of the D-step and G-step schedules: the host side of a step as a table built once per growth stage.
+
+The schedules in ``engine`` are pure launch sequences with no host synchronisation and no data-dependent control flow, so for a
+fixed (network pair, depth, minibatch, loss hyper-parameters) and alpha == 1 every step issues the SAME C-ABI calls with the same
+arguments on the same streams, separated by the same event record / wait pairs -- only ~5 us of each ~25 us launch is the launch
+itself, the rest is Python (shape logic, ``torch.empty``, pointer checks, stream contexts; ``tools/host_profile.py``).  A plan
+records that sequence once -- while executing it for real -- as a flat list
+
+    (CALL, ctypes function, argument tuple)          the stream handle is one of the arguments
+    (RECORD, event, stream) / (WAIT, event, stream)  the fork / join points between the main and the weight-gradient stream
+    (PENDING, net) / (BWD_COPIES, net)               waits whose event changes from step to step (deferred D update, side-stream
+                                                     refresh of the backward-only derived weights): looked up at replay time
+
+and replays it with one Python loop: same kernels, same streams, same events, same overlap as the eager path (unlike a hipGraph,
+whose replay serialises the two streams on ROCm 7.2: 12.2 vs 11.0 ms at 1024^2, 4.7 vs 2.2 ms at 8x8, ``bench.py --graphs``).
+Every tensor whose pointer enters a recorded call is kept alive by the plan, so the caching allocator can never hand its block to
+somebody else (the price: the plan pins one step's worth of activations, ~10 GB at 1024^2 of 288 GB).  Inputs are copied into
+static buffers, losses come back in static tensors (copies are handed out), gradients land in the networks' flat gradient buffers
+exactly as in the eager path.
+
+Not in a plan: Adam and the derived-weight refresh (host scalars / version checks: ``Trainer`` runs them eagerly after each update,
+``_prologue`` re-checks the versions before every replay so that a foreign optimizer or ``load_state_dict`` is noticed), the RCCL
+exchange (data-parallel runs stay eager: the bucketed exchange hooks into the backward sweep), fade-in phases (a new alpha per
+iteration), the mixing-factor draw (a counter-based RNG call with a new counter per step, written into the static buffer)."""
+import collections
+
+import torch
+
+from . import _lib, engine, ops
+
+CALL, RECORD, WAIT, PENDING, BWD_COPIES = 0, 1, 2, 3, 4
+
+
+class _Plan(object):
+    def __init__(self):
+        self.entries = None          # the recorded list (None until recorded)
+        self.keep = {}               # id -> tensor: everything whose pointer is baked into the entries
+        self.static_in = None
+        self.static_out = None
+        self.warm = 0
+
+
+_CACHE = collections.OrderedDict()
+MAX_PLANS = 4                        # (D, G) of the current network pair + one more pair: every plan pins GBs of activations
+STATS = {'recorded': 0, 'replayed': 0}
+
+
+def clear():
+    _CACHE.clear()
+
+
+class _Recorder(object):
+    """Context manager: while active every ``_lib.call`` is executed AND logged, the stream / event operations the engine issues
+    are executed AND logged with events the plan owns, and every tensor whose pointer passes ``ops._p`` is kept."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.entries = []
+
+    def __enter__(self):
+        rec = self
+        self._call = _lib.call
+        self._p = ops._p
+        self._wait_stream = torch.cuda.Stream.wait_stream
+        self._wait_event = torch.cuda.Stream.wait_event
+        self._ev_record = torch.cuda.Event.record
+        self._wait_pending = engine.wait_pending
+        self._await_bwd = engine._await_backward_copies
+        lib = _lib.load()
+
+        def call(name, *args):
+            fn = getattr(lib, name)
+            _lib.check(fn(*args), name)
+            rec.entries.append((CALL, fn, args, name))
+
+        def p(t):
+            if t is not None:
+                rec.plan.keep[id(t)] = t
+            return rec._p(t)
+
+        def wait_stream(self_stream, other):
+            ev = torch.cuda.Event()
+            rec._ev_record(ev, other)
+            rec._wait_event(self_stream, ev)
+            rec.entries.append((RECORD, ev, other))
+            rec.entries.append((WAIT, ev, self_stream))
+
+        def wait_event(self_stream, ev):
+            rec._wait_event(self_stream, ev)
+            rec.entries.append((WAIT, ev, self_stream))
+
+        def ev_record(ev, stream=None):
+            stream = torch.cuda.current_stream() if stream is None else stream
+            rec._ev_record(ev, stream)
+            rec.entries.append((RECORD, ev, stream))
+
+        def wait_pending(net):
+            rec._wait_pending(net)
+            rec.entries.append((PENDING, net, torch.cuda.current_stream()))
+
+        def await_bwd(net):
+            rec._await_bwd(net)
+            rec.entries.append((BWD_COPIES, net, torch.cuda.current_stream()))
+
+        _lib.call = call
+        ops._lib.call = call
+        ops._p = p
+        torch.cuda.Stream.wait_stream = wait_stream
+        torch.cuda.Stream.wait_event = wait_event
+        torch.cuda.Event.record = ev_record
+        engine.wait_pending = wait_pending
+        engine._await_backward_copies = await_bwd
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call = self._call
+        ops._lib.call = self._call
+        ops._p = self._p
+        torch.cuda.Stream.wait_stream = self._wait_stream
+        torch.cuda.Stream.wait_event = self._wait_event
+        torch.cuda.Event.record = self._ev_record
+        engine.wait_pending = self._wait_pending
+        engine._await_backward_copies = self._await_bwd
+        if exc[0] is None:
+            self.plan.entries = self.entries
+            STATS['recorded'] += 1
+        return False
+
+
+def _replay(plan):
+    check = _lib.check
+    for e in plan.entries:
+        kind = e[0]
+        if kind == CALL:
+            rc = e[1](*e[2])
+            if rc:
+                check(rc, e[3])
+        elif kind == RECORD:
+            e[1].record(e[2])
+        elif kind == WAIT:
+            e[2].wait_event(e[1])
+        elif kind == PENDING:
+            ev = getattr(e[1], '_pending', None)
+            if ev is not None:
+                e[2].wait_event(ev)
+                e[1]._pending = None
+        else:
+            engine._await_backward_copies(e[1])       # (the replay runs on the stream the step was recorded on)
+    STATS['replayed'] += 1
+
+
+def _new_plan(key):
+    """A plan pins one step's worth of activations: when a network pair moves to another growth stage / minibatch, the plans of
+    the stage it left are dropped (one D plan and one G plan per network pair at any time)."""
+    for k in [k for k in _CACHE if k[:3] == key[:3] and k != key]:
+        del _CACHE[k]
+    while len(_CACHE) >= MAX_PLANS:
+        _CACHE.popitem(last=False)          # least recently used
+    g = _CACHE[key] = _Plan()
+    return g
+
+
+def _prologue(*nets):
+    """What the bodies would notice at their entry points: a parameter update that did not go through FusedAdam, a growth-stage
+    change -- the derived weights are refreshed eagerly (never inside a plan)."""
+    for net in nets:
+        net._sync_version()
+        net._ensure_buffers()
+        if net._derived_ver != (net._param_version, int(net.depth)):
+            engine._derived(net)
+
+
+def d_step(D, G, real, latents, mix, lam, eps, target):
+    """Plan-replayed ``d_loss_forward`` + ``d_loss_backward``.  Returns (d_cost, d_real_loss, d_fake_loss)."""
+    key = ('D', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(D.depth), tuple(real.shape), tuple(latents.shape), float(lam), float(eps), float(target))
+    g = _CACHE.get(key)
+    if g is None:
+        g = _new_plan(key)
+        g.static_in = (torch.empty_like(real), torch.empty_like(latents), torch.empty_like(mix))
+    else:
+        _CACHE.move_to_end(key)
+    for dst, src in zip(g.static_in, (real, latents, mix)):
+        dst.copy_(src)
+    _prologue(D, G)
+
+    def body():
+        D._skip_join = True                  # the update that follows runs behind the weight gradients (Trainer: deferred, or joins itself)
+        try:
+            c, rl, fl, state = engine.d_loss_forward(D, G, g.static_in[0], g.static_in[1], g.static_in[2], lam, eps, target)
+            engine.d_loss_backward(state)
+        finally:
+            D._skip_join = False
+        return c, rl, fl
+    if g.entries is None:
+        if g.warm < 2:                       # eager warm-up (kernel attributes, first-request derived copies, allocator pools)
+            g.warm += 1
+            out = body()
+            engine._join_side()
+            return out
+        with _Recorder(g):
+            g.static_out = body()
+    else:
+        _replay(g)
+    engine._assign_grads(D, engine.d_active_params(D, int(D.depth), 1.0), linear=True)
+    # the static outputs are overwritten by the next replay: hand out copies (a plugin may keep loss tensors)
+    return tuple(t.clone() for t in g.static_out)
+
+
+def g_step(G, D, latents):
+    """Plan-replayed ``g_loss_forward`` + ``g_loss_backward``.  Returns g_cost."""
+    key = ('G', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(G.depth), tuple(latents.shape))
+    g = _CACHE.get(key)
+    if g is None:
+        g = _new_plan(key)
+        g.static_in = (torch.empty_like(latents),)
+    else:
+        _CACHE.move_to_end(key)
+    g.static_in[0].copy_(latents)
+    if getattr(D, '_pending', None) is None:  # (a deferred D update refreshes D's derived weights itself, on the second stream)
+        _prologue(D)
+    _prologue(G)
+
+    def body():
+        c, state = engine.g_loss_forward(G, D, g.static_in[0])
+        engine.g_loss_backward(state)
+        return c, state['active_g']
+    if g.entries is None:
+        if g.warm < 2:
+            g.warm += 1
+            return body()[0]
+        with _Recorder(g):
+            g.static_out = body()
+    else:
+        _replay(g)
+    engine._assign_grads(G, g.static_out[1])
+    return g.static_out[0].clone()

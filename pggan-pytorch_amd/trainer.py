@@ -160,6 +160,8 @@ class Trainer(object):
         self._average_in_allreduce = {}
         self._exchanges = {}
         if parallel is not None:
+            from . import wgan_gp_loss
+            wgan_gp_loss.enable_plans(False)         # the bucketed exchange hooks into the eager backward sweep
             for net, opt in ((D, optimizer_d), (G, optimizer_g)):
                 if hasattr(opt, 'grad_scale'):
                     opt.grad_scale = parallel.grad_scale          # FusedAdam folds 1/world into its update
@@ -209,7 +211,7 @@ class Trainer(object):
         if self.parallel is None or not hasattr(net, '_flat_param'):
             return
         from . import parallel as par, wgan_gp_loss
-        if wgan_gp_loss._graphs_on(net) and float(net.alpha) >= 1.0 and net._flat_param.is_cuda:
+        if wgan_gp_loss._replay_mode(net) is not None and float(net.alpha) >= 1.0 and net._flat_param.is_cuda:
             return
         if os.environ.get('PGGAN_DP_BUCKETS', '1') == '0':
             return
@@ -264,6 +266,7 @@ class Trainer(object):
                 # generator forward that opens the G step; the main stream re-joins at its first use of D (engine.wait_pending)
                 engine.defer_to_side(self.D, self._d_update)
             else:
+                engine._join_side()                  # (a replayed plan leaves the weight gradients un-joined; a second join is free)
                 self._d_update()
             latents = _to_device(self.random_latents_generator())                 # :103
         g_losses = _as_tuple(self.G_loss(self.G, self.D, latents))                # :105-110
@@ -274,6 +277,8 @@ class Trainer(object):
             self.G._grad_hook = None
         self._exchange(self.G)
         self.optimizer_g.step()                                                   # :112
+        if getattr(self.G, '_flat_param', None) is not None and self.G._flat_param.is_cuda:
+            engine._derived(self.G)                  # (the next generator pass needs them first thing; never part of a replayed plan)
         engine.wait_pending(self.D)                  # (a G_loss that never ran D: nothing may outlive the iteration)
         self.iterations += 1
         self.call_plugins('iteration', self.iterations, *(g_losses + d_losses))   # :115

@@ -16,21 +16,44 @@ _use_graphs = 'auto'        # 'auto': replay only where the step is launch-bound
 
 
 def enable_graphs(flag=True):
-    """Replay the D-step / G-step schedules from captured hipGraphs whenever alpha == 1 (see graphs.py).
-    ``'auto'`` (default) does so only at depth 0: measured on MI355X the 4x4 stage (~100 launches of ~10 us) is
-    launch-bound and replays 1.44x faster, while from 8x8 on eager two-stream launching is faster (the replay
-    serialises the weight-gradient stream)."""
+    """How the D-step / G-step schedules are issued whenever alpha == 1:
+    ``'auto'`` (default): the launch-bound 4x4 stage is replayed from captured hipGraphs (graphs.py: ~100 launches of ~10 us, 1.44x
+    faster), every other stage from a recorded LAUNCH PLAN (plans.py: the same kernels on the same streams with the same events as
+    the eager path, minus the Python between them; ``enable_plans(False)`` turns that off);
+    ``True``: hipGraph replay everywhere (measured slower from 8x8 on: the replay serialises the weight-gradient stream);
+    ``False``: eager launches (per-launch instrumentation, debugging)."""
     global _use_graphs
     _use_graphs = 'auto' if flag == 'auto' else bool(flag)
     if not flag:
-        from . import graphs
+        from . import graphs, plans
         graphs.clear()
+        plans.clear()
+
+
+def enable_plans(flag=True):
+    """Launch-plan replay of the stages above 4x4 (see ``enable_graphs``).  Off under data parallelism: the bucketed gradient
+    exchange hooks into the eager backward sweep."""
+    global _use_plans
+    _use_plans = bool(flag)
+    if not flag:
+        from . import plans
+        plans.clear()
+
+
+_use_plans = __import__('os').environ.get('PGGAN_PLANS', '1') != '0'
+
+
+def _replay_mode(net):
+    """'graph' | 'plan' | None (eager) for a step of ``net`` at its current growth stage (alpha == 1 is checked by the callers)."""
+    if _use_graphs is False:
+        return None
+    if _use_graphs is True or int(net.depth) == 0:
+        return 'graph'
+    return 'plan' if _use_plans else None
 
 
 def _graphs_on(net):
-    if _use_graphs == 'auto':
-        return int(net.depth) == 0
-    return bool(_use_graphs)
+    return _replay_mode(net) == 'graph'
 
 
 def set_mixing_factors(m):
@@ -90,9 +113,14 @@ class LossTensor(torch.Tensor):
             return func(*args, **(kwargs or {}))
 
 
-def _graphed_backward(scale):
-    if scale != 1.0:
-        raise NotImplementedError('backward(gradient != 1) is not available on the hipGraph path')
+def _replayed_backward(net):
+    """``backward()`` of a loss whose step was replayed (hipGraph or launch plan): the gradients are already in ``param.grad``;
+    a ``gradient`` other than 1 rescales the flat gradient buffer afterwards -- what the eager path does too (engine.d_loss_backward)."""
+    def fn(scale):
+        if scale != 1.0:
+            from . import ops
+            ops.axpby_mask(net._flat_grad, a=scale, out=net._flat_grad)
+    return fn
 
 
 def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
@@ -110,13 +138,14 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
         mixing_factors = None
     else:                                                                # :15-17 (device RNG)
         mix = _draw_mixing_factors(n, real_images_in.device)
-    if _graphs_on(D) and float(D.alpha) >= 1.0 and real_images_in.is_cuda:
-        from . import graphs
+    mode = _replay_mode(D) if (float(D.alpha) >= 1.0 and real_images_in.is_cuda and hasattr(D, '_flat_param')) else None
+    if mode is not None:
+        from . import graphs, plans
         real_c = engine._check_dev(real_images_in, 'real images')
         z_c = engine._check_dev(fake_latents_in, 'latents')
-        d_cost, d_real_loss, d_fake_loss = graphs.d_step(D, G, real_c, z_c, mix.contiguous(), iwass_lambda,
-                                                         iwass_epsilon, iwass_target)
-        d_cost = LossTensor.wrap(d_cost, _graphed_backward)      # gradients are already in param.grad
+        d_cost, d_real_loss, d_fake_loss = (graphs if mode == 'graph' else plans).d_step(D, G, real_c, z_c, mix.contiguous(), iwass_lambda,
+                                                                                         iwass_epsilon, iwass_target)
+        d_cost = LossTensor.wrap(d_cost, _replayed_backward(D))  # gradients are already in param.grad
         if return_all:
             return d_cost, d_real_loss, d_fake_loss
         return d_cost
@@ -131,9 +160,10 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
 def wgan_gp_G_loss(G, D, fake_latents_in):
     """reference wgan_gp_loss.py:68-74."""
     G.zero_grad()                                                        # :69
-    if _graphs_on(G) and float(G.alpha) >= 1.0 and fake_latents_in.is_cuda:
-        from . import graphs
-        g_cost = graphs.g_step(G, D, engine._check_dev(fake_latents_in, 'latents'))
-        return LossTensor.wrap(g_cost, _graphed_backward)
+    mode = _replay_mode(G) if (float(G.alpha) >= 1.0 and fake_latents_in.is_cuda and hasattr(G, '_flat_param')) else None
+    if mode is not None:
+        from . import graphs, plans
+        g_cost = (graphs if mode == 'graph' else plans).g_step(G, D, engine._check_dev(fake_latents_in, 'latents'))
+        return LossTensor.wrap(g_cost, _replayed_backward(G))
     g_cost, state = engine.g_loss_forward(G, D, fake_latents_in)
     return LossTensor.wrap(g_cost, lambda scale: engine.g_loss_backward(state, scale))

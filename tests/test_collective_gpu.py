@@ -131,7 +131,8 @@ def test_trainer_with_one_rank_communicator_matches_plain_trainer(dp, monkeypatc
     """``Trainer(parallel=dp)`` — bucketed exchange on the third stream, and one exchange per network — against the plain
     Trainer.  With one rank every collective is the identity and 1/world = 1, so the runs differ only by stream placement:
     the pre-Adam gradients of the first iteration agree to the atomic-add order of the weight-gradient commits, the weights
-    after 3 iterations to the 2*lr per step a sign-like Adam (beta1 = 0) can move a near-zero gradient element."""
+    after 3 iterations to twice the sum of the per-step bounds lr*sqrt((1 - beta2^t)/(1 - beta2)) of a sign-like Adam (beta1 = 0:
+    an element whose gradient was round-off noise until step t moves by that much, in either direction)."""
     g0, d0, gr0 = _train(None, True, monkeypatch)
     c0 = dp.stats['collectives']
     g1, d1, gr1 = _train(dp, True, monkeypatch)
@@ -140,7 +141,7 @@ def test_trainer_with_one_rank_communicator_matches_plain_trainer(dp, monkeypatc
     c2 = dp.stats['collectives']
     assert c1 - c0 > c2 - c1 >= 2 * 3            # buckets: more, smaller collectives; without: >= one span per network and step
     for name, ref, got in (('G bucketed', g0, g1), ('D bucketed', d0, d1), ('G flush', g0, g2), ('D flush', d0, d2)):
-        assert float((got - ref).abs().max()) <= 2 * 0.001 * 3 + 1e-6, name
+        assert float((got - ref).abs().max()) <= 2 * 0.001 * sum(((1 - 0.99 ** t) / 0.01) ** 0.5 for t in (1, 2, 3)) + 1e-6, name
         assert float((got - ref).norm() / ref.norm()) < 1e-3, name
     for other in (gr1, gr2):                     # first iteration: every layer received the same contributions
         assert_same_contributions(other[0][0], gr0[0][0])

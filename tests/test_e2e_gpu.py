@@ -2,6 +2,7 @@
 reference and (b) the CPU oracle on seeded inputs, through the product's public API
 (Generator / Discriminator / wgan_gp_D_loss / wgan_gp_G_loss / Trainer / DepthManager / FusedAdam).
 Tolerances (stated): outputs & losses 2e-4 rel. max-norm (north-star bound 1e-3), gradients 2e-3."""
+import copy
 import heapq
 
 import numpy as np
@@ -37,6 +38,13 @@ DEV = 'cuda'
 def _l2(a, b):
     a, b = a.detach().cpu().double().reshape(-1), torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).double().reshape(-1)
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _adam_step_bound(lr, t, beta2=0.99):
+    """Largest move of one parameter in Adam step t with beta1 = 0: lr * |g| / sqrt(v_hat) <= lr * sqrt((1 - beta2^t) / (1 - beta2)) -- reached by an
+    element whose gradient was ~0 until this step.  Two runs whose gradients differ only by atomic-order noise can differ by twice that on such
+    an element (opposite signs)."""
+    return lr * ((1.0 - beta2 ** t) / (1.0 - beta2)) ** 0.5
 
 
 def _cpu_sd(sd):
@@ -310,6 +318,68 @@ def test_hipgraph_replay_matches_eager():
     assert len({id(v) for v in pg.ops._workspaces.values() if v is not None}) <= 4
 
 
+@pytest.mark.parametrize('foreign_optimizer', [False, True])
+def test_launch_plan_replay_matches_eager(foreign_optimizer):
+    """The D-/G-step schedules replayed from recorded launch plans (plans.py: the same C-ABI calls on the same streams with the same
+    events, minus the Python between them) against eager launches.  Two trainers with the same seeds are stepped side by side, one
+    with plans, one eager; after every iteration the PRE-ADAM gradients are compared tensor by tensor (equal up to the order of the
+    atomic weight-gradient commits) and the eager trainer is re-synchronised to the other (weights, Adam moments), so replayed
+    iterations are checked at identical weights.  Also: the plans are really replayed, a growth-stage change records new plans, and
+    with a foreign optimizer (torch.optim.Adam: no mark_params_changed) the version check in front of every replay keeps the derived
+    Winograd weights fresh (stale ones would put the losses off by O(lr))."""
+    wl = pg.wgan_gp_loss
+
+    def build():
+        torch.manual_seed(11)
+        shape = (1, 3, 32, 32)
+        kw = dict(fmap_base=512, fmap_max=64)
+        G = pg.Generator(shape, latent_size=64, **kw).cuda()
+        D = pg.Discriminator(shape, **kw).cuda()
+        G.depth = D.depth = 2
+        mk = (lambda ps: torch.optim.Adam(ps, 0.001, betas=(0.0, 0.99))) if foreign_optimizer else (lambda ps: pg.FusedAdam(ps, 0.001, betas=(0.0, 0.99)))
+        opt_g, opt_d = mk(G.parameters()), mk(D.parameters())
+        ds = pg.utils.SyntheticDataset(32, 3, seed=5)
+        ds.model_depth = 2
+        tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, ds.loader(8), pg.utils.device_latents(8, 64, seed=3))
+        tr._losses = []
+        return tr, ds
+    wl.enable_graphs('auto')
+    pg.plans.STATS.update(recorded=0, replayed=0)
+    try:
+        (tra, dsa), (trb, dsb) = build(), build()
+        for it in range(10):
+            if it == 6:                                        # growth-stage change: new plans (two eager steps, one recorded, then replay)
+                for tr, ds in ((tra, dsa), (trb, dsb)):
+                    tr.G.depth = tr.D.depth = ds.model_depth = 3
+                    tr.dataiter = ds.loader(8)
+            out = []
+            for tr, plans_on in ((tra, True), (trb, False)):
+                wl._use_plans = plans_on                       # (the switch itself, without dropping the recorded plans)
+                wl.manual_seed(100 + it)                       # same mixing factors for both
+                tr.train()
+                torch.cuda.synchronize()
+                out.append((grads_by_name(tr.D), grads_by_name(tr.G)))
+            assert_same_contributions(out[0][0], out[1][0])
+            assert_same_contributions(out[0][1], out[1][1], tol=0.3, total=5e-2)     # (through D after its update: see test_deferred_d_update_matches_inline)
+            for a, b in ((tra.G, trb.G), (tra.D, trb.D)):
+                assert float((a._flat_param - b._flat_param).abs().max()) <= 2 * _adam_step_bound(0.001, it + 1) + 1e-6
+                assert _l2(a._flat_param, b._flat_param.cpu()) < 3e-3
+                with torch.no_grad():
+                    b._flat_param.copy_(a._flat_param)
+                b.mark_params_changed()
+            for oa, ob in ((tra.optimizer_g, trb.optimizer_g), (tra.optimizer_d, trb.optimizer_d)):
+                if foreign_optimizer:
+                    ob.load_state_dict(copy.deepcopy(oa.state_dict()))   # (load_state_dict keeps same-dtype state tensors by reference)
+                else:
+                    for (_, ma, va), (_, mb_, vb) in zip(oa._flat.values(), ob._flat.values()):
+                        mb_.copy_(ma)
+                        vb.copy_(va)
+        assert pg.plans.STATS['recorded'] == 4 and pg.plans.STATS['replayed'] == 2 * (3 + 1), pg.plans.STATS   # (D, G) x two stages; iterations 3..5 and 9
+    finally:
+        wl._use_plans = True
+        wl.enable_graphs(False)
+
+
 def test_whole_module_pickle_roundtrip(tmp_path):
     """SaverPlugin semantics (plugins.py:155-166): ``torch.save(model)`` / ``torch.load`` of whole modules must
     preserve weights AND the equalized-lr constants c (not in the reference's state_dict), and the reloaded
@@ -576,8 +646,8 @@ def test_deferred_d_update_matches_inline(monkeypatch):
         # update, where a sign-like Adam has already turned that noise into +-lr differences of near-zero elements: looser.
         assert_same_contributions(grads_by_name(tra.D), grads_by_name(trb.D))
         assert_same_contributions(grads_by_name(tra.G), grads_by_name(trb.G), tol=0.3, total=5e-2)
-        for a, b in ((tra.G, trb.G), (tra.D, trb.D)):           # this iteration's updates: a flipped element moves by at most 2 lr
-            assert float((a._flat_param - b._flat_param).abs().max()) <= 2 * 0.001 + 1e-6
+        for a, b in ((tra.G, trb.G), (tra.D, trb.D)):           # this iteration's updates: a flipped near-zero element moves by at most twice the step bound
+            assert float((a._flat_param - b._flat_param).abs().max()) <= 2 * _adam_step_bound(0.001, it + 1) + 1e-6
             assert _l2(a._flat_param, b._flat_param.cpu()) < 3e-3
             with torch.no_grad():
                 b._flat_param.copy_(a._flat_param)               # re-synchronise B: the next iteration starts from identical weights ...
