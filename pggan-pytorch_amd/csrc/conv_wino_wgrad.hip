@@ -53,6 +53,38 @@ constexpr int HW_ = PW + 2, HH_ = PH + 2;      // 18 x 10 input halo pixels
 // LDS pixel stride (floats): the 4 tiles of a k-step (2 px apart) land 16 banks apart -- 40 for 32 channels, 24 for 16
 constexpr int stride_for(int nw) { return nw == 2 ? 40 : 24; }
 
+// The two operand transforms of a k-step, with the signs arranged so that neither needs a negation: Z' = S Z S and V' = S V S for
+// S = diag(1, 1, 1, -1) have the same element-wise product as Z = A dY A^T and V = B^T d B, Z' is sums and differences of the four
+// gz values only, and V' absorbs the signs by swapping the operands of the row-3 / column-3 subtractions.  (The ISA of the first
+// form had 8 v_xor sign flips per 32 MFMAs; VALU cycles and MFMA cycles of co-resident waves add on gfx950,
+// profiles/r04_mfma_valu_share.txt.)  12 VALU for Z', 32 for V'.
+__device__ __forceinline__ void wino_zprime(const float* gp, int stride, int row, float (&z)[16])
+{
+    const float y00 = gp[0], y01 = gp[stride], y10 = gp[row], y11 = gp[row + stride];
+    const float c1a = y00 + y10, c1b = y01 + y11, c2a = y00 - y10, c2b = y01 - y11;
+    z[0] = y00; z[1] = y00 + y01; z[2] = y00 - y01; z[3] = y01;
+    z[4] = c1a; z[5] = c1a + c1b; z[6] = c1a - c1b; z[7] = c1b;            // z[5] = y00 + y01 + y10 + y11: the tile's bias sum
+    z[8] = c2a; z[9] = c2a + c2b; z[10] = c2a - c2b; z[11] = c2b;
+    z[12] = y10; z[13] = y10 + y11; z[14] = y10 - y11; z[15] = y11;
+}
+__device__ __forceinline__ void wino_vprime(const float* xp, int stride, int row, float (&d)[4][4])
+{
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[a][c] = xp[a * row + c * stride];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[3][c] - d[1][c];
+        d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float t0 = d[a][0] - d[a][2], t1 = d[a][1] + d[a][2], t2 = d[a][2] - d[a][1], t3 = d[a][3] - d[a][1];
+        d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
+    }
+}
+
 template <int NCO, int NCI>
 __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
 {
@@ -62,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     __shared__ __align__(16) float smem[PH * PW * SZ + HH_ * HW_ * SX];
     float* gzt = smem;                                     // [128 px][16*NCO co]
     float* xt = smem + PH * PW * SZ;                       // [180 px][16*NCI ci]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kk = lane >> 4;
     const int wave_co = wave % NCO, wave_ci = (wave / NCO) % NCI, wk = wave / (NCO * NCI);
     const int co0 = blockIdx.y * (16 * NCO), ci0 = blockIdx.z * (16 * NCI);
@@ -141,41 +173,18 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
         if (region + 1 < r_end) fetch(region + 1);
         const bool bias_here = (p.db_batches >> (region >= p.nregions1 ? 1 : 0)) & 1;      // (workgroup-uniform)
         PG_RSTAMP(3);
-        // 32 tiles = 8 k-steps of 4 tiles; lane (li, kk): tile 4*step + kk, A channel co = wave_co*16 + li, B channel ci = wave_ci*16 + li
-#pragma unroll 2
-        for (int step = wk; step < 8; step += KSPL) {
-            const int t = 4 * step + kk;
-            const int ttx = t & (RTW - 1), tty = t >> 3;
-            const float* gp = gzt + ((2 * tty) * PW + 2 * ttx) * SZ + wave_co * 16 + li;
-            const float y00 = gp[0], y01 = gp[SZ], y10 = gp[PW * SZ], y11 = gp[(PW + 1) * SZ];
-            if (bias_here) bsum += (y00 + y01) + (y10 + y11);
-            // Z = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
-            const float c0a = y00, c0b = y01;                 // rows of (A dY): r0 = y0., r1 = y0. + y1., r2 = y0. - y1., r3 = -y1.
-            const float c1a = y00 + y10, c1b = y01 + y11;
-            const float c2a = y00 - y10, c2b = y01 - y11;
-            const float c3a = -y10, c3b = -y11;
-            float z[16];
-            z[0] = c0a; z[1] = c0a + c0b; z[2] = c0a - c0b; z[3] = -c0b;
-            z[4] = c1a; z[5] = c1a + c1b; z[6] = c1a - c1b; z[7] = -c1b;
-            z[8] = c2a; z[9] = c2a + c2b; z[10] = c2a - c2b; z[11] = -c2b;
-            z[12] = c3a; z[13] = c3a + c3b; z[14] = c3a - c3b; z[15] = -c3b;
-            // V = B^T d B from the 4x4 patch of x
-            const float* xp = xt + ((2 * tty) * HW_ + 2 * ttx) * SX + wave_ci * 16 + li;
-            float d[4][4];
+        // 32 tiles = 8 k-steps of 4 tiles; lane (li, kk): tile 4*step + kk, A channel co = wave_co*16 + li, B channel ci = wave_ci*16 + li.
+        // step = wk + KSPL s (wave-uniform, unrolled): tile row step >> 1, tile column 4 (step & 1) + kk -- one base per lane + immediates
+        const float* gq = gzt + (2 * kk) * SZ + wave_co * 16 + li;
+        const float* xq = xt + (2 * kk) * SX + wave_ci * 16 + li;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[a][c] = xp[(a * HW_ + c) * SX];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
-                d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const float t0 = d[a][0] - d[a][2], t1 = d[a][1] + d[a][2], t2 = d[a][2] - d[a][1], t3 = d[a][1] - d[a][3];
-                d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
-            }
+        for (int s_ = 0; s_ < 8 / KSPL; ++s_) {
+            const int step = wk + KSPL * s_;
+            const int tty = step >> 1, tx0 = 4 * (step & 1);
+            float z[16], d[4][4];
+            wino_zprime(gq + ((2 * tty) * PW + 2 * tx0) * SZ, SZ, PW * SZ, z);
+            if (bias_here) bsum += z[5];
+            wino_vprime(xq + ((2 * tty) * HW_ + 2 * tx0) * SX, SX, HW_ * SX, d);
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) acc[xi] = MFMA16(z[xi], d[xi >> 2][xi & 3], acc[xi]);
         }
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
     __shared__ __align__(16) float smem[PH * PW * SZ + HH_ * HW_ * SX];
     float* gzt = smem;                                     // [128 px][32 co]
     float* xt = smem + PH * PW * SZ;                       // [180 px][32 ci]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kk = lane >> 4;
     const int wave_ci = wave & 1, wk = wave >> 1;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
@@ -337,41 +346,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
         __syncthreads();
         if (region + 1 < r_end) fetch(region + 1);
         const bool bias_here = (p.db_batches >> (region >= p.nregions1 ? 1 : 0)) & 1;
-#pragma unroll 2
-        for (int step = wk; step < 8; step += 2) {
-            const int t = 4 * step + kk;
-            const int ttx = t & (RTW - 1), tty = t >> 3;
-            // V = B^T d B from the 4x4 x patch (B operand, shared by both cout halves)
-            const float* xp = xt + ((2 * tty) * HW_ + 2 * ttx) * SX + wave_ci * 16 + li;
+        // step = wk + 2 s (wave-uniform, unrolled): tile row s, tile column 4 wk + kk -- one base per lane + immediates
+        const float* gq = gzt + (2 * (4 * wk + kk)) * SZ + li;
+        const float* xq = xt + (2 * (4 * wk + kk)) * SX + wave_ci * 16 + li;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
             float d[4][4];
+            wino_vprime(xq + (2 * s_) * HW_ * SX, SX, HW_ * SX, d);          // B operand, shared by both cout halves
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[a][c] = xp[(a * HW_ + c) * SX];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c], t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
-                d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const float t0 = d[a][0] - d[a][2], t1 = d[a][1] + d[a][2], t2 = d[a][2] - d[a][1], t3 = d[a][1] - d[a][3];
-                d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {                    // Z = A dY A^T of cout half h (A operand)
-                const float* gp = gzt + ((2 * tty) * PW + 2 * ttx) * SZ + h * 16 + li;
-                const float y00 = gp[0], y01 = gp[SZ], y10 = gp[PW * SZ], y11 = gp[(PW + 1) * SZ];
-                if (bias_here) bsum[h] += (y00 + y01) + (y10 + y11);
-                const float c0a = y00, c0b = y01;
-                const float c1a = y00 + y10, c1b = y01 + y11;
-                const float c2a = y00 - y10, c2b = y01 - y11;
-                const float c3a = -y10, c3b = -y11;
+            for (int h = 0; h < 2; ++h) {
                 float z[16];
-                z[0] = c0a; z[1] = c0a + c0b; z[2] = c0a - c0b; z[3] = -c0b;
-                z[4] = c1a; z[5] = c1a + c1b; z[6] = c1a - c1b; z[7] = -c1b;
-                z[8] = c2a; z[9] = c2a + c2b; z[10] = c2a - c2b; z[11] = -c2b;
-                z[12] = c3a; z[13] = c3a + c3b; z[14] = c3a - c3b; z[15] = -c3b;
+                wino_zprime(gq + (2 * s_) * PW * SZ + h * 16, SZ, PW * SZ, z);
+                if (bias_here) bsum[h] += z[5];
 #pragma unroll
                 for (int xi = 0; xi < 16; ++xi) acc[h][xi] = MFMA16(z[xi], d[xi >> 2][xi & 3], acc[h][xi]);
             }

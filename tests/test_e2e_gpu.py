@@ -665,17 +665,16 @@ def test_config2_grow_run_against_oracle(oracle):
     fade-ins at minibatch 64, through Trainer + DepthManager + LRScheduler + FusedAdam, against the oracle's
     ``train_iteration`` driven by the oracle's own schedule (lod spans shortened to 2 iterations so that every stage and
     every fade occurs: 14 iterations, 192 stacked images per D pass)."""
-    N, LOD, ITERS, RAMP = 64, 128, 14, 0.256
-    torch.manual_seed(77)
-    shape = (1, 3, 32, 32)
-    G, D = pg.Generator(shape), pg.Discriminator(shape)
-    gp, dp = G.reference_state_dict(), D.reference_state_dict()
+    import _config2_oracle as c2
+    N, LOD, ITERS, RAMP = c2.N, c2.LOD, c2.ITERS, c2.RAMP
+    shape = c2.SHAPE
+    G, D = c2.initial_nets()
     G.to(DEV)
     D.to(DEV)
     cfg = oracle.NetCfg(32, 3)
     sched = [oracle.depth_schedule(it * N, 3, LOD, LOD, minibatch_default=N) for it in range(ITERS)]
     assert sorted(set(d for d, _, _, _ in sched)) == [0, 1, 2, 3] and sum(1 for _, a, _, _ in sched if a < 1.0) == 6
-    batches = [oracle.synthetic_batch(300 + it, N, 3, 4 * 2 ** sched[it][0], 512) for it in range(ITERS)]
+    batches = [c2.batch(oracle, sched, it) for it in range(ITERS)]
     state = dict(it=0, z=0)
 
     class Data(object):
@@ -720,7 +719,6 @@ def test_config2_grow_run_against_oracle(oracle):
     tr.register_plugin(Rec())
     for q in tr.plugin_queues.values():
         heapq.heapify(q)
-    og, od = oracle.AdamState(), oracle.AdamState()
     # PRE-ADAM gradients, iteration by iteration, against the oracle evaluated on the HIP run's OWN weights of that iteration (what the
     # round-3 review asked for instead of end-state bounds that have to absorb 14 sign-like Adam steps): one iteration of every stage
     # and fade up to 16x16.  The D weights the G step sees are snapshotted when the G loss is entered (after D's deferred update).
@@ -753,15 +751,17 @@ def test_config2_grow_run_against_oracle(oracle):
             _check_grads_loose(reference_grads(D), rd['grads'], 'config 2 it %d (depth %d alpha %.2f) D step' % (it, depth, alpha))
             rg = oracle.g_loss_and_grads(gp_h, snap['dp_after'], cfg, z_g, depth, alpha)
             _check_grads_loose(reference_grads(G), rg['grads'], 'config 2 it %d (depth %d alpha %.2f) G step' % (it, depth, alpha))
-        real, z_d, z_g, mix = batches[it]
-        lr = 0.001 * oracle.rampup(it * N, RAMP)
-        d, g = oracle.train_iteration(gp, dp, cfg, og, od, real, z_d, z_g, mix, depth, alpha, lr, lr)
+    # the oracle's own 14-iteration trajectory (tests/_config2_oracle.py: started in the background when the session began)
+    ref = c2.result()
+    gp, dp = ref['gp'], ref['dp']
+    for it in range(ITERS):
         gc, dc = losses[it]
+        d_cost, g_cost = ref['losses'][it]
         # later iterations inherit sign-like Adam(beta1=0) steps on round-off-sized gradients and single LeakyReLU branch flips
         # (tests/test_fp64_adjudicator.py): the two training trajectories drift apart like any two fp32 runs of a GAN
         tol = 5e-4 if it == 0 else (3e-3 if it <= 3 else 1.5e-2)
-        assert abs(dc - float(d['D_cost'])) < tol * max(1.0, abs(float(d['D_cost']))), (it, dc, float(d['D_cost']))
-        assert abs(gc - float(g['G_cost'])) < tol * max(1.0, abs(float(g['G_cost']))), (it, gc, float(g['G_cost']))
+        assert abs(dc - d_cost) < tol * max(1.0, abs(d_cost)), (it, dc, d_cost)
+        assert abs(gc - g_cost) < tol * max(1.0, abs(g_cost)), (it, gc, g_cost)
     # end state: a DRIFT GUARD only (two fp32 GAN trajectories; the per-iteration gradient checks above are the parity claim)
     for name, ref, net in (('G', gp, G), ('D', dp, D)):
         mine = net.reference_state_dict()

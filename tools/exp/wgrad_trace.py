@@ -33,7 +33,7 @@ torch.cuda.synchronize()
 setter(None)
 t = tr.cpu().numpy().reshape(1024, 4, 8, 8).astype(np.float64)
 ok = t[:, :, 0, 0] > 0
-names = ['lds store (waits for the prefetch)', 'barrier', 'fetch issue', 'fragment reads + transforms + mfma' if wino else 'fragment reads + mfma', 'barrier']
+names = ['lds store (waits for the prefetch) | dma kernel: vmcnt wait', 'barrier', 'fetch issue', 'fragment reads + transforms + mfma' if wino else 'fragment reads + mfma', 'barrier']
 for c in range(8):
     seg = [(t[:, :, c, i + 1] - t[:, :, c, i])[ok].mean() for i in range(5)]
     nxt = (t[:, :, c + 1, 0] - t[:, :, c, 5])[ok].mean() if c < 7 else float('nan')
