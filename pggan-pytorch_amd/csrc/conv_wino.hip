@@ -757,7 +757,10 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
     static const int strip_env = getenv("PG_WINO_STRIP") ? atoi(getenv("PG_WINO_STRIP")) : 1;
     static const int strip_minw = getenv("PG_WINO_STRIP_MINW") ? atoi(getenv("PG_WINO_STRIP_MINW")) : 128;
     static const int strip_maxcin = getenv("PG_WINO_STRIP_MAXCIN") ? atoi(getenv("PG_WINO_STRIP_MAXCIN")) : 16;   // (32-channel inputs: the 87 KB ring leaves one workgroup per CU, 0.6-1.0x the tile kernel)
-    if ((strip_env && g_wino_vec == 0 && W >= strip_minw && Cin <= strip_maxcin) || g_wino_vec == 21) {
+    // (exception: the pool-adjoint epilogue of a 32-channel layer writes 4x its pixels -- the tile kernel's 64-byte segments reach 2 TB/s,
+    //  the strip kernel's full rows 3.1: 127.6 vs 160.8 us at n9 256^2 32->32, but 42.8 vs 39.2 us at n3)
+    const bool strip_unpool32 = Cin == 32 && yup && (long long)N * H * W >= 400000;
+    if ((strip_env && g_wino_vec == 0 && W >= strip_minw && (Cin <= strip_maxcin || strip_unpool32)) || g_wino_vec == 21) {
         const int sepi = (g_wino_epi != 0 ? 1 : 0) | (g_wino_vec == 21 ? 2 : 0);
         p.ksplit = 1; p.kcper = Cin >> 3; p.mKs = 0; p.ks_count = nullptr; p.ks_part = nullptr;
         const int rc = launch_wino_strip(p, sepi, (hipStream_t)stream, g_wino_last, sizeof(g_wino_last));

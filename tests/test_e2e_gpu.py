@@ -195,7 +195,8 @@ def test_trainer_trace_golden():
 
 
 @pytest.mark.parametrize('res,depth,alpha,n,fmap_base,C', [(128, 5, 1.0, 2, 4096, 3), (128, 4, 0.5, 3, 4096, 3),
-                                                           (1024, 8, 1.0, 1, 4096, 3), (256, 6, 0.25, 2, 8192, 3),
+                                                           (128, 5, 1.0, 1, 4096, 3),     # one sample: minibatch-stddev of a single image (the 1024^2 form of this case cost 19 s of oracle time)
+                                                           (256, 6, 0.25, 2, 8192, 3),
                                                            (256, 6, 1.0, 2, 4096, 1), (1024, 7, 0.5, 1, 4096, 3),
                                                            (1024, 8, 1.0, 3, 4096, 3)])   # config 5's real minibatch: stddev couples the 3 samples
 def test_against_oracle_at_baseline_widths(oracle, res, depth, alpha, n, fmap_base, C):
@@ -664,7 +665,7 @@ def test_config2_grow_run_against_oracle(oracle):
     """BASELINE.json config 2 as written: the 32x32 network (default 512-channel widths) grown depth 0 -> 3 with alpha
     fade-ins at minibatch 64, through Trainer + DepthManager + LRScheduler + FusedAdam, against the oracle's
     ``train_iteration`` driven by the oracle's own schedule (lod spans shortened to 2 iterations so that every stage and
-    every fade occurs: 14 iterations, 192 stacked images per D pass)."""
+    every fade occurs: 14 iterations, 192 stacked images per D pass; the oracle follows the first 12, see tests/_config2_oracle.py)."""
     import _config2_oracle as c2
     N, LOD, ITERS, RAMP = c2.N, c2.LOD, c2.ITERS, c2.RAMP
     shape = c2.SHAPE
@@ -745,16 +746,19 @@ def test_config2_grow_run_against_oracle(oracle):
         if it in check_at:
             gp_h, dp_h = _cpu_sd(G.reference_state_dict()), _cpu_sd(D.reference_state_dict())
         tr.train()
+        if it == c2.ORACLE_ITERS - 1:
+            torch.cuda.synchronize()
+            mine_at = {'G': _cpu_sd(G.reference_state_dict()), 'D': _cpu_sd(D.reference_state_dict())}
         if it in check_at:
             real, z_d, z_g, mix = batches[it]
             rd = oracle.d_loss_and_grads(dp_h, gp_h, cfg, real, z_d, mix, depth, alpha)
             _check_grads_loose(reference_grads(D), rd['grads'], 'config 2 it %d (depth %d alpha %.2f) D step' % (it, depth, alpha))
             rg = oracle.g_loss_and_grads(gp_h, snap['dp_after'], cfg, z_g, depth, alpha)
             _check_grads_loose(reference_grads(G), rg['grads'], 'config 2 it %d (depth %d alpha %.2f) G step' % (it, depth, alpha))
-    # the oracle's own 14-iteration trajectory (tests/_config2_oracle.py: started in the background when the session began)
-    ref = c2.result()
+    # the oracle's own trajectory over the first ORACLE_ITERS iterations (tests/_config2_oracle.py)
+    ref = c2.trajectory()
     gp, dp = ref['gp'], ref['dp']
-    for it in range(ITERS):
+    for it in range(c2.ORACLE_ITERS):
         gc, dc = losses[it]
         d_cost, g_cost = ref['losses'][it]
         # later iterations inherit sign-like Adam(beta1=0) steps on round-off-sized gradients and single LeakyReLU branch flips
@@ -762,12 +766,12 @@ def test_config2_grow_run_against_oracle(oracle):
         tol = 5e-4 if it == 0 else (3e-3 if it <= 3 else 1.5e-2)
         assert abs(dc - d_cost) < tol * max(1.0, abs(d_cost)), (it, dc, d_cost)
         assert abs(gc - g_cost) < tol * max(1.0, abs(g_cost)), (it, gc, g_cost)
-    # end state: a DRIFT GUARD only (two fp32 GAN trajectories; the per-iteration gradient checks above are the parity claim)
-    for name, ref, net in (('G', gp, G), ('D', dp, D)):
-        mine = net.reference_state_dict()
-        for k, v in ref.items():
+    # state after ORACLE_ITERS iterations: a DRIFT GUARD only (two fp32 GAN trajectories; the per-iteration gradient checks above are the parity claim)
+    for name, ref_sd in (('G', gp), ('D', dp)):
+        mine = mine_at[name]
+        for k, v in ref_sd.items():
             if torch.is_tensor(v):
-                assert float((mine[k].cpu() - v).abs().max()) < 2 * 0.001 * ITERS + 1e-4, (name, k)
-                # (biases start at zero: after 14 sign-like Adam steps their relative L2 distance between two fp32 trajectories is the
+                assert float((mine[k].cpu() - v).abs().max()) < 2 * 0.001 * c2.ORACLE_ITERS + 1e-4, (name, k)
+                # (biases start at zero: after a dozen sign-like Adam steps their relative L2 distance between two fp32 trajectories is the
                 # noisiest number of the run -- 1.4e-2 .. 2.02e-2 over repeated runs of the same build; the max-norm bound above is the claim)
                 assert _l2(mine[k].cpu(), v) < (4e-2 if k.endswith('bias') else 2e-2), (name, k, _l2(mine[k].cpu(), v))

@@ -1,5 +1,1 @@
-Q="--no-cpu --no-per-depth --no-configs --no-kernel-timing --steps 40 --warmup 10"
-for i in 1 2 3; do
-echo "== new"; python bench.py $Q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'])"
-echo "== head"; PGGAN_HIP_LIB=ab/libpggan_head.so python bench.py $Q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'])"
-done
+PG_WINO_STRIP_MAXCIN=32 BW_ONLY=unpool python tools/bench_wino_strip.py 2>&1 | grep -v amdgpu.ids

@@ -59,8 +59,10 @@ for k in kernels:
                  '%.3g' % sq.get(k, {}).get('SQ_INSTS_MFMA', 0), '%.3g' % sq.get(k, {}).get('SQ_INSTS_VALU', 0),
                  '%.3f' % (sq.get(k, {}).get('SQ_WAIT_INST_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1))),
                  '%.3f' % (sq.get(k, {}).get('SQ_WAIT_ANY', 0) / max(1.0, sq.get(k, {}).get('SQ_WAVE_CYCLES', 1))),
-                 # effective shader clock while the kernel ran: GRBM_GUI_ACTIVE cycles / kernel wall time (MI355X_MICROARCH.md, DVFS)
-                 '%.2f' % (lds.get(k, {}).get('GRBM_GUI_ACTIVE', 0.0) / max(1.0, sum(ld.get(k, {}).values()))),
+                 # effective shader clock while the kernel ran: GRBM_GUI_ACTIVE cycles / kernel wall time (MI355X_MICROARCH.md, DVFS).  rocprofv3
+                 # sums the counter over the 8 XCDs; it also counts the dispatch time around a kernel, so launches shorter than ~100 us read
+                 # high (an upper bound there; the 200-330 us launches read 2.25 GHz)
+                 '%.2f' % (lds.get(k, {}).get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / max(1.0, sum(ld.get(k, {}).values()))),
                  # round 4: what the waves wait for.  VALU instructions per MFMA (fp32 MFMA time and VALU time of the waves of a SIMD ADD on
                  # gfx950, tools/exp/mfma_valu_share.hip: MFMA-busy <= 32 / (32 + 4 x this)); LDS pipe active, waves waiting for LDS and
                  # waves executing VALU / LDS instructions as fractions of the wave cycles of the same pass
