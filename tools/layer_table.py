@@ -25,6 +25,7 @@ def record_step():
     import bench
     import pggan_amd as pg
     ops = pg.ops
+    pg.wgan_gp_loss.enable_graphs(False)                        # eager launches: a replayed launch plan does not pass through ops.*
     tr = bench.make_trainer(pg, 1024, 8, 1.0, 3, 1337, None)
     for _ in range(3):
         tr.train()
