@@ -459,13 +459,15 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
 #endif
     const int nco = Cout <= 16 ? 1 : 2, nci = Cin <= 16 ? 1 : 2;
     const int gy = (Cout + 16 * nco - 1) / (16 * nco), gz_ = (Cin + 16 * nci - 1) / (16 * nci);
-    // ~512 workgroups: best of a 256/384/512/1024 sweep (tools/sweep_wino_wgrad.py); more workgroups pay for
+    // ~384-512 workgroups: best of a 256/384/512/1024 sweep (tools/sweep_wino_wgrad.py); more workgroups pay for
     // themselves in the per-workgroup G^T M G commit (9216 atomics each), fewer leave CUs idle.  Round 2 measured the commit by
     // leaving it out: 5 % of the launch on n9 @64 128->256 (141 -> 134 us) but 35 % on n3 @128 64->64 (39 -> 25 us), where 128
     // workgroups add to the same 36 K addresses; the phase trace (tools/exp/wgrad_trace.py ... wino) puts a region at 14.1 k
     // cycles, 11.7 k of them the 8 k-steps (20 ds_read_b32 + ~50 VALU + 16 MFMAs each: 1460 cycles per step at two waves per
     // SIMD, 512 of MFMA issue), 2.4 k staging: the kernel is bound by its compute phase and its commit, not by staging.
-    static const int target = [] { const char* t = getenv("PG_WW_TARGET"); return t ? atoi(t) : 512; }();
+    // (round 4, inside the train step where the kernel shares the CUs with the main stream's convs: 384 -> 10.573 / 10.573 ms per step,
+    //  512 -> 10.607 / 10.617, 256 -> 10.662 / 10.649, 768 -> 10.765 / 10.748; alone on the device 512 is 1-2 % faster than 384)
+    static const int target = [] { const char* t = getenv("PG_WW_TARGET"); return t ? atoi(t) : 384; }();
     int chunks = (target + gy * gz_ - 1) / (gy * gz_);
     if (chunks > p.nregions) chunks = p.nregions;
     if (chunks < 1) chunks = 1;

@@ -1,1 +1,6 @@
-PG_WINO_STRIP_MAXCIN=32 BW_ONLY=unpool python tools/bench_wino_strip.py 2>&1 | grep -v amdgpu.ids
+Q="--no-cpu --no-per-depth --no-configs --no-kernel-timing --steps 40 --warmup 10"
+for i in 1 2; do
+for t in 512 384 256 768; do
+echo "== PG_WW_TARGET=$t"; PG_WW_TARGET=$t python bench.py $Q 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'])"
+done
+done
