@@ -678,7 +678,9 @@ int launch_wgrad_strip_t(const WArgs& a, int N, hipStream_t s, char* name, size_
 int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
 {
     static const int seg_env = getenv("PG_STRIP_SEG") ? atoi(getenv("PG_STRIP_SEG")) : 0;
-    static const int wreg_env = getenv("PG_STRIP_WREG") ? atoi(getenv("PG_STRIP_WREG")) : 0;
+    // (8 -> 8 weights in registers: 0.5-3 % slower alone on the device in round 3, but faster INSIDE the two-stream step, where the LDS pipe is
+    //  shared with the weight-gradient kernels -- round 4, same box, three pairs: 10.71 / 10.68 / 10.68 vs 10.81 / 10.82 / 10.72 ms per step)
+    static const int wreg_env = getenv("PG_STRIP_WREG") ? atoi(getenv("PG_STRIP_WREG")) : 1;
     static const int epi_env = getenv("PG_STRIP_EPI") ? atoi(getenv("PG_STRIP_EPI")) : -1;      // 0: always the generic epilogue (A/B)
     if (p.KS != 3 || p.pad != 1 || p.yup || p.ksplit != 1) return PG_E_UNSUP;
     if ((p.Wout % SW) || (p.Hout % 16) || p.Hout != p.Hin || p.Wout != p.Win) return PG_E_UNSUP;
