@@ -305,7 +305,7 @@ def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
 # Weight gradients are leaves of the backward sweeps (nothing downstream reads them before the optimizer), so
 # they are launched on a second HIP stream and overlap the backward-data chain on the main stream: two
 # half-occupancy MFMA kernels share the CUs instead of running back to back.
-ASYNC_WGRAD = True
+ASYNC_WGRAD = _os.environ.get('PGGAN_ASYNC_WGRAD', '1') != '0'
 ASYNC_DERIVED = _os.environ.get('PGGAN_ASYNC_DERIVED', '1') != '0'
 # 0: every live layer gets a flipped / transposed copy and the backward-data Winograd form is derived from that copy (round 2)
 WTU_FROM_PARAM = _os.environ.get('PGGAN_WTU_FROM_PARAM', '1') != '0'
