@@ -98,3 +98,23 @@ for g, a, b in gaps:
     agg[k][1] += 1
 for k, (g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
     print('  %7.1f us per step in %4.1f gaps per step: %s' % (g / 1e3 / nsteps, c / nsteps, k))
+
+# where the MAIN queue waits while another queue works (dependencies on the weight-gradient / update stream): gaps of the main queue
+# that are not idle gaps of the whole device, aggregated by the main-queue kernels on either side
+mainq = max(byq, key=lambda q: len(byq[q]))
+waits = defaultdict(lambda: [0, 0])
+for st in good:
+    mq = sorted((s, e, name) for s, e, q, name in st if q == mainq)
+    others = sorted((s, e) for s, e, q, _ in st if q != mainq)
+    for (s0, e0, n0), (s1, e1, n1) in zip(mq, mq[1:]):
+        if s1 - e0 < 10000:
+            continue
+        cover = union([(max(s, e0), min(e, s1)) for s, e in others if e > e0 and s < s1])        # part of the gap in which another queue is busy
+        if cover > 5000:
+            w = waits[(n0.split('(')[0][-60:], n1.split('(')[0][-60:])]
+            w[0] += cover
+            w[1] += 1
+tot_wait = sum(w[0] for w in waits.values())
+print('main queue waiting while another queue is busy: %.3f ms per step' % (tot_wait / 1e6 / nsteps))
+for (a, b), (ns, cnt) in sorted(waits.items(), key=lambda kv: -kv[1][0])[:10]:
+    print('    %6.1f us per step in %4.1f gaps per step: %s -> %s' % (ns / 1e3 / nsteps, cnt / nsteps, a, b))
