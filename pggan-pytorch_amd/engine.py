@@ -56,6 +56,7 @@ SIGN_BYTES_MIN_H = int(_os.environ.get('PGGAN_SIGN_BYTES_MIN_H', '64'))
 # With the mask as sign bytes the pool adjoint between two DBlocks can be evaluated in the input gathers of its consumers
 # (backward-data conv and weight gradient of the finer block's c2) instead of being written out at the fine resolution.
 USE_LAZY_UNPOOL = _os.environ.get('PGGAN_LAZY_UNPOOL', '1') != '0'
+USE_LAZY_UNPOOL_FADE = _os.environ.get('PGGAN_LAZY_UNPOOL_FADE', '1') != '0'    # ... also across the fade-in boundary (alpha < 1)
 
 
 def _live_conv_layers(net):
@@ -777,7 +778,15 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             prev = recs[idx - 1]
             pc2 = prev['blk'].c2
             if prev['first'] and alpha < 1.0:
-                g = ops.avgpool2_bwd(gin, _mask32(prev['a2']), alpha, pc2.slope)
+                pc2w = pc2.conv.weight.shape
+                if (USE_LAZY_UNPOOL and USE_LAZY_UNPOOL_FADE and not save_adjoints and prev['a2'].dtype == torch.uint8 and pc2w[3] == 8 and pc2w[2] in (8, 16)
+                        and pc2.ksize == 3 and prev['H'] % 32 == 0):
+                    # fade-in at the 1024^2 stage: the same lazy pool adjoint as in the fully grown stage (x alpha); the entry block's c2
+                    # consumers evaluate it in their gathers instead of reading a 604 MB fine-resolution gradient (round 4)
+                    carry = (gin, prev['a2'], 0.25 * alpha, pc2.slope)
+                    g = None
+                else:
+                    g = ops.avgpool2_bwd(gin, _mask32(prev['a2']), alpha, pc2.slope)
                 pfr = blk.fromRGB                                             # the block whose fromRGB fed the fade-in
                 gpf = ops.axpby_mask(gin, mask=prev['pf'], a=1.0 - alpha, mask_slope=pfr.slope)
                 if save_adjoints:

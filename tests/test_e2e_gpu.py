@@ -198,6 +198,8 @@ def test_trainer_trace_golden():
                                                            (128, 5, 1.0, 1, 4096, 3),     # one sample: minibatch-stddev of a single image (the 1024^2 form of this case cost 19 s of oracle time)
                                                            (256, 6, 0.25, 2, 8192, 3),
                                                            (256, 6, 1.0, 2, 4096, 1), (1024, 7, 0.5, 1, 4096, 3),
+                                                           (1024, 8, 0.5, 1, 4096, 3),    # fade-in of the 1024^2 stage: the lazy pool adjoint across the fade boundary
+
                                                            (1024, 8, 1.0, 3, 4096, 3)])   # config 5's real minibatch: stddev couples the 3 samples
 def test_against_oracle_at_baseline_widths(oracle, res, depth, alpha, n, fmap_base, C):
     """HIP vs CPU oracle on seeded inputs at BASELINE.json widths (default 4096 and the paper's 8192), incl. the
