@@ -6,8 +6,6 @@ from PyTorch after 0.3, so the minimal ``Plugin`` protocol is restated here: an 
 (``iteration`` / ``epoch`` / ``s`` / ``end``) — exactly what ``Trainer.call_plugins`` relies on.
 All schedule arithmetic is Python int (+ one IEEE double division for alpha): bit-exact by construction."""
 import os
-import time
-from datetime import timedelta
 from glob import glob
 
 
@@ -143,34 +141,6 @@ class RampupLR(object):
     def step(self, cur_nimg):
         for g, base in zip(self.optimizer.param_groups, self.base_lrs):
             g['lr'] = base * self.fn(cur_nimg)
-
-
-class ThroughputMonitor(Plugin):
-    """Adds ``img/s`` per tick next to the reference's ``sec.tick`` / ``sec.kimg`` (plugins.py:114-139)."""
-
-    def __init__(self, base_time=0):
-        super(ThroughputMonitor, self).__init__([(1, 'epoch')])
-        self.base_time = base_time
-
-    def register(self, trainer):
-        self.trainer = trainer
-        self.start_time = self.epoch_start = time.time()
-        self.start_nimg = trainer.cur_nimg
-        self.trainer.stats['sec'] = {'log_format': ':.1f'}
-
-    def epoch(self, epoch_index):
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        cur = time.time()
-        tick_time = cur - self.epoch_start
-        self.epoch_start = cur
-        nimg = max(1, self.trainer.cur_nimg - self.start_nimg)
-        self.start_nimg = self.trainer.cur_nimg
-        self.trainer.stats['time'] = timedelta(seconds=cur - self.start_time + self.base_time)
-        self.trainer.stats['sec']['tick'] = tick_time
-        self.trainer.stats['sec']['kimg'] = tick_time / nimg * 1000
-        self.trainer.stats['img/s'] = nimg / tick_time
 
 
 class SaverPlugin(Plugin):
