@@ -24,6 +24,9 @@ ksum = sum(float(cells(r)[2]) for r in rows)
 cb, cfg, r = d['cpu_baseline']['per_depth'], d['configs'], d['roofline']
 c2, fa, f8, c3, c4 = cfg['config2'], cfg['depth8_alpha0.5'], cfg['depth8_fmap8192'], cfg['config3'], cfg['config4']
 w = d['d_step_gp_counters']
+import csv
+pm = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r04_pmc_summary.csv'))))
+hbm_gb = sum(int(q['calls']) * (float(q['hbm_fetch_bytes_per_launch(x2 corrected)']) + float(q['hbm_write_bytes_per_launch'])) for q in pm) / 3 / 1e9   # 3 steps in the PMC passes
 new = f"""Round-4 numbers (1×MI355X, fp32, default `python bench.py`, `profiles/r04_*`; round 3 in brackets; these are DRIVER-CLASS runs: a fresh
 box of the pool, the default command, nothing selected — such runs of the round-4 code measured 10.50–10.85 ms per step
 (276.5–285.7 img/s: the boxes of the pool differ by ±2 %); the tables below are the run of the final code):
@@ -38,7 +41,8 @@ CPU oracle on the box's host cores (32 threads), img/s at depth 0‥8: {' / '.jo
 `roofline` = `{r['kernel']}` (the tile kernel with the general epilogue, {r['launches_per_step']:.0f} launches per step): {r['avg_launch_us']:.1f} µs by HIP events inside
 the two-stream step (62.4 µs alone in the PMC pass), `frac` {r['frac']:.2f} executed ({r['algorithmic_frac']:.2f} algorithmic), {r['mfma_busy_pct']:.1f} % MFMA-busy at {r['valu_per_mfma']:.1f} VALU instructions per
 MFMA, {r['traffic'] / 1e6:.0f} MB of HBM traffic per launch.  Traced (`r04_stream_overlap.txt`, launch plans on): the main queue is busy 94.7 % of the step, some queue 97.1 %,
-the main queue waits for the other one 0.05 ms per step; the iteration-boundary gap of rounds 1–3 (0.5 ms under the tracer) is gone.
+the main queue waits for the other one 0.05 ms per step; the iteration-boundary gap of rounds 1–3 (0.5 ms under the tracer) is gone.  Σ HBM traffic of a step
+(`r04_pmc_summary.csv`, calls × (FETCH + WRITE)): {hbm_gb:.1f} GB (29.5 in round 3: the RGB-side tensors are still materialised, §8).
 
 {pd}
 
