@@ -667,7 +667,7 @@ def test_config2_grow_run_against_oracle(oracle):
     """BASELINE.json config 2 as written: the 32x32 network (default 512-channel widths) grown depth 0 -> 3 with alpha
     fade-ins at minibatch 64, through Trainer + DepthManager + LRScheduler + FusedAdam, against the oracle's
     ``train_iteration`` driven by the oracle's own schedule (lod spans shortened to 2 iterations so that every stage and
-    every fade occurs: 14 iterations, 192 stacked images per D pass; the oracle follows the first 12, see tests/_config2_oracle.py)."""
+    every fade occurs: 14 iterations, 192 stacked images per D pass; the oracle follows the first 11, see tests/_config2_oracle.py)."""
     import _config2_oracle as c2
     N, LOD, ITERS, RAMP = c2.N, c2.LOD, c2.ITERS, c2.RAMP
     shape = c2.SHAPE

@@ -425,7 +425,7 @@ def test_engine_with_lazy_pool_adjoint_gpu(monkeypatch, alpha):
     orig = pg.ops.conv2d_unpooled
     monkeypatch.setattr(pg.ops, 'conv2d_unpooled', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
     _engine_vs_oracle('cuda', monkeypatch, 128, 5, alpha, 2, kw=dict(fmap_base=512, fmap_max=64))
-    assert (len(calls) > 0) == (alpha == 1.0)         # with the fade-in active the top boundary keeps the materialised form
+    assert len(calls) > 0                             # ... also across the fade-in boundary (x alpha) since round 4
 
 
 @pytest.mark.gpu
