@@ -465,9 +465,11 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
     // workgroups add to the same 36 K addresses; the phase trace (tools/exp/wgrad_trace.py ... wino) puts a region at 14.1 k
     // cycles, 11.7 k of them the 8 k-steps (20 ds_read_b32 + ~50 VALU + 16 MFMAs each: 1460 cycles per step at two waves per
     // SIMD, 512 of MFMA issue), 2.4 k staging: the kernel is bound by its compute phase and its commit, not by staging.
-    // (round 4, inside the train step where the kernel shares the CUs with the main stream's convs: 384 -> 10.573 / 10.573 ms per step,
-    //  512 -> 10.607 / 10.617, 256 -> 10.662 / 10.649, 768 -> 10.765 / 10.748; alone on the device 512 is 1-2 % faster than 384)
-    static const int target = [] { const char* t = getenv("PG_WW_TARGET"); return t ? atoi(t) : 384; }();
+    // (round 4, inside the train step where the kernel shares the CUs with the main stream's convs; ms per step, 384 | 512: 1024^2 stage (launches
+    //  of 3 + 9 images) 10.573 / 10.573 | 10.607 / 10.617; 512^2 and 256^2 stages equal; 128^2 stage (16 + 48 images) 21.17 / 21.16 | 20.97 / 21.01;
+    //  256 and 768 lose at 1024^2: 10.66 / 10.75.  Alone on the device 512 is 1-2 % faster than 384.)
+    static const int target_env = [] { const char* t = getenv("PG_WW_TARGET"); return t ? atoi(t) : 0; }();
+    const int target = target_env > 0 ? target_env : (N + N2 <= 12 ? 384 : 512);
     int chunks = (target + gy * gz_ - 1) / (gy * gz_);
     if (chunks > p.nregions) chunks = p.nregions;
     if (chunks < 1) chunks = 1;
