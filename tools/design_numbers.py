@@ -40,7 +40,7 @@ every kernel of the window**; weighted with this run's in-step durations {d['d_s
 CPU oracle on the box's host cores (32 threads), img/s at depth 0‥8: {' / '.join(('%.1f' if p['images_per_sec'] >= 1 else '%.2f') % p['images_per_sec'] for p in cb[:8])} / **{cb[8]['images_per_sec']:.2f}**.
 `roofline` = `{r['kernel']}` (the tile kernel with the general epilogue, {r['launches_per_step']:.0f} launches per step): {r['avg_launch_us']:.1f} µs by HIP events inside
 the two-stream step (62.4 µs alone in the PMC pass), `frac` {r['frac']:.2f} executed ({r['algorithmic_frac']:.2f} algorithmic), {r['mfma_busy_pct']:.1f} % MFMA-busy at {r['valu_per_mfma']:.1f} VALU instructions per
-MFMA, {r['traffic'] / 1e6:.0f} MB of HBM traffic per launch.  Traced (`r04_stream_overlap.txt`, launch plans on): the main queue is busy 94.7 % of the step, some queue 97.1 %,
+MFMA, {r['traffic'] / 1e6:.0f} MB of HBM traffic per launch.  Traced (`r04_stream_overlap.txt`, launch plans on): the main queue is busy 94.9 % of the step, some queue 97.2 %,
 the main queue waits for the other one 0.05 ms per step; the iteration-boundary gap of rounds 1–3 (0.5 ms under the tracer) is gone.  Σ HBM traffic of a step
 (`r04_pmc_summary.csv`, calls × (FETCH + WRITE)): {hbm_gb:.1f} GB (29.5 in round 3: the RGB-side tensors are still materialised, §8).
 
