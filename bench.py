@@ -14,11 +14,14 @@ the reference's per-depth minibatch (3 per GPU, plugins.py:20), fp32.  Data-para
 per GPU, minibatch per rank fixed (weak scaling), RCCL sum-all-reduce of each network's flat gradient buffer
 (bucketed, overlapped with the backward sweeps) through the library's C-ABI.  ``--gpus N`` with N > 1 and no
 WORLD_SIZE in the environment launches the N ranks itself (torch.distributed.run) and fails loudly when fewer than N
-devices are visible.  Rank 0 prints ONE JSON line (the last line of stdout).
+devices are visible.  Rank 0 prints ONE JSON line (the last line of stdout), at most 6 KB: the contract keys, ``roofline``,
+``cpu_baseline``, the D+GP window and one row per growth stage.  Every table behind it (per-kernel timings, secondary workloads, CPU
+per-depth numbers, timing windows) is written to ``bench_detail.json`` next to this file (a short digest goes to stderr).
 
-Fractions in the line: ``algorithmic_frac`` = 2*MAC FLOP of the reference's convolutions per second over the nominal
-157.3 TF fp32-MFMA peak (can exceed what the matrix cores execute: Winograd F(2x2,3x3) layers issue 16/36 of it);
-``executed_mfma_frac`` = the same with Winograd launches credited 16/36 (HIP-event timed conv launches only);
+Fractions: ``roofline.frac`` / ``executed_mfma_frac`` / per-depth ``executed_frac`` = MFMA FLOP the HIP-event-timed conv launches
+EXECUTE (Winograd F(2x2,3x3) launches credited 16/36 of the 2*MAC count) / their time / the nominal 157.3 TF fp32-MFMA peak: <= 1 by
+construction.  The algorithmic 2*MAC work of the reference's convolutions is reported as a RATE (``algorithmic_tflops``; it can exceed
+what the matrix cores execute, so it is never called a fraction outside ``roofline.algorithmic_frac`` of the dominant kernel);
 ``mfma_busy_pct`` = time-weighted SQ_VALU_MFMA_BUSY_CYCLES of the conv kernels from the committed PMC pass
 (``mfma_busy_source``).  Setup before the W warmup steps: --prime (default 50) untimed steps (code objects, allocator
 growth, clock ramp), reported as "priming_steps".
@@ -46,7 +49,14 @@ import torch  # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12          # gfx950 f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 REF_MINIBATCH = {6: 14, 7: 6, 8: 3}          # reference plugins.py:19-20 (default 16)
-PROFILE_TAG = 'r04'                           # profiles/<tag>_roofline.json: PMC pass the traffic / MFMA-busy figures come from
+def _latest_profile_tag():
+    """profiles/<tag>_roofline.json of the newest round: the PMC pass the traffic / MFMA-busy figures are quoted from."""
+    import glob
+    tags = sorted(os.path.basename(f)[:-len('_roofline.json')] for f in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_roofline.json')))
+    return tags[-1] if tags else 'none'
+
+
+PROFILE_TAG = _latest_profile_tag()
 
 
 def forward_flops(G, D, depth, alpha):
@@ -376,17 +386,39 @@ def relaunch(n):
     sys.exit(subprocess.call(cmd))
 
 
-def stage_entry(pg, tr, dp, n_gpus, mb, depth, alpha, extra=None):
-    """images/s, ms per step and D+GP ms of one configured trainer (median of 3 timed windows), with the algorithmic
-    fractions of the nominal fp32-MFMA peak."""
+def executed_fraction(pg, tr, steps=2):
+    """MFMA FLOP the conv / weight-gradient launches of ``steps`` eager train steps EXECUTE (Winograd F(2x2,3x3) launches credited
+    16/36 of the algorithmic 2*MAC count) per second of their summed HIP-event time, over the nominal peak: a fraction <= 1 by
+    construction, for every growth stage (the algorithmic rate of a Winograd stage can exceed the peak; it is reported as a rate,
+    never as a fraction)."""
+    mode = pg.wgan_gp_loss._use_graphs
+    pg.wgan_gp_loss._use_graphs = False                # per-launch events need eager launches (the switch itself: recorded plans stay)
+    try:
+        with KernelTimer(pg) as kt:
+            for _ in range(steps):
+                tr.train()
+            fam = kt.summary(steps)
+    finally:
+        pg.wgan_gp_loss._use_graphs = mode
+    tot = sum(v['ms'] for v in fam.values())
+    if not tot:
+        return None, None
+    return (sum(v['exec_flops'] for v in fam.values()) / (tot * 1e-3) / MFMA_F32_PEAK, tot / steps)
+
+
+def stage_entry(pg, tr, dp, n_gpus, mb, depth, alpha, extra=None, executed=True):
+    """images/s, ms per step and D+GP ms of one configured trainer (median of 3 timed windows); the algorithmic work as a RATE
+    (TFLOP/s of the reference's 2*MAC count) and the executed-MFMA fraction of the conv launches."""
     ms, k, all_ms = robust_ms(tr, dp)
     dms, _, _ = robust_ms(tr, dp, fn=d_step_fn(tr), prime=3, window_s=0.25)
     w_d, w = step_flops(tr.G, tr.D, depth, alpha)
     e = {'depth': depth, 'res': 4 * 2 ** depth, 'alpha': alpha, 'minibatch': mb, 'images_per_sec': n_gpus * mb / (ms * 1e-3),
          'ms_per_step': ms, 'ms_windows': all_ms, 'steps_per_window': k, 'd_step_gp_ms': dms,
          'algorithmic_gflop_per_image': w / 1e9,
-         'algorithmic_frac': w * (mb / (ms * 1e-3)) / MFMA_F32_PEAK,
-         'd_step_gp_algorithmic_frac': w_d * (mb / (dms * 1e-3)) / MFMA_F32_PEAK}
+         'algorithmic_tflops_per_gpu': w * (mb / (ms * 1e-3)) / 1e12,
+         'd_step_gp_algorithmic_tflops_per_gpu': w_d * (mb / (dms * 1e-3)) / 1e12}
+    if executed:               # every rank runs the instrumented steps (collectives stay matched); the line quotes rank 0's
+        e['executed_frac'], e['conv_kernel_ms_per_step'] = executed_fraction(pg, tr)
     if extra:
         e.update(extra)
     return e
@@ -458,6 +490,87 @@ def grow_run(pg, dp, n_gpus, rank):
     return {'workload': 'config 2: 32x32 network, grow depth 0->3 with alpha fade-ins, minibatch 64 per GPU, DepthManager + '
                         'LRScheduler, %d iterations' % tr.iterations,
             'images_per_sec': total / dt, 'seconds': dt, 'iterations': tr.iterations, 'stages': stages}
+
+
+LINE_LIMIT = 6000          # bytes: the driver keeps ~8 KB of stdout; a 20.8 KB line (round 4) could not be parsed
+
+
+def _r(v, sig=5):
+    """floats to ``sig`` significant digits (the line is a record, not a checkpoint)."""
+    if isinstance(v, float):
+        return float('%.*g' % (sig, v))
+    return v
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def write_detail(out):
+    """Everything measured goes to ``bench_detail.json`` (next to bench.py, and under gpurun_out/ when that exists), a digest to stderr;
+    stdout carries only the compact line."""
+    text = json.dumps(out, indent=1, sort_keys=True)
+    first = None
+    for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, 'bench_detail.json'), 'w') as f:
+                    f.write(text)
+                first = first or os.path.relpath(os.path.join(d, 'bench_detail.json'), ROOT)
+            except OSError:
+                pass
+    # stderr: a short human-readable digest (never a JSON object: nothing but the stdout line may look like the record)
+    w = sys.stderr.write
+    w('[bench] detail file: %s (%d bytes)\n' % (first, len(text)))
+    for e in out.get('per_depth') or []:
+        w('[bench] depth %d (%4dx%-4d mb %2d): %9.1f img/s  %8.3f ms/step  D+GP %8.3f ms  executed MFMA frac %s\n' % (
+            e['depth'], e['res'], e['res'], e['minibatch'], e['images_per_sec'], e['ms_per_step'], e['d_step_gp_ms'],
+            '%.3f' % e['executed_frac'] if e.get('executed_frac') is not None else 'n/a'))
+    for k, v in sorted((out.get('kernels') or {}).items(), key=lambda kv: -kv[1]['ms_per_step'])[:12]:
+        w('[bench] %-58s %6.3f ms/step %5.1f launches %7.1f us  %6.1f TF executed\n' % (k, v['ms_per_step'], v['launches_per_step'], v['avg_launch_us'], v['executed_tflops']))
+    sys.stderr.flush()
+    return first
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line of the contract, <= LINE_LIMIT bytes: contract keys, ``roofline`` of the dominant kernel, ``cpu_baseline``,
+    the D+GP window and a [depth, img/s, ms, D+GP ms] row per growth stage.  Tables (per-kernel, secondary workloads, CPU per depth,
+    timing windows) live in the detail file."""
+    line = {k: _r(out[k]) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'priming_steps', 'ms_per_step',
+                                    'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data') if k in out}
+    line['config'] = {k: _r(v) for k, v in out.get('config', {}).items()}
+    roof = out.get('roofline')
+    if roof:
+        line['roofline'] = _pick(roof, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'algorithmic_frac'))
+        line['roofline']['traffic'] = _r(roof.get('traffic'))                        # (null = no PMC pass to quote)
+        line['roofline'].update(_pick(roof, ('traffic_source', 'mfma_busy_pct', 'valu_per_mfma', 'avg_launch_us', 'launches_per_step',
+                                             'ms_per_step_in_kernel')))
+    cpu = out.get('cpu_baseline')
+    line['cpu_baseline'] = _pick(cpu, ('value', 'unit', 'cores', 'kind', 'sample', 'measured_at_n_gpus')) if cpu else None
+    dwin = out.get('d_step_gp_counters') or {}
+    d = {'ms': _r(out.get('d_step_gp_ms')), 'executed_frac': _r(out.get('d_step_gp_executed_mfma_frac')),
+         'mfma_busy_pct_conv': _r(dwin.get('mfma_busy_pct_conv_kernels', out.get('d_step_gp_mfma_busy_pct'))),
+         'mfma_busy_pct_all': _r(dwin.get('mfma_busy_pct_all_kernels')), 'counter_source': dwin.get('source_short')}
+    line['d_step_gp'] = {k: v for k, v in d.items() if v is not None}
+    line.update(_pick(out, ('executed_mfma_frac', 'mfma_busy_pct', 'step_issue', 'rccl_ranks', 'allreduce_ms', 'allreduce_bytes_per_step',
+                            'exposed_exchange_ms', 'ms_per_step_without_exchange')))
+    if out.get('per_depth'):
+        line['per_depth_cols'] = ['depth', 'images_per_sec', 'ms_per_step', 'd_step_gp_ms', 'executed_frac']
+        line['per_depth'] = [[e['depth'], _r(e['images_per_sec'], 4), _r(e['ms_per_step'], 4), _r(e['d_step_gp_ms'], 4),
+                              _r(e.get('executed_frac'), 3)] for e in out['per_depth']]
+    if out.get('configs'):
+        line['configs'] = {k: [_r(v['images_per_sec'], 4), _r(v.get('ms_per_step', 1e3 * v.get('seconds', 0.0)), 4)] for k, v in out['configs'].items()}
+    if detail_path:
+        line['detail'] = detail_path
+    text = json.dumps(line, separators=(',', ':'))
+    for drop in ('configs', 'per_depth', 'per_depth_cols'):      # never exceed the limit: shed the optional tables first
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(',', ':'))
+    if len(text) > LINE_LIMIT:
+        raise RuntimeError('bench.py: compact JSON line is %d bytes (limit %d)' % (len(text), LINE_LIMIT))
+    return text
 
 
 def main():
@@ -536,6 +649,7 @@ def main():
     dt = timed_steps(tr, args.steps, args.warmup, dp, fn=d_step_fn(tr) if args.d_step_only else None)
     ms_per_step = 1e3 * dt / args.steps
     host_ms, host_free_ms = HOST_ENQUEUE['ms'], HOST_ENQUEUE['free_ms']
+    d_gp_ms = robust_ms(tr, dp, fn=d_step_fn(tr), prime=3, window_s=0.25)[0]      # D step + gradient penalty + Adam(D) of the headline stage
     value = n_gpus * mb * args.steps / dt
     w_d, w = step_flops(tr.G, tr.D, depth, args.alpha)
 
@@ -544,18 +658,19 @@ def main():
                    'images/sec, PGGAN full train step (D+GP step + G step + Adam) at %dx%d') % (res, res),
         'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'priming_steps': args.prime,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic (seeded uniform [-1,1) images / normal latents, pre-generated ring of 8 device batches)',
-        'config': {'workload': 'BASELINE config %d: PGGAN %dx%d network (fmap_base=%d, C=%d, latent %d) growth stage depth %d = %dx%d, '
-                               'alpha %.2f, minibatch %d per GPU%s, Trainer.train() with WGAN-GP (lambda 10) and Adam(0,0.99), fp32'
+        'dtype': 'f32', 'data': 'synthetic (seeded uniform images / normal latents, ring of 8 device-resident batches)',
+        'config': {'workload': 'BASELINE config %d: PGGAN %dx%d net (fmap_base %d, C=%d, latent %d), stage depth %d = %dx%d, '
+                               'alpha %.2f, minibatch %d/GPU%s, Trainer.train(): WGAN-GP + Adam(0,0.99), fp32'
                                % (args.config, net_res, net_res, args.fmap_base, c['ch'], tr.G.latent_size, depth, res, res, args.alpha, mb,
-                                  ' (reference per-depth schedule)' if args.config == 5 and not args.minibatch else ''),
+                                  ' (reference schedule)' if args.config == 5 and not args.minibatch else ''),
                    'resolution': res, 'depth': depth, 'minibatch_per_gpu': mb, 'global_batch': mb * n_gpus,
                    'parallelism': 'dp%d' % n_gpus, 'fmap_base': args.fmap_base},
         'step_algorithmic_gflop_per_image': w / 1e9,
-        'algorithmic_frac': w * (value / n_gpus) / MFMA_F32_PEAK,
+        'step_algorithmic_tflops_per_gpu': w * (value / n_gpus) / 1e12,     # a rate: Winograd stages can exceed the executed peak
         'host_enqueue_ms_per_step': host_free_ms,  # Python + launch time of one step on the host running free (median of the first ten timed steps)
         'host_enqueue_ms_per_step_whole_loop': host_ms,   # ... averaged over all timed steps (includes waiting for queue space behind the device)
         'step_issue': pg.wgan_gp_loss._replay_mode(tr.G) or 'eager',
+        'd_step_gp_ms': d_gp_ms,
     }
     out['config']['hip_graphs'] = bool((args.graphs or depth == 0) and args.alpha >= 1.0)
     if args.host_data or (args.config == 5 and not args.no_configs):
@@ -665,7 +780,7 @@ def main():
         except Exception:
             dwin = None
         if dwin:
-            out['d_step_gp_counters'] = dict(dwin, source=src + ' (rocprofv3 --pmc pass of bench.py --d-step-only: every kernel of the window)')
+            out['d_step_gp_counters'] = dict(dwin, source=src + ' (rocprofv3 --pmc pass of bench.py --d-step-only: every kernel of the window)', source_short=src)
         out['kernels'] = {k: {'tflops': v['tflops'], 'executed_tflops': v['exec_tflops'], 'ms_per_step': v['ms_per_step'],
                               'launches_per_step': v['launches_per_step'], 'avg_launch_us': v['avg_launch_us']}
                           for k, v in fam.items()}
@@ -751,9 +866,10 @@ def main():
     if rank == 0:
         # the JSON line is the LAST thing on stdout: RCCL prints its banner through C stdio, which is still buffered here
         import ctypes
+        detail_path = write_detail(out)
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        print(compact_line(out, detail_path), flush=True)
 
 
 if __name__ == '__main__':

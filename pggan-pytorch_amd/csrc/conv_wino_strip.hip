@@ -500,19 +500,6 @@ int pgw::launch_wino_strip(WinoP& p, int mode, hipStream_t s, char* name, size_t
     if (p.Cin != 8 && p.Cin != 16 && p.Cin != 32) return PG_E_UNSUP;
     if ((p.Cout & 15) || (p.W % SW) || (p.H & 15) || (p.H & (p.H - 1)) || (p.W & (p.W - 1))) return PG_E_UNSUP;
     if ((long long)p.H * p.W * 32 * 4 >= (1ll << 31)) return PG_E_UNSUP;          // 32-bit byte offsets inside an image
-    // couts per workgroup: every cout of a pixel for the PixelNorm epilogues (<= 32), else 32 when the layer has them and the
-    // 64 KB of U still leave room (Cin <= 16), 16 otherwise
-    int ncb = (p.pn_r || p.pnb_y) ? (p.Cout > 16 ? 2 : 1) : ((p.Cout % 32 == 0 && p.Cin <= 16) ? 2 : 1);
-    if (ncb_env == 1 || ncb_env == 2) { if (!(p.pn_r || p.pnb_y)) ncb = ncb_env; }
-    if ((p.pn_r || p.pnb_y) && p.Cout > 32) return PG_E_UNSUP;
-    if (p.Cout % (16 * ncb)) return PG_E_UNSUP;
-    WinoStripGeo g;
-    g.ncog = p.Cout / (16 * ncb);
-    if (g.ncog & (g.ncog - 1)) return PG_E_UNSUP;
-    g.strips = p.W / SW; g.stepsH = p.H >> 2;
-    g.total = p.N * g.strips * g.stepsH;
-    g.lgCog = ilog2i(g.ncog); g.lgStrips = ilog2i(g.strips); g.lgStepsH = ilog2i(g.stepsH);
-    g.spw = g.nrun = g.stagger = 0;                          // (launch_ws: they depend on the kernel variant's occupancy)
     // the specialised epilogue, when the launch asks for exactly one of the forms the train step uses
     int se = SE_GENERIC;
     const bool small = (long long)p.H * p.W * p.Cout * 4 * (p.yup ? 4 : 1) < (1ll << 31);
@@ -529,6 +516,20 @@ int pgw::launch_wino_strip(WinoP& p, int mode, hipStream_t s, char* name, size_t
         }
     }
     if (se == SE_GENERIC && !(mode & 2)) return PG_E_UNSUP;
+    // couts per workgroup: every cout of a pixel for the PixelNorm epilogues (<= 32), else 32 when the layer has them and the
+    // 64 KB of U still leave room (Cin <= 16), 16 otherwise
+    int ncb = (p.pn_r || p.pnb_y) ? (p.Cout > 16 ? 2 : 1) : ((p.Cout % 32 == 0 && p.Cin <= 16) ? 2 : 1);
+    if (ncb_env == 1 || ncb_env == 2) { if (!(p.pn_r || p.pnb_y)) ncb = ncb_env; }
+    if (se == SE_PLAIN_SIGNS || se == SE_UNPOOL) ncb = 1;       // (these two exist for 16 couts per workgroup only: never fall through to the general epilogue)
+    if ((p.pn_r || p.pnb_y) && p.Cout > 32) return PG_E_UNSUP;
+    if (p.Cout % (16 * ncb)) return PG_E_UNSUP;
+    WinoStripGeo g;
+    g.ncog = p.Cout / (16 * ncb);
+    if (g.ncog & (g.ncog - 1)) return PG_E_UNSUP;
+    g.strips = p.W / SW; g.stepsH = p.H >> 2;
+    g.total = p.N * g.strips * g.stepsH;
+    g.lgCog = ilog2i(g.ncog); g.lgStrips = ilog2i(g.strips); g.lgStepsH = ilog2i(g.stepsH);
+    g.spw = g.nrun = g.stagger = 0;                          // (launch_ws: they depend on the kernel variant's occupancy)
     switch (p.Cin) {
         case 8: return ncb == 2 ? launch_ws_epi<8, 2>(p, g, se, s, name, name_len) : launch_ws_epi<8, 1>(p, g, se, s, name, name_len);
         case 16: return ncb == 2 ? launch_ws_epi<16, 2>(p, g, se, s, name, name_len) : launch_ws_epi<16, 1>(p, g, se, s, name, name_len);

@@ -112,11 +112,11 @@ def _derived(net):
         pass
     elif (ASYNC_WGRAD and ASYNC_DERIVED and dev is not None and cur != _SIDE.get(dev) and not torch.cuda.is_current_stream_capturing()):
         side = _side_stream()
-        side.wait_stream(cur)
+        _wait_stream(side, cur)
         with torch.cuda.stream(side):
             backward_copies()
             ev = torch.cuda.Event()
-            ev.record(side)
+            _record_event(ev, side)
         for buf in (net._flat_wt, net._flat_wtu):  # written on the side stream: the allocator must not hand the block on before that
             if buf is not None:
                 buf.record_stream(side)
@@ -143,7 +143,7 @@ def _await_backward_copies(net):
         cur = torch.cuda.current_stream(torch._C._cuda_getDevice())
         waited = net.__dict__.setdefault('_derived_bwd_waited', set())
         if cur.cuda_stream not in waited:
-            cur.wait_event(ev)
+            _wait_event(cur, ev)
             waited.add(cur.cuda_stream)
 
 
@@ -313,6 +313,20 @@ WTU_FROM_PARAM = _os.environ.get('PGGAN_WTU_FROM_PARAM', '1') != '0'
 _SIDE = {}
 
 
+# Every cross-stream ordering the step schedules issue goes through these three: plans._Recorder swaps them (module attributes of
+# THIS module only -- never torch's classes, so stream / event traffic of other threads or libraries cannot leak into a plan).
+def _wait_stream(waiter, other):
+    waiter.wait_stream(other)
+
+
+def _record_event(ev, stream):
+    ev.record(stream)
+
+
+def _wait_event(stream, ev):
+    stream.wait_event(ev)
+
+
 def _side_stream():
     dev = torch.cuda.current_device()
     if dev not in _SIDE:
@@ -334,7 +348,7 @@ class _on_side(object):
             return self
         main = torch.cuda.current_stream(torch._C._cuda_getDevice())      # explicit index: skips the slow device lookup
         self.side = _side_stream()
-        self.side.wait_stream(main)
+        _wait_stream(self.side, main)
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self
@@ -351,7 +365,7 @@ class _on_side(object):
 def _join_side():
     """Main stream waits for every weight-gradient launch (call before the optimizer / all-reduce)."""
     if ASYNC_WGRAD and torch.cuda.is_available() and torch.cuda.current_device() in _SIDE:
-        torch.cuda.current_stream(torch._C._cuda_getDevice()).wait_stream(_SIDE[torch.cuda.current_device()])
+        _wait_stream(torch.cuda.current_stream(torch._C._cuda_getDevice()), _SIDE[torch.cuda.current_device()])
 
 
 def defer_to_side(net, fn):
@@ -848,8 +862,9 @@ def _d_backward_pn(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=Non
     a2 = lastrec['a2']
     gtop = ops.linear1_bwd_data(gscore, D.linear.weight.data, None, (nh,) + tuple(a2.shape[1:]))
     if nh < NB:                                      # mixed images: zero score gradient, injections only
-        g = torch.zeros_like(a2)
-        g[:nh].copy_(gtop)
+        g = torch.empty_like(a2)                     # (C-ABI launches, not ATen ops: a launch plan replays only those)
+        ops.zero_(g[nh:])
+        ops.axpby_mask(gtop, a=1.0, out=g[:nh])
     else:
         g = gtop
     if full:
@@ -863,14 +878,14 @@ def _d_backward_pn(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=Non
         fr_slope = blk.fromRGB.slope
         inj = injs[idx] if injs is not None else {}
         if save_adjoints:
-            adj[idx]['gy2'] = g.clone()
+            adj[idx]['gy2'] = ops.axpby_mask(g, a=1.0)          # device copy through the C-ABI (recorded by a launch plan)
         gz2 = _pn_bwd(g, rec['a2'], rec['r2'], c2.slope, nh, inj.get('inj2'))
         Hc2 = 1 if rec['last'] else H
         if full:
             _wgrad(rec['a1'], gz2, c2, NB, H)
         gy1 = _dgrad(D, gz2, c2, NB, Hc2)
         if save_adjoints:
-            adj[idx]['gy1'] = gy1.clone()
+            adj[idx]['gy1'] = ops.axpby_mask(gy1, a=1.0)
         gz1 = _pn_bwd(gy1, rec['a1'], rec['r1'], c1.slope, nh, inj.get('inj1'))
         if rec['last']:
             mb, inp = rec['mb'], rec['inp']

@@ -59,14 +59,10 @@ class _Recorder(object):
 
     def __enter__(self):
         rec = self
-        self._call = _lib.call
-        self._p = ops._p
-        self._wait_stream = torch.cuda.Stream.wait_stream
-        self._wait_event = torch.cuda.Stream.wait_event
-        self._ev_record = torch.cuda.Event.record
-        self._wait_pending = engine.wait_pending
-        self._await_bwd = engine._await_backward_copies
         lib = _lib.load()
+        self._saved = dict(call=_lib.call, p=ops._p, wait_stream=engine._wait_stream, wait_event=engine._wait_event,
+                           record_event=engine._record_event, wait_pending=engine.wait_pending, await_bwd=engine._await_backward_copies)
+        sv = self._saved
 
         def call(name, *args):
             fn = getattr(lib, name)
@@ -76,51 +72,50 @@ class _Recorder(object):
         def p(t):
             if t is not None:
                 rec.plan.keep[id(t)] = t
-            return rec._p(t)
+            return sv['p'](t)
 
-        def wait_stream(self_stream, other):
+        def wait_stream(waiter, other):            # = record an event on ``other``, make ``waiter`` wait for it (events the plan owns)
             ev = torch.cuda.Event()
-            rec._ev_record(ev, other)
-            rec._wait_event(self_stream, ev)
+            ev.record(other)
+            waiter.wait_event(ev)
             rec.entries.append((RECORD, ev, other))
-            rec.entries.append((WAIT, ev, self_stream))
+            rec.entries.append((WAIT, ev, waiter))
 
-        def wait_event(self_stream, ev):
-            rec._wait_event(self_stream, ev)
-            rec.entries.append((WAIT, ev, self_stream))
+        def wait_event(stream, ev):
+            stream.wait_event(ev)
+            rec.entries.append((WAIT, ev, stream))
 
-        def ev_record(ev, stream=None):
-            stream = torch.cuda.current_stream() if stream is None else stream
-            rec._ev_record(ev, stream)
+        def record_event(ev, stream):
+            ev.record(stream)
             rec.entries.append((RECORD, ev, stream))
 
         def wait_pending(net):
-            rec._wait_pending(net)
+            sv['wait_pending'](net)
             rec.entries.append((PENDING, net, torch.cuda.current_stream()))
 
         def await_bwd(net):
-            rec._await_bwd(net)
+            sv['await_bwd'](net)
             rec.entries.append((BWD_COPIES, net, torch.cuda.current_stream()))
 
+        # (module attributes of this package only; ``ops`` and ``engine`` reach the library through ``_lib.call`` / their own globals)
         _lib.call = call
-        ops._lib.call = call
         ops._p = p
-        torch.cuda.Stream.wait_stream = wait_stream
-        torch.cuda.Stream.wait_event = wait_event
-        torch.cuda.Event.record = ev_record
+        engine._wait_stream = wait_stream
+        engine._wait_event = wait_event
+        engine._record_event = record_event
         engine.wait_pending = wait_pending
         engine._await_backward_copies = await_bwd
         return self
 
     def __exit__(self, *exc):
-        _lib.call = self._call
-        ops._lib.call = self._call
-        ops._p = self._p
-        torch.cuda.Stream.wait_stream = self._wait_stream
-        torch.cuda.Stream.wait_event = self._wait_event
-        torch.cuda.Event.record = self._ev_record
-        engine.wait_pending = self._wait_pending
-        engine._await_backward_copies = self._await_bwd
+        sv = self._saved
+        _lib.call = sv['call']
+        ops._p = sv['p']
+        engine._wait_stream = sv['wait_stream']
+        engine._wait_event = sv['wait_event']
+        engine._record_event = sv['record_event']
+        engine.wait_pending = sv['wait_pending']
+        engine._await_backward_copies = sv['await_bwd']
         if exc[0] is None:
             self.plan.entries = self.entries
             STATS['recorded'] += 1
@@ -145,7 +140,8 @@ def _replay(plan):
                 e[2].wait_event(ev)
                 e[1]._pending = None
         else:
-            engine._await_backward_copies(e[1])       # (the replay runs on the stream the step was recorded on)
+            with torch.cuda.stream(e[2]):             # (no-op when e[2] is the current stream, which is the usual case)
+                engine._await_backward_copies(e[1])
     STATS['replayed'] += 1
 
 
@@ -184,19 +180,24 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
     _prologue(D, G)
 
     def body():
-        D._skip_join = True                  # the update that follows runs behind the weight gradients (Trainer: deferred, or joins itself)
+        # The plan itself never joins the weight-gradient stream: whether the caller's next launch needs the join is not known
+        # here.  ``backward()`` of the returned loss does it (wgan_gp_loss._replayed_backward) unless the caller has set
+        # ``D._skip_join`` by then (Trainer: the whole update follows on the weight-gradient stream, in order behind them).
+        caller = getattr(D, '_skip_join', False)
+        D._skip_join = True
         try:
             c, rl, fl, state = engine.d_loss_forward(D, G, g.static_in[0], g.static_in[1], g.static_in[2], lam, eps, target)
             engine.d_loss_backward(state)
         finally:
-            D._skip_join = False
+            D._skip_join = caller
         return c, rl, fl
+    if D.__dict__.get('_plan_unjoined', False):     # a step whose loss never had backward() called: its weight gradients may still be in flight
+        engine._join_side()
+    D._plan_unjoined = True
     if g.entries is None:
         if g.warm < 2:                       # eager warm-up (kernel attributes, first-request derived copies, allocator pools)
             g.warm += 1
-            out = body()
-            engine._join_side()
-            return out
+            return body()
         with _Recorder(g):
             g.static_out = body()
     else:

@@ -6,6 +6,8 @@ from PyTorch after 0.3, so the minimal ``Plugin`` protocol is restated here: an 
 (``iteration`` / ``epoch`` / ``s`` / ``end``) — exactly what ``Trainer.call_plugins`` relies on.
 All schedule arithmetic is Python int (+ one IEEE double division for alpha): bit-exact by construction."""
 import os
+import time
+from datetime import timedelta
 from glob import glob
 
 
@@ -141,6 +143,50 @@ class RampupLR(object):
     def step(self, cur_nimg):
         for g, base in zip(self.optimizer.param_groups, self.base_lrs):
             g['lr'] = base * self.fn(cur_nimg)
+
+
+class TimeMonitor(Plugin):
+    """Per-tick timing stats under the reference's names (plugins.py:114-139: ``stats['time']``, ``stats['sec']['tick']``,
+    ``stats['sec']['kimg']``) plus the two numbers this project's benchmark is quoted in: ``stats['img/s']`` (images shown per
+    second over the tick, all ranks) and ``stats['d_gp_ms']`` (device time of the D step + gradient penalty + Adam(D), mean of the
+    sampled iterations of the tick; ``Trainer`` brackets every ``sample_every``-th D update with two HIP events on the streams it
+    runs on).  The device is synchronised at tick boundaries only -- the host clock is the device's there and nowhere else."""
+
+    stat_name = 'time'
+
+    def __init__(self, base_time=0, sample_every=16):
+        super(TimeMonitor, self).__init__([(1, 'epoch')])
+        self.base_time = base_time
+        self.sample_every = int(sample_every)
+
+    def register(self, trainer):
+        self.trainer = trainer
+        self.start_time = self.epoch_start = time.time()
+        self.start_nimg = trainer.cur_nimg
+        trainer.stats['sec'] = {'log_format': ':.1f'}
+        trainer.stats['img/s'] = dict(val=0.0, log_epoch_fields=['{val:.1f}'], log_name='img/s')
+        trainer.stats['d_gp_ms'] = dict(val=0.0, log_epoch_fields=['{val:.3f}'], log_name='d_gp_ms')
+        trainer.d_step_probe = dict(every=max(1, self.sample_every), pairs=[])
+
+    def epoch(self, epoch_index):
+        import torch
+        tr = self.trainer
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.time()
+        tick_time = now - self.epoch_start
+        self.epoch_start = now
+        nimg = max(1, tr.cur_nimg - self.start_nimg)
+        self.start_nimg = tr.cur_nimg
+        tr.stats['time'] = timedelta(seconds=now - self.start_time + self.base_time)
+        tr.stats['sec']['tick'] = tick_time
+        tr.stats['sec']['kimg'] = tick_time / nimg * 1000
+        tr.stats['img/s']['val'] = nimg / max(tick_time, 1e-9)
+        probe = getattr(tr, 'd_step_probe', None)
+        if probe and probe['pairs']:
+            ms = [a.elapsed_time(b) for a, b in probe['pairs']]
+            tr.stats['d_gp_ms']['val'] = sum(ms) / len(ms)
+            del probe['pairs'][:]
 
 
 class SaverPlugin(Plugin):

@@ -159,6 +159,9 @@ class Trainer(object):
         self.input_transform = input_transform
         self._average_in_allreduce = {}
         self._exchanges = {}
+        # plugins.TimeMonitor: {'every': k, 'pairs': [(start event, end event), ...]} -- every k-th iteration the last D update
+        # (D loss + gradient penalty + backward + exchange + Adam(D)) is bracketed with two HIP events; read at tick boundaries
+        self.d_step_probe = None
         if parallel is not None:
             from . import wgan_gp_loss
             wgan_gp_loss.enable_plans(False)         # the bucketed exchange hooks into the eager backward sweep
@@ -230,6 +233,14 @@ class Trainer(object):
         self.optimizer_d.step()                                                   # reference trainer.py:100
         if getattr(self.D, '_flat_param', None) is not None and self.D._flat_param.is_cuda:
             engine._derived(self.D)
+        if self._probe_open is not None:             # end of the D+GP window, on the stream the update ran on
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            self.d_step_probe['pairs'].append((self._probe_open, end))
+            del self.d_step_probe['pairs'][:-64]
+            self._probe_open = None
+
+    _probe_open = None
 
     def _can_overlap_d_update(self):
         """Only with the product's own G loss (it reaches D's weights through the engine, which waits for the deferred
@@ -252,6 +263,10 @@ class Trainer(object):
                 reals = self.input_transform(reals)
             self.cur_nimg += reals.size(0) * world                                # :93 (global images)
             last = rep == self.D_training_repeats - 1
+            probe = self.d_step_probe
+            if probe and last and self.iterations % probe['every'] == 0 and getattr(reals, 'is_cuda', False):
+                self._probe_open = torch.cuda.Event(enable_timing=True)
+                self._probe_open.record()
             d_losses = _as_tuple(self.D_loss(self.D, self.G, reals, latents))     # :95
             defer = last and self._can_overlap_d_update()
             self.D._skip_join = defer                # the update runs on the second stream, behind the weight gradients

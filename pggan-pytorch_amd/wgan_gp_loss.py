@@ -114,9 +114,15 @@ class LossTensor(torch.Tensor):
 
 
 def _replayed_backward(net):
-    """``backward()`` of a loss whose step was replayed (hipGraph or launch plan): the gradients are already in ``param.grad``;
-    a ``gradient`` other than 1 rescales the flat gradient buffer afterwards -- what the eager path does too (engine.d_loss_backward)."""
+    """``backward()`` of a loss whose step was replayed (hipGraph or launch plan): the gradient launches are already enqueued.  A
+    replayed plan leaves the weight-gradient stream un-joined; the join happens HERE, so that ``loss.backward(); optimizer.step()``
+    keeps the contract of the eager path (engine.d_loss_backward: gradients complete for whatever the caller does next on this
+    stream) -- unless the caller has set ``net._skip_join`` (Trainer: the update follows on the weight-gradient stream itself).
+    A ``gradient`` other than 1 rescales the flat gradient buffer afterwards, as the eager path does."""
     def fn(scale):
+        if not (getattr(net, '_skip_join', False) and scale == 1.0):
+            engine._join_side()
+        net._plan_unjoined = False           # joined, or the caller took over (its update is ordered behind the weight-gradient stream)
         if scale != 1.0:
             from . import ops
             ops.axpby_mask(net._flat_grad, a=scale, out=net._flat_grad)

@@ -2,9 +2,14 @@ import json
 import os
 import sys
 
-import numpy as np
-import pytest
-import torch
+# The data-parallel tests of the GPU tier (one-rank RCCL communicator) must run in the SHIPPED configuration: 8 hardware queues, so
+# that the main / weight-gradient / exchange streams do not share one (parallel._want_hw_queues; read when the HIP runtime
+# initialises, i.e. at the first HIP call, so it has to be in the environment before any test touches the device).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')

@@ -383,6 +383,74 @@ def test_launch_plan_replay_matches_eager(foreign_optimizer):
         wl.enable_graphs(False)
 
 
+@pytest.mark.parametrize('d_pixelnorm', [False, True])
+def test_plan_replay_public_api_loop(d_pixelnorm):
+    """The loop of the public API without ``Trainer``: ``c = wgan_gp_D_loss(...); c.backward(); opt.step()``.  With launch plans on, the
+    recorded / replayed step leaves the weight-gradient stream un-joined and ``backward()`` must join it before the optimizer reads the
+    gradient buffer (Adam used to run under the largest weight-gradient launches).  Also the Discriminator(pixelnorm=True)
+    sweep under a plan: its adjoint copies / zero fills are C-ABI launches now, so a replay recomputes them (they used to be ATen ops the
+    plan did not record: stale adjoints from the recording step).  Compared per step with an eager twin at identical weights."""
+    wl = pg.wgan_gp_loss
+
+    def build():
+        torch.manual_seed(21)
+        shape = (1, 3, 64, 64)
+        kw = dict(fmap_base=1024, fmap_max=64)
+        G = pg.Generator(shape, latent_size=64, **kw).cuda()
+        D = pg.Discriminator(shape, pixelnorm=d_pixelnorm, **kw).cuda()
+        G.depth = D.depth = 4
+        return G, D, pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+    pg.plans.STATS.update(recorded=0, replayed=0)
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    try:
+        (Ga, Da, oa), (Gb, Db, ob) = build(), build()
+        for it in range(7):
+            real = torch.rand((6, 3, 64, 64), device=DEV, generator=gen) * 2 - 1
+            z = torch.randn((6, 64), device=DEV, generator=gen)
+            mix = torch.rand((6, 1), device=DEV, generator=gen)
+            costs = []
+            for (G, D, opt), mode in (((Ga, Da, oa), 'auto'), ((Gb, Db, ob), False)):
+                wl._use_graphs = mode                           # (the switch itself: enable_graphs(False) would drop the recorded plans)
+                wl.set_mixing_factors(mix)
+                c = pg.wgan_gp_D_loss(D, G, real, z)[0]
+                c.backward()
+                costs.append((float(c), D._flat_grad.clone()))
+                opt.step()
+            torch.cuda.synchronize()
+            assert abs(costs[0][0] - costs[1][0]) <= 2e-4 * max(1.0, abs(costs[1][0])), (it, costs[0][0], costs[1][0])
+            assert _l2(costs[0][1], costs[1][1].cpu()) < 2e-3, it       # pre-Adam gradients (atomic commit order differs)
+            with torch.no_grad():                               # keep the twins at identical weights / moments
+                Db._flat_param.copy_(Da._flat_param)
+            Db.mark_params_changed()
+            for (_, ma, va), (_, mb_, vb) in zip(oa._flat.values(), ob._flat.values()):
+                mb_.copy_(ma)
+                vb.copy_(va)
+        assert pg.plans.STATS['recorded'] == 1 and pg.plans.STATS['replayed'] == 4, pg.plans.STATS
+    finally:
+        wl.enable_graphs(False)
+
+
+def test_time_monitor_d_step_probe():
+    """TimeMonitor on the device: every k-th iteration's D update is bracketed with two HIP events (start on the main stream, end on
+    the stream the deferred update runs on); the tick reports their mean as stats['d_gp_ms'] next to img/s."""
+    torch.manual_seed(2)
+    shape = (1, 3, 16, 16)
+    kw = dict(fmap_base=128, fmap_max=32)
+    G = pg.Generator(shape, latent_size=32, **kw).cuda()
+    D = pg.Discriminator(shape, **kw).cuda()
+    G.depth = D.depth = 2
+    ds = pg.utils.SyntheticDataset(16, 3, seed=5)
+    ds.model_depth = 2
+    tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99)),
+                    pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99)), ds, ds.loader(4), pg.utils.device_latents(4, 32, seed=3),
+                    tick_nimg_default=4 * 12)
+    tr.register_plugin(pg.TimeMonitor(sample_every=3))
+    tr.run(4 * 24 / 1000.0)
+    assert tr.cur_tick == 2
+    assert 0.0 < tr.stats['d_gp_ms']['val'] < 1e3 and tr.stats['img/s']['val'] > 0
+    assert tr.stats['sec']['tick'] > 0 and not tr.d_step_probe['pairs']          # consumed at the tick boundary
+
+
 def test_whole_module_pickle_roundtrip(tmp_path):
     """SaverPlugin semantics (plugins.py:155-166): ``torch.save(model)`` / ``torch.load`` of whole modules must
     preserve weights AND the equalized-lr constants c (not in the reference's state_dict), and the reloaded

@@ -278,3 +278,25 @@ def test_bench_refuses_more_gpus_than_visible():
     env['WORLD_SIZE'] = '4'
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE' in r.stderr
+
+
+def test_time_monitor_stat_names():
+    """plugins.TimeMonitor fills the reference's per-tick timing stats (plugins.py:114-139: 'time', 'sec.tick', 'sec.kimg') and this
+    project's 'img/s' / 'd_gp_ms'; no device is needed for the host-clock half."""
+    from datetime import timedelta
+
+    class T(object):
+        cur_nimg = 100
+        stats = {}
+        d_step_probe = None
+    tr = T()
+    mon = pg.TimeMonitor(base_time=5, sample_every=4)
+    assert mon.trigger_interval == [(1, 'epoch')]
+    mon.register(tr)
+    assert tr.stats['sec'] == {'log_format': ':.1f'} and tr.d_step_probe == {'every': 4, 'pairs': []}
+    tr.cur_nimg = 1100
+    mon.epoch(1)
+    assert isinstance(tr.stats['time'], timedelta) and tr.stats['time'].total_seconds() >= 5
+    assert tr.stats['sec']['tick'] > 0 and abs(tr.stats['sec']['kimg'] - tr.stats['sec']['tick']) < 1e-9       # 1000 images in the tick
+    assert abs(tr.stats['img/s']['val'] * tr.stats['sec']['tick'] - 1000) < 1e-6
+    assert tr.stats['d_gp_ms']['val'] == 0.0                 # (no sampled iteration: the probe needs device events)
