@@ -170,21 +170,6 @@ int pg_conv2d_wino_pnbwd_nhwc(const float* x, const float* u, const float* ysave
                               int pool, const float* pool_other, float pool_a, float pool_b,
                               int N, int H, int W, int Cin, int Cout, float scale, float slope, pg_stream_t stream);
 
-/* Two-pass form of pg_conv2d_wino_nhwc for the K-heavy layers (Cin >= 128 on maps <= 64x64; replaces F.conv2d at reference
- * network.py:34 for the D blocks / G mirror of those widths): the Winograd input transform V = B^T d B is computed ONCE per layer
- * input by pg_wino_transform_input_nhwc (x NHWC [N,H,W,Cin], or [N,H/2,W/2,Cin] with ups = 1: nearest x2 upsample in the gather)
- * into v = [Cin/8][16][tile blocks][64 tiles][8] (pg_wino_v_elems floats: 4x the input), and pg_conv2d_wino_v_nhwc runs the conv on
- * it: same arguments, fused epilogues and results (bit-identical unsliced) as pg_conv2d_wino_nhwc with x replaced by v; flags must
- * not carry PG_FLAG_UPSAMPLE.  Cin and Cout multiples of 16, H and W powers of two >= 8.  K slices through the stream's scratch
- * (pg_set_workspace) as in pg_conv2d_wino_nhwc.                                                                          */
-int pg_wino_v_elems(int N, int H, int W, int Cin, size_t* elems);
-int pg_wino_transform_input_nhwc(const float* x, float* v, int N, int H, int W, int Cin, int ups, pg_stream_t stream);
-int pg_conv2d_wino_v_nhwc(const float* v, const float* u, const float* bias, const float* mask, float* y,
-                          float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
-                          float* yup, const float* upmask, float up_mul,
-                          int N, int H, int W, int Cin, int Cout, int flags,
-                          float scale, float slope, float mask_slope, pg_stream_t stream);
-
 /* Scratch for the launches on `stream` (of the current device) that slice their K loop across workgroups: the 3x3 layers of
  * the 16x16 / 32x32 stages at minibatch 3 give pg_conv2d_wino_nhwc fewer workgroups than the chip has CUs, so up to 8 workgroups
  * share a (64-tile, 16-cout) block, each leaves its partial outputs in the scratch and the last one to arrive adds them in slice

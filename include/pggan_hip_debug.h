@@ -28,8 +28,6 @@ int pg_debug_set_wino(int vec);
 int pg_debug_set_wino_ksplit(int n);
 /* 0: the general epilogue for every launch of the second-generation Winograd conv (A/B against the specialised ones); -1: built-in choice. */
 int pg_debug_set_wino_epi(int mode);
-/* Couts per workgroup / 16 of the two-pass Winograd conv (pg_conv2d_wino_v_nhwc): 1 | 2, 0: built-in choice. */
-int pg_debug_set_wino_v(int ncb);
 
 #ifdef __cplusplus
 }

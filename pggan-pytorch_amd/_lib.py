@@ -36,9 +36,6 @@ SIGNATURES = {
     'pg_wino_transform_weights': [P, P, I, I, P],
     'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P, P],
     'pg_conv2d_wino_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
-    'pg_wino_v_elems': [I, I, I, I, P],
-    'pg_wino_transform_input_nhwc': [P, P, I, I, I, I, I, P],
-    'pg_conv2d_wino_v_nhwc': [P, P, P, P, P, P, P, F, F, I, P, P, F, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wino_pixelnorm_nhwc': [P, P, P, P, P, I, I, I, I, I, I, F, F, F, P],
     'pg_conv2d_wino_pnbwd_nhwc': [P, P, P, P, P, I, P, F, F, I, I, I, I, I, F, F, P],
     'pg_set_workspace': [P, P, ctypes.c_size_t],
@@ -102,7 +99,6 @@ DEBUG_SIGNATURES = {
     'pg_debug_set_wino': [I],
     'pg_debug_set_wino_ksplit': [I],
     'pg_debug_set_wino_epi': [I],
-    'pg_debug_set_wino_v': [I],
 }
 
 _lib = None

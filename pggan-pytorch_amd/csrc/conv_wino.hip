@@ -469,219 +469,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Two-pass Winograd conv for the K-heavy layers (round 5): the input transform V = B^T d B is computed ONCE per
-// layer input by a streaming kernel (wino_input_transform_kernel) instead of once per 16-cout workgroup and K chunk -- on the
-// 256 / 512-cout layers that is 16-32x the same 64 VALU instructions per chunk and wave, and on gfx950 VALU time ADDS to fp32 MFMA time.
-//
-// V layout: V[Cin/8][16 positions][tile blocks][64 tiles][8 channels], tile blocks / tiles in the order of the tile kernels
-// (wino_block_geometry: block = TN images x TTH x TTW tiles, tile t = wave * 16 + li).  The 16 tiles x 8 channels a wave needs of one
-// position are 512 contiguous bytes = ONE buffer_load_dwordx2 per lane, global -> VGPR: V is private to a wave (tile = MFMA column), so
-// it never touches LDS; only U (shared by the four waves) is staged, by LDS-DMA as in conv_wino2_kernel.  The K loop of a wave is then
-// 16 V loads + 16 NCB LDS fragment reads + 2 NCB DMA issues per 32 NCB MFMAs, no patch reads, no transform.
-// L1 / L2 -> CU traffic per MFMA: 256 / NCB bytes of V + 64 of U = 24 B/clk/CU at NCB = 2 against ~55 the DMA path sustains
-// (profiles/r03_l2_to_lds_dma_bandwidth.txt) -- why the V form takes 32 couts per workgroup.
-__global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* __restrict__ x, float* __restrict__ v,
-                                                                   int N, int H, int W, int Cin, int ups,
-                                                                   int lgTW, int lgTH, int TN, int blocksW, int blocksH, int ntb)
-{
-    // block = (tile block tb, 16 channels = two packs); thread = (pack of the pair, tile, half pack): consecutive threads write
-    // consecutive 16-byte pieces of V (tile-major, two per tile)
-    const int tb = (int)blockIdx.x % ntb, cb = (int)blockIdx.x / ntb;
-    const int tid = threadIdx.x, pk = 2 * cb + (tid >> 7), t = (tid >> 1) & 63, h = tid & 1;
-    if (pk * 8 >= Cin) return;
-    int b = tb;
-    const int bw = b % blocksW; b /= blocksW;
-    const int bh = b % blocksH; b /= blocksH;
-    const int TTW = 1 << lgTW, TTH = 1 << lgTH;
-    const int ttx = t & (TTW - 1), tty = (t >> lgTW) & (TTH - 1), ttn = t >> (lgTW + lgTH);
-    const int n = b * TN + ttn;
-    const int y0 = 2 * ((bh << lgTH) + tty) - 1, x0 = 2 * ((bw << lgTW) + ttx) - 1;
-    const int xH = ups ? (H >> 1) : H, xW = ups ? (W >> 1) : W;
-    const int c0 = pk * 8 + 4 * h;
-    float4 d[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int ih = y0 + a, iw = x0 + c;
-            const bool ok = n < N && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            if (ups) { ih >>= 1; iw >>= 1; }
-            d[a][c] = ok ? *reinterpret_cast<const float4*>(x + (((size_t)n * xH + ih) * xW + iw) * Cin + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    // V = B^T d B: the operation order of conv_wino2_kernel's in-loop transform (bit-identical V)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float4 t0 = f4sub(d[0][c], d[2][c]), t1 = f4add(d[1][c], d[2][c]), t2 = f4sub(d[2][c], d[1][c]), t3 = f4sub(d[1][c], d[3][c]);
-        d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const float4 t0 = f4sub(d[a][0], d[a][2]), t1 = f4add(d[a][1], d[a][2]), t2 = f4sub(d[a][2], d[a][1]), t3 = f4sub(d[a][1], d[a][3]);
-        d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
-    }
-    float* vb = v + ((((size_t)pk * 16) * ntb + tb) * 64 + t) * 8 + 4 * h;
-    const size_t ps = (size_t)ntb * 512;                       // floats between two Winograd positions of a pack
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(vb + (size_t)(4 * a + c) * ps) = d[a][c];
-}
-
-template <int NCB, bool KSP, int EPI>
-__global__ __launch_bounds__(256, NCB == 2 ? 2 : 3) void conv_wino_v_kernel(WinoP p)     // p.x = V
-{
-    static_assert(EPI == EPI_GENERIC || NCB == 1, "specialised epilogues: 16 couts per workgroup");
-    constexpr int KC = 8;
-    constexpr int US = 2 * NCB;                              // DMA instructions per thread for a U chunk: 2 planes x 16 xi x 16 NCB rows / 256
-    constexpr int UBYTES = US * 256 * 16;                    // LDS: [U 0][U 1]
-    typedef float v2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    extern __shared__ __align__(16) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kk = lane >> 4;
-    int b = (int)pg_xcd_remap(blockIdx.x, gridDim.x);
-    int cob, ks = 0;
-    if constexpr (KSP) { const int q = (int)__umulhi((unsigned)b, p.mKs); ks = b - q * p.ksplit; b = q; }
-    const int blk = b;
-    if (p.ncob == 1) cob = 0;
-    else if (p.cout_minor) { const int q = (int)__umulhi((unsigned)b, p.mDiv); cob = b - q * p.ncob; b = q; }
-    else { cob = (int)__umulhi((unsigned)b, p.mDiv); b -= cob * p.ntb; }
-    const int tb = b;                                        // tile block: the V index
-    const int bw = b & (p.blocksW - 1); b >>= p.lgBW;
-    const int bh = b & (p.blocksH - 1); b >>= p.lgBH;
-    const int n0 = b * p.TN;
-    const int TTW = 1 << p.lgTW, TTH = 1 << p.lgTH;
-    const int ty0 = bh << p.lgTH, tx0 = bw << p.lgTW;
-    const int co0 = cob * 16 * NCB;
-    const int t = wave * 16 + li;
-    const int ttx = t & (TTW - 1), tty = (t >> p.lgTW) & (TTH - 1), ttn = t >> (p.lgTW + p.lgTH);
-    const int ubyte = ((kk >> 1) * 256 * NCB + li) * 16 + (kk & 1) * 8;      // + buffer, + (xi * 16 * NCB + cb * 16) * 16
-
-    // V: one raw buffer over the whole tensor; lane offset = (tile, channel pair), wave-uniform offset = (pack, position, tile block)
-    const __amdgpu_buffer_rsrc_t rv = pg_make_rsrc(p.x, (unsigned)((size_t)p.Cin * 2 * p.ntb * 4096));      // Cin/8 * 16 * ntb * 2048 bytes
-    const unsigned vlane = (unsigned)(t * 32 + kk * 8);
-    const unsigned vpos = (unsigned)p.ntb * 2048u, vtb = (unsigned)tb * 2048u;
-    unsigned usrc[US];
-#pragma unroll
-    for (int i = 0; i < US; ++i) {
-        const int sl = (i * 4 + wave) * 64 + lane;
-        const int q = sl / (256 * NCB), r = sl - q * 256 * NCB;                          // r = xi * 16*NCB + co
-        const int xi = r / (16 * NCB), co = co0 + r - xi * 16 * NCB;
-        usrc[i] = co < p.Cout ? 4u * (unsigned)((xi * p.Cout + co) * 8 + 4 * q) : PG_OOB;
-    }
-    const unsigned upack = 4u * 16u * 8u * (unsigned)p.Cout;
-    const unsigned long long ua = (unsigned long long)p.u;
-    const pg_u32x4 rus = pg_u32x4{(unsigned)ua, (unsigned)(ua >> 32) & 0xffffu, (unsigned)((size_t)16 * p.Cout * p.Cin * 4), 0x00020000u};
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    auto dma16 = [&](const pg_u32x4& rs, unsigned voff, unsigned soff, unsigned dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(dst) : "memory");
-    };
-    const unsigned wbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-    auto dma_u = [&](int k0) {
-        const unsigned dst = wbase + (unsigned)((k0 >> 3) & 1) * UBYTES, usoff = (unsigned)(k0 >> 3) * upack;
-#pragma unroll
-        for (int i = 0; i < US; ++i) dma16(rus, usrc[i], usoff, dst + i * 4096);
-    };
-    auto load_v = [&](int k0, v2 (&d)[16]) {
-        const unsigned base = (unsigned)(k0 >> 3) * 16u * vpos + vtb;
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            const u2 r = __builtin_amdgcn_raw_buffer_load_b64(rv, (int)vlane, (int)(base + (unsigned)xi * vpos), 0);
-            d[xi] = v2{__uint_as_float(r[0]), __uint_as_float(r[1])};
-        }
-    };
-
-    f32x4 acc[NCB][16];
-    const int kbeg = KSP ? ks * p.kcper * KC : 0;
-    const int kend = KSP ? min(p.Cin, kbeg + p.kcper * KC) : p.Cin;
-    v2 va[16], vb[16];
-    load_v(kbeg, va);
-    dma_u(kbeg);
-    auto chunk = [&](const int k0, const v2 (&d)[16], v2 (&dn)[16], auto first) {
-        __builtin_amdgcn_sched_barrier(0);                    // (every MFMA of the previous chunk is issued before the wait: 2048 cycles of cover)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's U DMA and V loads of the chunk have landed ...
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // (the same wait where the compiler's own counter model sees it: vmcnt(0))
-        __syncthreads();                                      // ... everyone's U has, and nobody still reads the other U buffer
-        if (k0 + KC < kend) { load_v(k0 + KC, dn); dma_u(k0 + KC); }
-        __builtin_amdgcn_sched_barrier(0);
-        typedef __attribute__((address_space(3))) const char* lds_cptr;
-        typedef __attribute__((address_space(3))) const volatile v2* lds_v2ptr;
-        const lds_cptr ub = (lds_cptr)lds + ubyte + ((k0 >> 3) & 1) * UBYTES;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            v2 af[NCB][4];
-#pragma unroll
-            for (int c = 0; c < NCB; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) af[c][j] = *(lds_v2ptr)(ub + (((g * 4 + j) * NCB + c) * 16) * 16);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int c = 0; c < NCB; ++c) {
-                        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                        acc[c][4 * g + j] = MFMA16(af[c][j][s2], d[4 * g + j][s2], (decltype(first)::value && s2 == 0) ? zero4 : acc[c][4 * g + j]);
-                    }
-        }
-    };
-    // two chunks per trip: the V registers of the chunk in flight and of the chunk being multiplied swap roles without moves
-    chunk(kbeg, va, vb, std::true_type{});
-    int k0 = kbeg + KC;
-    for (; k0 + KC < kend; k0 += 2 * KC) {
-        chunk(k0, vb, va, std::false_type{});
-        chunk(k0 + KC, va, vb, std::false_type{});
-    }
-    if (k0 < kend) chunk(k0, vb, va, std::false_type{});
-
-    const int oy0 = 2 * (ty0 + tty), ox0 = 2 * (tx0 + ttx);
-    if constexpr (KSP) {
-        // partial 2x2 outputs of this K slice -> slice (blk, ks) of the scratch; the last arriver adds the slices in split order and
-        // runs the fused epilogue (as conv_wino2_kernel; NCB x 16 KB per slice)
-        f32x4 yq[NCB][4];
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) wino_output_transform(acc[c], yq[c]);
-        constexpr int SC1 = 16;
-        const __amdgpu_buffer_rsrc_t rp = pg_make_rsrc(p.ks_part + (size_t)blk * p.ksplit * 4096 * NCB, (unsigned)p.ksplit * 16384u * NCB);
-#pragma unroll
-        for (int c = 0; c < NCB; ++c)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_raw_buffer_store_b128(pg_u32x4{__float_as_uint(yq[c][q][0]), __float_as_uint(yq[c][q][1]), __float_as_uint(yq[c][q][2]),
-                                                                __float_as_uint(yq[c][q][3])}, rp, (((ks * NCB + c) * 4 + q) * 256 + tid) * 16, 0, SC1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __attribute__((address_space(3))) unsigned* const ticket = (__attribute__((address_space(3))) unsigned*)lds;
-        if (tid == 0) *ticket = __hip_atomic_fetch_add(p.ks_count + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*ticket != (unsigned)(p.ksplit - 1)) return;
-        if (tid == 0) __hip_atomic_store(p.ks_count + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) yq[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s2 = 0; s2 < p.ksplit; ++s2)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const pg_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rp, (((s2 * NCB + c) * 4 + q) * 256 + tid) * 16, 0, SC1);
-                    yq[c][q] += f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
-                }
-            wino_epilogue_sel<EPI>(p, yq[c], co0 + 16 * c + 4 * kk, n0 + ttn, oy0, ox0);
-        }
-    } else if constexpr (EPI != EPI_GENERIC) {
-        f32x4 yq[4];
-        wino_output_transform(acc[0], yq);
-        wino_epilogue_fast<EPI>(p, yq, co0 + 4 * kk, n0 + ttn, oy0, ox0);
-    } else {
-#pragma unroll
-        for (int c = 0; c < NCB; ++c)
-            wino_epilogue(p, acc[c], co0 + 16 * c + 4 * kk, n0 + ttn, oy0, ox0);
-    }
-}
-
 // all layers of a network in one launch (layer l: w at wbase + woff[l], u at ubase + uoff[l])
 constexpr int WB_MAX = 32;
 struct WinoBatch {
@@ -1111,115 +898,4 @@ extern "C" int pg_conv2d_wino_pnbwd_nhwc(const float* x, const float* u, const f
     if (pool && ((H | W) & 1)) return PG_E_ARG;
     return wino_conv(x, u, nullptr, nullptr, y, pool ? y : nullptr, pool ? pool_other : nullptr, pool_a, pool_b, pool ? 1 : 0, nullptr, nullptr, 1.f,
                      N, H, W, Cin, Cout, 0, scale, 1.f, slope, nullptr, 0.f, stream, ysaved, r);
-}
-
-// ---- two-pass form (V = Winograd-domain input, see conv_wino_v_kernel) ------------------------------------------------------
-namespace {
-thread_local int g_wino_v_ncb = 0;             // 0: built-in choice; 1 / 2: couts per workgroup / 16 (pg_debug_set_tuning key 40)
-}
-extern "C" int pg_debug_set_wino_v(int ncb) { if (ncb < 0 || ncb > 2) return PG_E_ARG; g_wino_v_ncb = ncb; return 0; }
-
-extern "C" int pg_wino_v_elems(int N, int H, int W, int Cin, size_t* elems)
-{
-    if (!elems || N <= 0 || Cin <= 0) return PG_E_ARG;
-    if ((Cin & 15) || !pow2(H) || !pow2(W) || H < 8 || W < 8) return PG_E_UNSUP;
-    int TTW, TTH, TN, ntb;
-    wino_block_geometry(N, H, W, TTW, TTH, TN, ntb);
-    *elems = (size_t)2 * Cin * ntb * 1024;                   // Cin/8 packs x 16 positions x ntb x 64 tiles x 8 channels
-    return 0;
-}
-
-extern "C" int pg_wino_transform_input_nhwc(const float* x, float* v, int N, int H, int W, int Cin, int ups, pg_stream_t stream)
-{
-    if (!x || !v || N <= 0 || Cin <= 0) return PG_E_ARG;
-    if (Cin & 15) return PG_E_ALIGN;                         // two 8-channel packs per workgroup
-    if (!pow2(H) || !pow2(W) || H < 8 || W < 8) return PG_E_UNSUP;
-    int TTW, TTH, TN, ntb;
-    wino_block_geometry(N, H, W, TTW, TTH, TN, ntb);
-    if ((long long)2 * Cin * ntb * 4096 >= (1ll << 31) || (long long)N * H * W * Cin >= (1ll << 31)) return PG_E_UNSUP;   // V is read through one raw buffer
-    const int blocksW = (W >> 1) / TTW, blocksH = (H >> 1) / TTH;
-    hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)(ntb * (Cin / 16))), dim3(256), 0, (hipStream_t)stream,
-                       x, v, N, H, W, Cin, ups ? 1 : 0, ilog2i(TTW), ilog2i(TTH), TN, blocksW, blocksH, ntb);
-    return (int)hipGetLastError();
-}
-
-extern "C" int pg_conv2d_wino_v_nhwc(const float* v, const float* u, const float* bias, const float* mask, float* y,
-                                     float* ypool, const float* pool_other, float pool_a, float pool_b, int pool_only,
-                                     float* yup, const float* upmask, float up_mul,
-                                     int N, int H, int W, int Cin, int Cout, int flags,
-                                     float scale, float slope, float mask_slope, pg_stream_t stream)
-{
-    if (!v || !u || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
-    if ((Cin & 15) || (Cout & 15)) return PG_E_ALIGN;
-    if (flags & PG_FLAG_UPSAMPLE) return PG_E_ARG;           // (the upsample belongs to pg_wino_transform_input_nhwc)
-    if (!pow2(H) || !pow2(W) || H < 8 || W < 8) return PG_E_UNSUP;
-    if ((long long)N * H * W * Cout >= (1ll << 29) || (long long)16 * Cout * Cin >= (1ll << 29)) return PG_E_UNSUP;
-    WinoP p;
-    p.x = v; p.u = u; p.bias = bias; p.mask = mask; p.y = y;
-#ifdef PG_WINO_TRACE
-    p.trace = nullptr;
-#endif
-    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ups = 0;
-    p.mask_bytes = (flags & PG_FLAG_MASK_BYTES) ? 1 : 0; p.y_bytes = (flags & PG_FLAG_Y_BYTES) ? 1 : 0;
-    if (p.y_bytes && !ypool) return PG_E_UNSUP;
-    p.ysigns = nullptr;
-    if (flags & PG_FLAG_SIGNS_OUT) {
-        if (!mask || p.mask_bytes || yup) return PG_E_ARG;
-        p.ysigns = reinterpret_cast<unsigned char*>(const_cast<float*>(mask));
-        p.mask = nullptr;
-    }
-    p.scale = scale; p.slope = slope; p.mask_slope = mask_slope;
-    p.ypool = ypool; p.pool_other = pool_other; p.pool_a = pool_a; p.pool_b = pool_b; p.pool_only = pool_only;
-    p.yup = yup; p.upmask = upmask; p.up_mul = up_mul;
-    p.pn_r = nullptr; p.pn_eps = 0.f; p.pnb_y = nullptr; p.pnb_r = nullptr;
-    int TTW, TTH, TN, ntb;
-    wino_block_geometry(N, H, W, TTW, TTH, TN, ntb);
-    if ((long long)2 * Cin * ntb * 4096 >= (1ll << 31)) return PG_E_UNSUP;
-    p.lgTW = ilog2i(TTW); p.lgTH = ilog2i(TTH); p.TN = TN;
-    p.blocksW = (W >> 1) / TTW; p.blocksH = (H >> 1) / TTH;
-    p.mWT = p.mHT = 0;
-    // 32 couts per workgroup (half the V traffic per MFMA) unless that leaves the chip under-filled even with K slices
-    static const int ncb_env = getenv("PG_WINO_V_NCB") ? atoi(getenv("PG_WINO_V_NCB")) : 0;
-    int ncb = g_wino_v_ncb ? g_wino_v_ncb : ncb_env ? ncb_env : 2;
-    if (ncb != 1 && ncb != 2) return PG_E_ARG;
-    if (Cout % (16 * ncb)) ncb = 1;
-    p.ncob = Cout / (16 * ncb);
-    p.ntb = ntb; p.lgBW = ilog2i(p.blocksW); p.lgBH = ilog2i(p.blocksH);
-    p.cout_minor = 1;                                         // cout blocks of one tile block adjacent: its V comes from HBM / MALL once, from the XCD's L2 afterwards
-    if ((long long)p.ncob * p.ncob * ntb >= (1ll << 32)) return PG_E_UNSUP;
-    p.mDiv = (unsigned)((1ull << 32) / (unsigned)p.ncob) + 1u;
-    const int nblk = ntb * p.ncob, nch = Cin >> 3;
-    int ks = 1;
-    Workspace ws{};
-    static const int v_target = getenv("PG_WINO_V_KS_TARGET") ? atoi(getenv("PG_WINO_V_KS_TARGET")) : (ncb == 2 ? 512 : 768);
-    if (g_wino_ksplit != 0 && g_wino_ksplit != 1 && nblk <= (int)WS_TICKETS && find_workspace((hipStream_t)stream, ws)) {
-        if (g_wino_ksplit > 1) ks = g_wino_ksplit;
-        else if (2 * nblk <= v_target) { ks = v_target / nblk; if (ks > 8) ks = 8; if (ks > nch / 4) ks = nch / 4; }
-        if (ks > nch) ks = nch;
-        if (ks > 1) {
-            p.kcper = (nch + ks - 1) / ks;
-            ks = (nch + p.kcper - 1) / p.kcper;
-            if (WS_HEAD + (size_t)nblk * ks * 16384 * ncb > ws.bytes || (long long)nblk * ks * ks >= (1ll << 32)) ks = 1;
-        }
-        if (ks < 1) ks = 1;
-    }
-    p.ksplit = ks;
-    if (ks > 1) {
-        p.mKs = (unsigned)((1ull << 32) / (unsigned)ks) + 1u;
-        p.ks_count = reinterpret_cast<unsigned*>(ws.ptr); p.ks_part = reinterpret_cast<float*>(ws.ptr + WS_HEAD);
-    } else { p.kcper = nch; p.mKs = 0; p.ks_count = nullptr; p.ks_part = nullptr; }
-    int epi = EPI_GENERIC;
-    if (ncb == 1 && g_wino_epi != 0 && !ypool && !yup && !p.y_bytes && !p.ysigns && (long long)H * W * Cout * 4 < (1ll << 31)) {
-        if (!p.mask) epi = EPI_PLAIN;
-        else if (p.mask_bytes) epi = EPI_MASKB;
-    }
-    void (*fn)(WinoP);
-    if (ncb == 2) fn = ks > 1 ? conv_wino_v_kernel<2, true, EPI_GENERIC> : conv_wino_v_kernel<2, false, EPI_GENERIC>;
-    else if (epi == EPI_PLAIN) fn = ks > 1 ? conv_wino_v_kernel<1, true, EPI_PLAIN> : conv_wino_v_kernel<1, false, EPI_PLAIN>;
-    else if (epi == EPI_MASKB) fn = ks > 1 ? conv_wino_v_kernel<1, true, EPI_MASKB> : conv_wino_v_kernel<1, false, EPI_MASKB>;
-    else fn = ks > 1 ? conv_wino_v_kernel<1, true, EPI_GENERIC> : conv_wino_v_kernel<1, false, EPI_GENERIC>;
-    snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino_v_kernel<%d, %s, %d>", ncb, ks > 1 ? "true" : "false", epi);
-    const size_t smem = (size_t)2 * 512 * ncb * 16;           // two U buffers
-    hipLaunchKernelGGL(fn, dim3((unsigned)(nblk * ks)), dim3(256), smem, (hipStream_t)stream, p);
-    return (int)hipGetLastError();
 }

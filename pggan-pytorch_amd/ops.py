@@ -166,37 +166,11 @@ def signbytes_to_mask(b):
     return m
 
 
-# Two-pass Winograd conv (csrc/conv_wino.hip: conv_wino_v_kernel): the input transform once per layer input instead of once per
-# 16-cout workgroup and K chunk.  Policy: the K-heavy layers -- many couts share one transformed input, and the Winograd-domain input
-# (4x the activation) stays cache-resident on the small maps.  PGGAN_WINO_V=0: one-pass kernels everywhere; =2: wherever the shape allows.
-WINO_V = int(_os.environ.get('PGGAN_WINO_V', '1'))
-WINO_V_MIN_CIN = int(_os.environ.get('PGGAN_WINO_V_MIN_CIN', '128'))
-WINO_V_MIN_COUT = int(_os.environ.get('PGGAN_WINO_V_MIN_COUT', '128'))
-WINO_V_MAX_H = int(_os.environ.get('PGGAN_WINO_V_MAX_H', '64'))
-
-
-def _wino_v_form(N, H, W, cin, cout):
-    if WINO_V == 0 or (cin & 15) or (cout & 15) or H < 8 or W < 8 or (H & (H - 1)) or (W & (W - 1)):
-        return False
-    return WINO_V == 2 or (cin >= WINO_V_MIN_CIN and cout >= WINO_V_MIN_COUT and max(H, W) <= WINO_V_MAX_H)
-
-
-def wino_transform_input(x, N, H, W, cin, ups=False):
-    """V = B^T d B of every 2x2-output tile of a 3x3 pad-1 conv input (x NHWC [N,H,W,cin], or [N,H/2,W/2,cin] with ``ups``), in the
-    layout pg_conv2d_wino_v_nhwc reads (include/pggan_hip.h): 4x the elements of the (upsampled) input."""
-    n = ctypes.c_size_t(0)
-    _lib.call('pg_wino_v_elems', N, H, W, cin, ctypes.addressof(n))
-    v = torch.empty((int(n.value),), device=x.device, dtype=torch.float32)
-    _lib.call('pg_wino_transform_input_nhwc', _p(x), _p(v), N, H, W, cin, 1 if ups else 0, _stream())
-    return v
-
-
 def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2, ups=False, out=None,
                 pool=False, other=None, a=1.0, b=0.0, pool_only=False, unpool=False, upmask=None, up_mul=1.0, y_bytes=False,
-                signs_out=False, v_form=None, v=None):
+                signs_out=False):
     """3x3 pad-1 conv on Winograd-domain weights (+ the fused pool / unpool epilogues).  Returns y, (y, ypool) or yup.
-    uint8 ``mask`` / ``upmask`` are sign bytes; ``y_bytes`` (with ``pool``) returns the sign bytes of y instead of y.
-    ``v_form``: two-pass form (None: the built-in policy); ``v``: an already transformed input (wino_transform_input)."""
+    uint8 ``mask`` / ``upmask`` are sign bytes; ``y_bytes`` (with ``pool``) returns the sign bytes of y instead of y."""
     cout, cin = u.shape[1], u.shape[2]
     flags = (FLAG_UPSAMPLE if ups else 0) | (FLAG_MASK_BYTES if _is_bytes(mask) or _is_bytes(upmask) else 0) | (FLAG_Y_BYTES if y_bytes else 0)
     if y_bytes:
@@ -209,14 +183,8 @@ def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2
     if signs_out:                                  # plain forward launch: (y, sign bytes of y)
         sb = torch.empty((N, H, W, cout // 4), device=x.device, dtype=torch.uint8)
         mask, flags = sb, flags | FLAG_SIGNS_OUT
-    if v is not None or (v_form if v_form is not None else _wino_v_form(N, H, W, cin, cout)):
-        if v is None:
-            v = wino_transform_input(x, N, H, W, cin, ups=ups)
-        _lib.call('pg_conv2d_wino_v_nhwc', _p(v), _p(u), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
-                  _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, flags & ~FLAG_UPSAMPLE, scale, slope, mask_slope, _stream_with_workspace())
-    else:
-        _lib.call('pg_conv2d_wino_nhwc', _p(x), _p(u), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
-                  _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, flags, scale, slope, mask_slope, _stream_with_workspace())
+    _lib.call('pg_conv2d_wino_nhwc', _p(x), _p(u), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
+              _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, flags, scale, slope, mask_slope, _stream_with_workspace())
     if signs_out:
         return y, sb
     if pool:

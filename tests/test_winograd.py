@@ -161,43 +161,6 @@ def test_conv2d_wino_k_split(case, slices):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', [(9, 16, 256, 256, 0), (3, 32, 128, 160, 0), (2, 64, 64, 48, 0), (3, 8, 512, 512, 0), (1, 32, 48, 32, 1),
-                                  (5, 8, 32, 16, 0), (2, 16, 528, 512, 0), (3, 16, 128, 256, 1)])
-@pytest.mark.parametrize('ncb', [0, 1, 2])
-@pytest.mark.parametrize('slices', [-1, 1, 3])
-def test_conv2d_wino_v_form(monkeypatch, case, ncb, slices):
-    """Two-pass Winograd conv (pg_wino_transform_input_nhwc + pg_conv2d_wino_v_nhwc, csrc/conv_wino.hip conv_wino_v_kernel): the input
-    transform once per layer input, V private to a wave in registers.  Every fused epilogue against the torch restatement of the conv
-    contract (tests/emu_ops.py) with the form forced on every shape; 16 / 32 couts per workgroup; K slices; upsample in the
-    transform; channel counts that are not multiples of 32; more images than one tile block; and, unsliced, bit-identical to the
-    one-pass kernel (same arithmetic in the same order)."""
-    lib = pg._lib.load()
-    N, H, ci, co, ups = case
-    monkeypatch.setattr(pg.ops, 'WINO_V', 2)
-    assert lib.pg_debug_set_wino_v(ncb) == 0 and lib.pg_debug_set_wino_ksplit(slices) == 0
-    try:
-        _wino_kernel_case(case)
-        name = lib.pg_debug_last_wino_kernel().decode()
-        assert name.startswith('conv_wino_v_kernel<'), name
-        if ncb:
-            assert name.startswith('conv_wino_v_kernel<%d' % (ncb if co % 32 == 0 or ncb == 1 else 1)), name
-        hin = H // 2 if ups else H
-        x, b = rnd(N, hin, hin, ci).cuda(), rnd(co, seed=2).cuda()
-        u = pg.ops.wino_transform_weights((rnd(3, 3, co, ci, seed=1) * 0.2).cuda())
-        ys = [pg.ops.conv2d_wino(x, u, b, N, H, H, 0.37, 0.2, ups=bool(ups)) for _ in range(3)]
-        assert all(torch.equal(ys[0], y) for y in ys[1:])                 # (sliced: the sum does not depend on who arrives last)
-        if slices == 1:
-            lib.pg_debug_set_wino(20)                                     # one-pass tile kernel, unsliced
-            one = pg.ops.conv2d_wino(x, u, b, N, H, H, 0.37, 0.2, ups=bool(ups), v_form=False)
-            assert lib.pg_debug_last_wino_kernel().decode().startswith('conv_wino2_kernel<')
-            assert torch.equal(one, ys[0])
-    finally:
-        lib.pg_debug_set_wino_v(0)
-        lib.pg_debug_set_wino_ksplit(-1)
-        lib.pg_debug_set_wino(0)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize('shapes', [[(64, 32), (16, 48), (512, 512)], [(8, 16), (40, 8), (24, 136)]])
 def test_backward_data_form_straight_from_the_parameter(shapes):
     """pg_wino_transform_weights_batched(transposed): the Winograd form of the flipped / transposed weights computed from the forward
