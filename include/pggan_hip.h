@@ -315,6 +315,28 @@ int pg_mbstd_bwd(const float* gy, const float* x, const float* stats,
                  float* gx, int G, int n, int HW, int C, int CP, int apply_mask, float mask_slope,
                  pg_stream_t stream);
 
+/* Exact-global minibatch stddev under data parallelism (the optional mode; reference network.py:174-187 evaluated on the
+ * GLOBAL batch world x mb): every rank holds an equal shard of each group.  The two launches of pg_mbstd_fwd / pg_mbstd_tangent are
+ * separate entry points, so that the host exchanges the partial rows between them (a sum all-reduce of a zero-filled
+ * [nranks][G][PG_MBSTD_STATS_STRIDE] buffer in which every rank fills its own slice = an all-gather):
+ *   pg_mbstd_stats / pg_mbstd_tangent_stats   this shard's partials -> stats / tstats rows
+ *   pg_mbstd_write / pg_mbstd_tangent_write   merge the rows of all ranks (`gathered`, rank-major; NULL with nranks 1 = the local row), in rank
+ *                                             order on every rank (bit-identical mu / sigma everywhere), M = all shards; y / ty as above
+ *   pg_mbstd_gsum                             out[2g] = sum gy[..., C], out[2g+1] = sum gy_first[..., C] of this shard (either may be NULL)
+ *   pg_mbstd_bwd_global                       pg_mbstd_bwd with Gs / Gs1 taken from `gsums` (pg_mbstd_gsum summed over all ranks) and M = all shards */
+int pg_mbstd_stats(const float* x, float* stats, int G, int n, int HW, int C, pg_stream_t stream);
+int pg_mbstd_write(const float* x, float* y, float* stats, const float* gathered, int nranks,
+                   int G, int n, int HW, int C, int CP, pg_stream_t stream);
+int pg_mbstd_tangent_stats(const float* x, const float* tx, const float* stats, float* tstats,
+                           int G, int n, int HW, int C, pg_stream_t stream);
+int pg_mbstd_tangent_write(const float* tx, float* ty, float* tstats, const float* stats, const float* gathered, int nranks,
+                           int G, int n, int HW, int C, int CP, pg_stream_t stream);
+int pg_mbstd_gsum(const float* gy, const float* gy_first, float* out, int G, int n, int HW, int C, int CP, pg_stream_t stream);
+int pg_mbstd_bwd_global(const float* gy, const float* x, const float* stats,
+                        const float* tx, const float* tstats, const float* gy_first,
+                        float* gx, const float* gsums, int nranks,
+                        int G, int n, int HW, int C, int CP, int apply_mask, float mask_slope, pg_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Final nn.Linear(nf0, 1)  network.py:219,239.   s[n] = sum_c h[n,c]*w[c] + b                  */
 int pg_linear1_fwd(const float* h, const float* w, const float* b, float* s, int N, int C, pg_stream_t stream);

@@ -63,6 +63,12 @@ SIGNATURES = {
     'pg_mbstd_fwd': [P, P, P, I, I, I, I, I, P],
     'pg_mbstd_tangent': [P, P, P, P, P, I, I, I, I, I, P],
     'pg_mbstd_bwd': [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+    'pg_mbstd_stats': [P, P, I, I, I, I, P],
+    'pg_mbstd_write': [P, P, P, P, I, I, I, I, I, I, P],
+    'pg_mbstd_tangent_stats': [P, P, P, P, I, I, I, I, P],
+    'pg_mbstd_tangent_write': [P, P, P, P, P, I, I, I, I, I, I, P],
+    'pg_mbstd_gsum': [P, P, P, I, I, I, I, I, P],
+    'pg_mbstd_bwd_global': [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P],
     'pg_linear1_fwd': [P, P, P, P, I, I, P],
     'pg_linear1_bwd_data': [P, P, P, P, I, I, F, P],
     'pg_linear1_wgrad': [P, P, P, P, I, I, P],

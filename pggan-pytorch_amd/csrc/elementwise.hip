@@ -325,42 +325,54 @@ __global__ __launch_bounds__(256) void mbstd_stats_kernel(const float* __restric
     }
 }
 
-// Chan's pairwise merge of the partials, sequential and identical in every workgroup
-__device__ __forceinline__ void mb_merge(const float* __restrict__ row, float M, float& mu, float& sigma)
+// Chan's pairwise merge of the partials, sequential and identical in every workgroup.  Exact-global mode under data parallelism
+// (pg_mbstd_write with ``gathered``): the rows of every rank's shard of the group ([rank][group][MB_STRIDE], rank-major,
+// ``rstride`` floats between ranks) are merged in rank order -- the same order on every rank, so mu / sigma are bit-identical everywhere.
+__device__ __forceinline__ void mb_merge(const float* __restrict__ row, int nranks, size_t rstride, float M, float& mu, float& sigma)
 {
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int i = 0; i < MB_PARTS; ++i) {
-        const float c = row[2 + 4 * i], m = row[3 + 4 * i], q = row[4 + 4 * i];
-        if (c > 0.f) {
-            const float tot = cnt + c, d = m - mean;
-            mean += d * (c / tot);
-            m2 += q + d * d * (cnt * c / tot);
-            cnt = tot;
+    for (int r = 0; r < nranks; ++r) {
+        const float* pr = row + (size_t)r * rstride;
+        for (int i = 0; i < MB_PARTS; ++i) {
+            const float c = pr[2 + 4 * i], m = pr[3 + 4 * i], q = pr[4 + 4 * i];
+            if (c > 0.f) {
+                const float tot = cnt + c, d = m - mean;
+                mean += d * (c / tot);
+                m2 += q + d * d * (cnt * c / tot);
+                cnt = tot;
+            }
         }
     }
     mu = mean;
     sigma = sqrtf(m2 / M + 1.0e-8f);
 }
 
+// ``gathered`` (exact-global mode): the partial rows of all ``nranks`` shards, [rank][G][MB_STRIDE]; null: this rank's row alone.  M below is
+// the element count of the WHOLE group (all shards: equal shard sizes, checked by the host side).
 template <bool TANGENT>
 __global__ __launch_bounds__(256) void mbstd_write_kernel(const float* __restrict__ src, float* __restrict__ y,
                                                           float* __restrict__ stats, const float* __restrict__ xstats,
+                                                          const float* __restrict__ gathered, int nranks,
                                                           int n, int HW, int C, int CP)
 {
     const int g = blockIdx.y;
     const size_t rows = (size_t)n * HW;
     const size_t M = rows * C;
+    const float Mg = (float)M * (float)nranks;
     float* row = stats + (size_t)g * MB_STRIDE;
+    const float* src_rows = gathered ? gathered + (size_t)g * MB_STRIDE : row;
+    const size_t rstride = (size_t)gridDim.y * MB_STRIDE;
     float extra;                                             // value of channel C
     if (!TANGENT) {
-        float mu, sigma; mb_merge(row, (float)M, mu, sigma);
+        float mu, sigma; mb_merge(src_rows, gathered ? nranks : 1, rstride, Mg, mu, sigma);
         if (blockIdx.x == 0 && threadIdx.x == 0) { row[0] = mu; row[1] = sigma; }
         extra = sigma;
     } else {
         float ts = 0.f, dot = 0.f;
-        for (int i = 0; i < MB_PARTS; ++i) { ts += row[2 + 4 * i]; dot += row[3 + 4 * i]; }
-        if (blockIdx.x == 0 && threadIdx.x == 0) { row[0] = ts / (float)M; row[1] = dot; }
-        extra = dot / ((float)M * xstats[(size_t)g * MB_STRIDE + 1]);
+        for (int r = 0; r < (gathered ? nranks : 1); ++r)
+            for (int i = 0; i < MB_PARTS; ++i) { ts += src_rows[r * rstride + 2 + 4 * i]; dot += src_rows[r * rstride + 3 + 4 * i]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { row[0] = ts / Mg; row[1] = dot; }
+        extra = dot / (Mg * xstats[(size_t)g * MB_STRIDE + 1]);
     }
     const int C4 = C >> 2, CP4 = CP >> 2;
     const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)g * M);
@@ -407,27 +419,31 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ stats, const float* __restrict__ tx,
                                                         const float* __restrict__ tstats, const float* __restrict__ gy_first,
                                                         float* __restrict__ gx, int n, int HW, int C, int CP,
-                                                        int apply_mask, float mask_slope)
+                                                        int apply_mask, float mask_slope,
+                                                        const float* __restrict__ gsums, int nranks)
 {
     __shared__ float sh[16];
     const int g = blockIdx.y;
     const size_t rows = (size_t)n * HW;
     const size_t M = rows * C;
     const float mu = stats[(size_t)g * MB_STRIDE], sigma = stats[(size_t)g * MB_STRIDE + 1];
-    // Gs over the (few hundred) rows: recomputed by every workgroup, same order -> same value
+    // Gs over the (few hundred) rows: recomputed by every workgroup, same order -> same value.  Exact-global mode: ``gsums`` =
+    // {Gs, Gs1} of the group summed over all shards (pg_mbstd_gsum + a sum all-reduce), M counts all shards.
     float gs = 0.f, gs1 = 0.f;
-    if (gy) for (size_t r = threadIdx.x; r < rows; r += 256) gs += gy[((size_t)g * rows + r) * CP + C];
-    if (tx) for (size_t r = threadIdx.x; r < rows; r += 256) gs1 += gy_first[((size_t)g * rows + r) * CP + C];
-    const float Gs = gy ? block_sum(gs, sh) : 0.f;
-    const float Gs1 = tx ? block_sum(gs1, sh) : 0.f;
-    const float invMs = 1.f / ((float)M * sigma);
+    if (!gsums) {
+        if (gy) for (size_t r = threadIdx.x; r < rows; r += 256) gs += gy[((size_t)g * rows + r) * CP + C];
+        if (tx) for (size_t r = threadIdx.x; r < rows; r += 256) gs1 += gy_first[((size_t)g * rows + r) * CP + C];
+    }
+    const float Gs = gsums ? (gy ? gsums[2 * g] : 0.f) : (gy ? block_sum(gs, sh) : 0.f);
+    const float Gs1 = gsums ? (tx ? gsums[2 * g + 1] : 0.f) : (tx ? block_sum(gs1, sh) : 0.f);
+    const float invMs = 1.f / ((float)M * (float)nranks * sigma);
     const float k1 = Gs * invMs;
     float tmean = 0.f, k2 = 0.f, k3 = 0.f;
     if (tx) {
         tmean = tstats[(size_t)g * MB_STRIDE];
         const float dot = tstats[(size_t)g * MB_STRIDE + 1];
         k2 = Gs1 * invMs;                                   // multiplies (tx - mean tx)
-        k3 = k2 * dot / ((float)M * sigma * sigma);         // multiplies (x - mu)
+        k3 = k2 * dot / ((float)M * (float)nranks * sigma * sigma);         // multiplies (x - mu)
     }
     const int C4 = C >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)g * M);
@@ -447,6 +463,21 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float* __restrict_
         if (apply_mask) v = mask4(v, xv, mask_slope);
         o4[i] = v;
     }
+}
+
+// local {sum over rows of gy[.., C], of gy_first[.., C]} per group (exact-global mode: all-reduced, then handed to mbstd_bwd_kernel)
+__global__ __launch_bounds__(256) void mbstd_gsum_kernel(const float* __restrict__ gy, const float* __restrict__ gy_first,
+                                                         float* __restrict__ out, int n, int HW, int C, int CP)
+{
+    __shared__ float sh[16];
+    const int g = blockIdx.x;
+    const size_t rows = (size_t)n * HW;
+    float a = 0.f, b = 0.f;
+    if (gy) for (size_t r = threadIdx.x; r < rows; r += 256) a += gy[((size_t)g * rows + r) * CP + C];
+    if (gy_first) for (size_t r = threadIdx.x; r < rows; r += 256) b += gy_first[((size_t)g * rows + r) * CP + C];
+    a = block_sum(a, sh);
+    b = block_sum(b, sh);
+    if (threadIdx.x == 0) { out[2 * g] = a; out[2 * g + 1] = b; }
 }
 
 // ----------------------------------------------------------------------------------- Linear(C,1)
@@ -735,8 +766,61 @@ extern "C" int pg_mbstd_fwd(const float* x, float* y, float* stats, int G, int n
     if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(mbstd_stats_kernel, dim3(MB_PARTS, G), dim3(256), 0, s, x, stats, n, HW, C);
-    hipLaunchKernelGGL(mbstd_write_kernel<false>, dim3(MB_PARTS, G), dim3(256), 0, s, x, y, stats, (const float*)nullptr, n, HW, C, CP);
+    hipLaunchKernelGGL(mbstd_write_kernel<false>, dim3(MB_PARTS, G), dim3(256), 0, s, x, y, stats, (const float*)nullptr, (const float*)nullptr, 1, n, HW, C, CP);
     return (int)hipGetLastError();
+}
+
+// ---- exact-global minibatch stddev under data parallelism (optional mode): the two launches of pg_mbstd_fwd /
+// pg_mbstd_tangent as separate entry points, so that the host can exchange the partial rows between them
+extern "C" int pg_mbstd_stats(const float* x, float* stats, int G, int n, int HW, int C, pg_stream_t stream)
+{
+    if (!x || !stats || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    LAUNCH(mbstd_stats_kernel, dim3(MB_PARTS, G), dim3(256), 0, stream, x, stats, n, HW, C);
+}
+
+extern "C" int pg_mbstd_write(const float* x, float* y, float* stats, const float* gathered, int nranks,
+                              int G, int n, int HW, int C, int CP, pg_stream_t stream)
+{
+    if (!x || !y || !stats || G <= 0 || n <= 0 || HW <= 0 || nranks < 1 || (nranks > 1 && !gathered)) return PG_E_ARG;
+    if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
+    LAUNCH(mbstd_write_kernel<false>, dim3(MB_PARTS, G), dim3(256), 0, stream, x, y, stats, (const float*)nullptr, gathered, nranks, n, HW, C, CP);
+}
+
+extern "C" int pg_mbstd_tangent_stats(const float* x, const float* tx, const float* stats, float* tstats,
+                                      int G, int n, int HW, int C, pg_stream_t stream)
+{
+    if (!x || !tx || !stats || !tstats || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
+    if (C & 3) return PG_E_ALIGN;
+    LAUNCH(mbstd_tangent_stats_kernel, dim3(MB_PARTS, G), dim3(256), 0, stream, x, tx, stats, tstats, n, HW, C);
+}
+
+extern "C" int pg_mbstd_tangent_write(const float* tx, float* ty, float* tstats, const float* stats, const float* gathered, int nranks,
+                                      int G, int n, int HW, int C, int CP, pg_stream_t stream)
+{
+    if (!tx || !ty || !tstats || !stats || G <= 0 || n <= 0 || HW <= 0 || nranks < 1 || (nranks > 1 && !gathered)) return PG_E_ARG;
+    if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
+    LAUNCH(mbstd_write_kernel<true>, dim3(MB_PARTS, G), dim3(256), 0, stream, tx, ty, tstats, stats, gathered, nranks, n, HW, C, CP);
+}
+
+extern "C" int pg_mbstd_gsum(const float* gy, const float* gy_first, float* out, int G, int n, int HW, int C, int CP, pg_stream_t stream)
+{
+    if (!out || (!gy && !gy_first) || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
+    if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
+    LAUNCH(mbstd_gsum_kernel, dim3(G), dim3(256), 0, stream, gy, gy_first, out, n, HW, C, CP);
+}
+
+extern "C" int pg_mbstd_bwd_global(const float* gy, const float* x, const float* stats,
+                                   const float* tx, const float* tstats, const float* gy_first,
+                                   float* gx, const float* gsums, int nranks,
+                                   int G, int n, int HW, int C, int CP, int apply_mask, float mask_slope, pg_stream_t stream)
+{
+    if (!x || !stats || !gx || !gsums || nranks < 1 || G <= 0 || n <= 0 || HW <= 0) return PG_E_ARG;
+    if (!gy && !tx) return PG_E_ARG;
+    if (tx && (!tstats || !gy_first)) return PG_E_ARG;
+    if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
+    LAUNCH(mbstd_bwd_kernel, dim3(MB_PARTS, G), dim3(256), 0, stream, gy, x, stats, tx, tstats, gy_first, gx, n, HW, C, CP, apply_mask, mask_slope,
+           gsums, nranks);
 }
 
 extern "C" int pg_mbstd_tangent(const float* x, const float* tx, const float* stats, float* ty, float* tstats,
@@ -746,7 +830,7 @@ extern "C" int pg_mbstd_tangent(const float* x, const float* tx, const float* st
     if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(mbstd_tangent_stats_kernel, dim3(MB_PARTS, G), dim3(256), 0, s, x, tx, stats, tstats, n, HW, C);
-    hipLaunchKernelGGL(mbstd_write_kernel<true>, dim3(MB_PARTS, G), dim3(256), 0, s, tx, ty, tstats, stats, n, HW, C, CP);
+    hipLaunchKernelGGL(mbstd_write_kernel<true>, dim3(MB_PARTS, G), dim3(256), 0, s, tx, ty, tstats, stats, (const float*)nullptr, 1, n, HW, C, CP);
     return (int)hipGetLastError();
 }
 
@@ -759,7 +843,8 @@ extern "C" int pg_mbstd_bwd(const float* gy, const float* x, const float* stats,
     if (!gy && !tx) return PG_E_ARG;
     if (tx && (!tstats || !gy_first)) return PG_E_ARG;
     if ((C & 3) || (CP & 3) || CP < C + 4) return PG_E_ALIGN;
-    LAUNCH(mbstd_bwd_kernel, dim3(MB_PARTS, G), dim3(256), 0, stream, gy, x, stats, tx, tstats, gy_first, gx, n, HW, C, CP, apply_mask, mask_slope);
+    LAUNCH(mbstd_bwd_kernel, dim3(MB_PARTS, G), dim3(256), 0, stream, gy, x, stats, tx, tstats, gy_first, gx, n, HW, C, CP, apply_mask, mask_slope,
+           (const float*)nullptr, 1);
 }
 
 extern "C" int pg_linear1_fwd(const float* h, const float* w, const float* b, float* s, int N, int C, pg_stream_t stream)

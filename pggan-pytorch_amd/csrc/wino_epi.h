@@ -165,6 +165,11 @@ template <int EPI>
 __device__ __forceinline__ void wino_epilogue_fast(const WinoP& p, const f32x4 (&yq)[4], int cb, int ni, int oy0, int ox0)
 {
     static_assert(EPI == EPI_PLAIN || EPI == EPI_MASKB, "specialised epilogues");
+    // The 16 tiles of a wave lie in ONE image (a tile block holds >= 16 tiles of each of its images), so the image index is
+    // wave-uniform: saying so keeps the per-image buffer descriptors in SGPRs.  (Left as a per-lane value hipcc wrapped every buffer
+    // load / store of this epilogue in a waterfall loop -- readfirstlane x4, compare, saveexec, branch: ~12 instructions around each of
+    // the 4 stores and 4 byte loads.)
+    ni = __builtin_amdgcn_readfirstlane(ni);
     if (cb >= p.Cout || ni >= p.N) return;
     const unsigned npix = (unsigned)(p.H * p.W);
     const __amdgpu_buffer_rsrc_t ry = pg_make_rsrc(p.y + (size_t)ni * npix * p.Cout, npix * (unsigned)p.Cout * 4u);

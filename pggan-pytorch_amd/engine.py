@@ -593,6 +593,43 @@ def generator_backward(G, ctx, g_out):
 
 
 # ------------------------------------------------------------------------------------------
+# Minibatch stddev: local-shard (default) or exact-global under data parallelism
+# ------------------------------------------------------------------------------------------
+# Default under data parallelism: every rank evaluates reference network.py:174-187 on its OWN minibatch (per-rank parity
+# with the single-GPU reference at batch mb is exact).  ``Trainer(parallel=dp, global_stddev=True)`` switches to the exact-global mode:
+# the one scalar a group's statistic is (and the three scalars its adjoint / Hessian-vector term need: G_sigma, <v, x - mu>, mean v) are
+# reduced over all ranks, so world x mb equals one process at batch world * mb.  The collectives are a few floats each on the main
+# stream, in the same order on every rank; steps are launched eagerly in this mode (wgan_gp_loss: no hipGraph / launch plan).
+def _mb_dp(D):
+    return D.__dict__.get('_global_stddev')
+
+
+def _mbstd_fwd(D, x, groups, cp):
+    dp = _mb_dp(D)
+    if dp is None:
+        return ops.mbstd_fwd(x, groups, cp)
+    st = ops.mbstd_stats(x, groups)
+    return ops.mbstd_write(x, st, dp.all_gather_rows(st), cp)
+
+
+def _mbstd_tangent(D, x, tx, stats, cp):
+    dp = _mb_dp(D)
+    if dp is None:
+        return ops.mbstd_tangent(x, tx, stats, cp)
+    ts = ops.mbstd_tangent_stats(x, tx, stats)
+    return ops.mbstd_tangent_write(tx, ts, dp.all_gather_rows(ts), stats, cp)
+
+
+def _mbstd_bwd(D, gy, x, stats, cp, apply_mask, mask_slope, tx=None, tstats=None, gy_first=None, out=None):
+    dp = _mb_dp(D)
+    if dp is None:
+        return ops.mbstd_bwd(gy, x, stats, cp, apply_mask, mask_slope, tx=tx, tstats=tstats, gy_first=gy_first, out=out)
+    gs = ops.mbstd_gsum(gy, gy_first if tx is not None else None, stats.shape[0], tuple(x.shape), cp)
+    dp.all_reduce_flat(gs.view(-1))
+    return ops.mbstd_bwd_global(gy, x, stats, cp, apply_mask, gs, dp.world_size, mask_slope, tx=tx, tstats=tstats, gy_first=gy_first, out=out)
+
+
+# ------------------------------------------------------------------------------------------
 # Discriminator
 # ------------------------------------------------------------------------------------------
 def d_forward(D, x, groups=1):
@@ -625,7 +662,7 @@ def d_forward(D, x, groups=1):
         if k == 0 and curb is not None:
             rec['inpb'] = curb
         if last:
-            mb, stats = ops.mbstd_fwd(cur, groups, blk.c1.cin_store)          # :168
+            mb, stats = _mbstd_fwd(D, cur, groups, blk.c1.cin_store)          # :168
             a1 = _conv(mb, blk.c1, NB, H)
             if pn:
                 a1, rec['r1'] = ops.pixelnorm_fwd(a1, inplace=True)
@@ -723,14 +760,14 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             gmb = _dgrad(D, gz1, c1, nh, H)                                   # [nh,4,4,CP]
             cp = c1.cin_store
             if hvp is None:
-                gin = ops.mbstd_bwd(gmb, inp, rec['stats'], cp, rec['first'], fr_slope)
+                gin = _mbstd_bwd(D, gmb, inp, rec['stats'], cp, rec['first'], fr_slope)
             else:
                 _, tx, tstats, gy_first = hvp
                 gin = torch.empty_like(inp)
                 ng = rec['stats'].shape[0] - 1
-                ops.mbstd_bwd(gmb, inp[:nh], rec['stats'][:ng], cp, rec['first'], fr_slope, out=gin[:nh])
-                ops.mbstd_bwd(None, inp[nh:], rec['stats'][ng:], cp, rec['first'], fr_slope,
-                              tx=tx, tstats=tstats, gy_first=gy_first, out=gin[nh:])
+                _mbstd_bwd(D, gmb, inp[:nh], rec['stats'][:ng], cp, rec['first'], fr_slope, out=gin[:nh])
+                _mbstd_bwd(D, None, inp[nh:], rec['stats'][ng:], cp, rec['first'], fr_slope,
+                           tx=tx, tstats=tstats, gy_first=gy_first, out=gin[nh:])
             if save_adjoints:
                 adj[idx].update(gz2=gz2, gz1=gz1, gmb=gmb)
         else:
@@ -894,14 +931,14 @@ def _d_backward_pn(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=Non
             gmb = _dgrad(D, gz1, c1, NB, H)                                   # [NB,4,4,CP]
             cp = c1.cin_store
             if hvp is None:
-                gin = ops.mbstd_bwd(gmb, inp, rec['stats'], cp, rec['first'], fr_slope)
+                gin = _mbstd_bwd(D, gmb, inp, rec['stats'], cp, rec['first'], fr_slope)
             else:
                 _, tx, tstats, gy_first = hvp[:4]
                 gin = torch.empty_like(inp)
                 ng = rec['stats'].shape[0] - 1
-                ops.mbstd_bwd(gmb[:nh], inp[:nh], rec['stats'][:ng], cp, rec['first'], fr_slope, out=gin[:nh])
-                ops.mbstd_bwd(gmb[nh:], inp[nh:], rec['stats'][ng:], cp, rec['first'], fr_slope,
-                              tx=tx, tstats=tstats, gy_first=gy_first, out=gin[nh:])
+                _mbstd_bwd(D, gmb[:nh], inp[:nh], rec['stats'][:ng], cp, rec['first'], fr_slope, out=gin[:nh])
+                _mbstd_bwd(D, gmb[nh:], inp[nh:], rec['stats'][ng:], cp, rec['first'], fr_slope,
+                           tx=tx, tstats=tstats, gy_first=gy_first, out=gin[nh:])
             if save_adjoints:
                 adj[idx].update(gz2=gz2, gz1=gz1, gmb=gmb)
         else:
@@ -974,7 +1011,7 @@ def d_tangent_wgrad(D, sub, adj, u):
         blk, H = rec['blk'], rec['H']
         c1, c2 = blk.c1, blk.c2
         if rec['last']:
-            tmb, tstats = ops.mbstd_tangent(rec['inp'], cur, rec['stats'], c1.cin_store)
+            tmb, tstats = _mbstd_tangent(D, rec['inp'], cur, rec['stats'], c1.cin_store)
             hvp = (cur, tstats, adj[idx]['gmb'])
             _wgrad(tmb, adj[idx]['gz1'], c1, N, H, bias=False, defer=True)
             t1 = _conv(tmb, c1, N, H, mask=rec['a1'], bias=False)

@@ -464,6 +464,59 @@ def mbstd_bwd(gy, x, stats, cp, apply_mask, mask_slope=0.2, tx=None, tstats=None
     return gx
 
 
+# exact-global mode under data parallelism (engine._mbstd_*: the partial rows / Gs sums travel between these calls)
+def mbstd_stats(x, groups):
+    NB, H, W, C = x.shape
+    stats = torch.empty((groups, MBSTD_STATS_STRIDE), device=x.device, dtype=torch.float32)
+    _lib.call('pg_mbstd_stats', _p(x), _p(stats), groups, NB // groups, H * W, C, _stream())
+    return stats
+
+
+def mbstd_write(x, stats, gathered, cp):
+    """``gathered``: [nranks, groups, MBSTD_STATS_STRIDE] partial rows of all ranks (rank-major).  Returns (y, stats) with mu / sigma of the
+    whole group (all shards) in stats[:, 0:2]."""
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    y = torch.empty((NB, H, W, cp), device=x.device, dtype=torch.float32)
+    _lib.call('pg_mbstd_write', _p(x), _p(y), _p(stats), _p(gathered), gathered.shape[0], groups, NB // groups, H * W, C, cp, _stream())
+    return y, stats
+
+
+def mbstd_tangent_stats(x, tx, stats):
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    tstats = torch.empty((groups, MBSTD_STATS_STRIDE), device=x.device, dtype=torch.float32)
+    _lib.call('pg_mbstd_tangent_stats', _p(x), _p(tx), _p(stats), _p(tstats), groups, NB // groups, H * W, C, _stream())
+    return tstats
+
+
+def mbstd_tangent_write(tx, tstats, gathered, stats, cp):
+    NB, H, W, C = tx.shape
+    groups = stats.shape[0]
+    ty = torch.empty((NB, H, W, cp), device=tx.device, dtype=torch.float32)
+    _lib.call('pg_mbstd_tangent_write', _p(tx), _p(ty), _p(tstats), _p(stats), _p(gathered), gathered.shape[0], groups, NB // groups, H * W, C, cp,
+              _stream())
+    return ty, tstats
+
+
+def mbstd_gsum(gy, gy_first, groups, shape, cp):
+    """[groups, 2]: this shard's sums of the stddev channel of ``gy`` / ``gy_first`` ([NB,H,W,cp]; either may be None)."""
+    NB, H, W, C = shape
+    ref = gy if gy is not None else gy_first
+    out = torch.zeros((groups, 2), device=ref.device, dtype=torch.float32)
+    _lib.call('pg_mbstd_gsum', _p(gy), _p(gy_first), _p(out), groups, NB // groups, H * W, C, cp, _stream())
+    return out
+
+
+def mbstd_bwd_global(gy, x, stats, cp, apply_mask, gsums, nranks, mask_slope=0.2, tx=None, tstats=None, gy_first=None, out=None):
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    gx = out if out is not None else torch.empty_like(x)
+    _lib.call('pg_mbstd_bwd_global', _p(gy), _p(x), _p(stats), _p(tx), _p(tstats), _p(gy_first), _p(gx), _p(gsums), nranks, groups,
+              NB // groups, H * W, C, cp, 1 if apply_mask else 0, mask_slope, _stream())
+    return gx
+
+
 # ------------------------------------------------------------------------------------- linear
 def linear1_fwd(h, w, b):
     N, C = h.shape[0], h.numel() // h.shape[0]

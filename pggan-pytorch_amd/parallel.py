@@ -163,12 +163,23 @@ class DataParallel(object):
             from . import _lib
             if flat.dtype != torch.float32 or not flat.is_contiguous():
                 raise RuntimeError('all_reduce_flat expects a contiguous float32 buffer')
+            if flat.numel() == 0:
+                return flat
             s = stream if stream is not None else torch.cuda.current_stream()
             _lib.call('pg_allreduce_sum_f32', self.comm, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
                       ctypes.c_void_p(s.cuda_stream))
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         return flat
+
+    def all_gather_rows(self, rows):
+        """[world, *rows.shape]: every rank's ``rows`` (a small statistics tensor), rank-major, identical on all ranks: a SUM all-reduce of a
+        zero-filled buffer in which each rank fills its own slice (x + 0 is exact, so this IS an all-gather; one collective primitive in the
+        C-ABI).  Current stream."""
+        buf = torch.zeros((self.world_size,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
+        buf[self.rank].copy_(rows)
+        self.all_reduce_flat(buf.view(-1))
+        return buf
 
     def all_reduce_grads(self, net, average=False):
         """Exchange of one network's gradients.  The parameters whose ``.grad`` the backward pass attached (a function of

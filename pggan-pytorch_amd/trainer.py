@@ -12,6 +12,9 @@ MI355X data-parallel additions (optional, default off):
     are sum-all-reduced over RCCL on the flat gradient buffers, ``cur_nimg`` advances by ``world_size * minibatch``
     so the depth/alpha schedule stays a pure function of the images shown, and the optimizers' gradient pre-scale is
     set to 1/world_size here (a plain ``torch.optim`` optimizer gets averaged gradients from the all-reduce instead);
+  * ``global_stddev=True`` (with ``parallel``): exact-global minibatch stddev -- the statistic of reference network.py:174-187 and the scalars
+    of its adjoint / Hessian-vector term are reduced over all ranks, so world x minibatch equals one process at batch world * minibatch
+    (default: every rank's own minibatch, SURVEY.md §8e);
   * host inputs are moved to the device (the reference's ``.cuda()`` calls)."""
 import heapq
 import os
@@ -133,7 +136,7 @@ class Trainer(object):
 
     def __init__(self, D, G, D_loss, G_loss, optimizer_d, optimizer_g, dataset, dataiter, random_latents_generator,
                  D_training_repeats=1, tick_nimg_default=2 * 1000, resume_nimg=0, parallel=None, input_transform=None,
-                 prefetch_inputs=False):
+                 prefetch_inputs=False, global_stddev=False):
         # networks, losses, optimizers, data sources: the names are API (plugins read and replace them)
         self.D, self.G = D, G
         self.D_loss, self.G_loss = D_loss, G_loss
@@ -162,6 +165,11 @@ class Trainer(object):
         # plugins.TimeMonitor: {'every': k, 'pairs': [(start event, end event), ...]} -- every k-th iteration the last D update
         # (D loss + gradient penalty + backward + exchange + Adam(D)) is bracketed with two HIP events; read at tick boundaries
         self.d_step_probe = None
+        if global_stddev and parallel is None:
+            raise ValueError('global_stddev=True needs parallel= (the exact-global minibatch stddev is a data-parallel mode)')
+        if parallel is not None and hasattr(D, '_flat_param'):
+            # minibatch stddev under data parallelism: local-shard statistics by default, exact-global on request
+            D._global_stddev = parallel if global_stddev else None
         if parallel is not None:
             from . import wgan_gp_loss
             wgan_gp_loss.enable_plans(False)         # the bucketed exchange hooks into the eager backward sweep

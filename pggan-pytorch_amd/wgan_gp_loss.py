@@ -144,7 +144,8 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
         mixing_factors = None
     else:                                                                # :15-17 (device RNG)
         mix = _draw_mixing_factors(n, real_images_in.device)
-    mode = _replay_mode(D) if (float(D.alpha) >= 1.0 and real_images_in.is_cuda and hasattr(D, '_flat_param')) else None
+    mode = _replay_mode(D) if (float(D.alpha) >= 1.0 and real_images_in.is_cuda and hasattr(D, '_flat_param')
+                               and D.__dict__.get('_global_stddev') is None) else None      # (exact-global stddev: collectives inside the step -> eager)
     if mode is not None:
         from . import graphs, plans
         real_c = engine._check_dev(real_images_in, 'real images')
@@ -166,7 +167,8 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
 def wgan_gp_G_loss(G, D, fake_latents_in):
     """reference wgan_gp_loss.py:68-74."""
     G.zero_grad()                                                        # :69
-    mode = _replay_mode(G) if (float(G.alpha) >= 1.0 and fake_latents_in.is_cuda and hasattr(G, '_flat_param')) else None
+    mode = _replay_mode(G) if (float(G.alpha) >= 1.0 and fake_latents_in.is_cuda and hasattr(G, '_flat_param')
+                               and D.__dict__.get('_global_stddev') is None) else None
     if mode is not None:
         from . import graphs, plans
         g_cost = (graphs if mode == 'graph' else plans).g_step(G, D, engine._check_dev(fake_latents_in, 'latents'))

@@ -339,6 +339,95 @@ def mbstd_fwd(x, groups, cp):
     return y, stats
 
 
+# ---- exact-global mode (the host side's view of pg_mbstd_stats / _write / _tangent_stats / _tangent_write / _gsum / _bwd_global): a
+# partial row is [mu, sigma, count, sum, sum of squares] resp. [mean tx, dot, sum tx, dot] -- the emulation keeps the interface, not the layout
+def mbstd_stats(x, groups):
+    NB = x.shape[0]
+    n = NB // groups
+    st = torch.zeros((groups, 8), dtype=torch.float64)
+    for g in range(groups):
+        xg = x[g * n:(g + 1) * n].double()
+        st[g, 2], st[g, 3], st[g, 4] = xg.numel(), xg.sum(), (xg * xg).sum()
+    return st
+
+
+def mbstd_write(x, stats, gathered, cp):
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    n = NB // groups
+    y = torch.zeros((NB, H, W, cp))
+    y[..., :C] = x
+    tot = gathered.double().sum(dim=0)
+    out = torch.zeros((groups, 8), dtype=torch.float64)
+    for g in range(groups):
+        M, sx, sxx = tot[g, 2], tot[g, 3], tot[g, 4]
+        mu = sx / M
+        sigma = torch.sqrt(torch.clamp(sxx / M - mu * mu, min=0.0) + 1e-8)
+        out[g, 0], out[g, 1], out[g, 2] = mu, sigma, M
+        y[g * n:(g + 1) * n, :, :, C] = sigma.float()
+    return y, out
+
+
+def mbstd_tangent_stats(x, tx, stats):
+    NB = x.shape[0]
+    groups = stats.shape[0]
+    n = NB // groups
+    ts = torch.zeros((groups, 8), dtype=torch.float64)
+    for g in range(groups):
+        xg, tg = x[g * n:(g + 1) * n].double(), tx[g * n:(g + 1) * n].double()
+        ts[g, 2], ts[g, 3] = tg.sum(), ((xg - stats[g, 0]) * tg).sum()
+    return ts
+
+
+def mbstd_tangent_write(tx, tstats, gathered, stats, cp):
+    NB, H, W, C = tx.shape
+    groups = stats.shape[0]
+    n = NB // groups
+    ty = torch.zeros((NB, H, W, cp))
+    ty[..., :C] = tx
+    tot = gathered.double().sum(dim=0)
+    out = torch.zeros((groups, 8), dtype=torch.float64)
+    for g in range(groups):
+        M, sigma = stats[g, 2], stats[g, 1]
+        out[g, 0], out[g, 1] = tot[g, 2] / M, tot[g, 3]
+        ty[g * n:(g + 1) * n, :, :, C] = (tot[g, 3] / (M * sigma)).float()
+    return ty, out
+
+
+def mbstd_gsum(gy, gy_first, groups, shape, cp):
+    NB, H, W, C = shape
+    n = NB // groups
+    out = torch.zeros((groups, 2), dtype=torch.float64)
+    for g in range(groups):
+        if gy is not None:
+            out[g, 0] = gy[g * n:(g + 1) * n][..., C].double().sum()
+        if gy_first is not None:
+            out[g, 1] = gy_first[g * n:(g + 1) * n][..., C].double().sum()
+    return out
+
+
+def mbstd_bwd_global(gy, x, stats, cp, apply_mask, gsums, nranks, mask_slope=0.2, tx=None, tstats=None, gy_first=None, out=None):
+    NB, H, W, C = x.shape
+    groups = stats.shape[0]
+    n = NB // groups
+    gx = torch.zeros_like(x)
+    for g in range(groups):
+        sl = slice(g * n, (g + 1) * n)
+        xg = x[sl].double()
+        mu, sigma, M = stats[g, 0], stats[g, 1], stats[g, 2]
+        v = torch.zeros_like(xg)
+        if gy is not None:
+            v = gy[sl][..., :C].double() + gsums[g, 0] * (xg - mu) / (M * sigma)
+        if tx is not None:
+            tmean, dot = tstats[g, 0], tstats[g, 1]
+            v = v + gsums[g, 1] / (M * sigma) * ((tx[sl].double() - tmean) - (xg - mu) * dot / (M * sigma * sigma))
+        v = v.float()
+        if apply_mask:
+            v = _maskmul(v, x[sl], mask_slope)
+        gx[sl] = v
+    return _ret(gx, out)
+
+
 def mbstd_tangent(x, tx, stats, cp):
     NB, H, W, C = x.shape
     groups = stats.shape[0]

@@ -298,6 +298,48 @@ def test_pixelnorm(P, C):
     check('lrelu-only bwd', ops.pixelnorm_lrelu_bwd(dev(gy), y, None, 0.2), E.pixelnorm_lrelu_bwd(gy, ry, None, 0.2))
 
 
+@pytest.mark.parametrize('G,n,C,world', [(1, 4, 16, 2), (3, 2, 512, 3), (3, 16, 512, 2), (2, 6, 32, 3)])
+def test_mbstd_exact_global_mode(G, n, C, world):
+    """The exact-global minibatch stddev entry points (pg_mbstd_stats / _write / _tangent_stats / _tangent_write / _gsum / _bwd_global,
+    SURVEY.md §8e optional mode) with the ranks of a data-parallel group played by slices of one batch on one device: every "rank" holds
+    n / world images of each group, the partial rows are stacked rank-major as the all-gather would, the Gs sums are added as the
+    all-reduce would -- and forward, tangent, adjoint and Hessian-vector term of every shard must equal the single-process kernels (and
+    the torch statement) on the whole batch."""
+    cp = C + 16
+    per = n // world
+    x = rnd(G * n, 4, 4, C) + 0.3
+    tx = rnd(G * n, 4, 4, C, seed=1)
+    gy, gf = rnd(G * n, 4, 4, cp, seed=2), rnd(G * n, 4, 4, cp, seed=3)
+    idx = [torch.cat([torch.arange(g * n + r * per, g * n + (r + 1) * per) for g in range(G)]) for r in range(world)]   # shard r: its slice of EVERY group
+    xs, txs, gys, gfs = ([dev(t[i]) for i in idx] for t in (x, tx, gy, gf))
+    ry, rst = E.mbstd_fwd(x, G, cp)
+    rty, rts = E.mbstd_tangent(x, tx, rst, cp)
+    parts = [ops.mbstd_stats(xr, G) for xr in xs]
+    gathered = torch.stack(parts).contiguous()
+    outs = [ops.mbstd_write(xr, parts[r].clone(), gathered, cp) for r, xr in enumerate(xs)]
+    for r in range(world):
+        check('global mbstd fwd, shard %d' % r, outs[r][0], ry[idx[r]])
+        check('global mbstd stats, shard %d' % r, outs[r][1][:, :2], rst)
+        assert torch.equal(outs[r][1][:, :2], outs[0][1][:, :2])                 # bit-identical mu / sigma on every rank
+    stats = [o[1] for o in outs]
+    tparts = [ops.mbstd_tangent_stats(xs[r], txs[r], stats[r]) for r in range(world)]
+    tgath = torch.stack(tparts).contiguous()
+    touts = [ops.mbstd_tangent_write(txs[r], tparts[r].clone(), tgath, stats[r], cp) for r in range(world)]
+    for r in range(world):
+        check('global mbstd tangent, shard %d' % r, touts[r][0], rty[idx[r]], 1e-4)
+        check('global mbstd tstats, shard %d' % r, touts[r][1][:, :2], rts, 1e-4)
+    for am in (False, True):
+        for use_gy, use_tx in ((True, False), (True, True), (False, True)):
+            gsum = sum(ops.mbstd_gsum(gys[r] if use_gy else None, gfs[r] if use_tx else None, G, tuple(xs[r].shape), cp) for r in range(world))
+            ref = E.mbstd_bwd(gy if use_gy else None, x, rst, cp, am, 0.2, tx=tx if use_tx else None, tstats=rts if use_tx else None,
+                              gy_first=gf if use_tx else None)
+            for r in range(world):
+                got = ops.mbstd_bwd_global(gys[r] if use_gy else None, xs[r], stats[r], cp, am, gsum, world, 0.2,
+                                           tx=txs[r] if use_tx else None, tstats=touts[r][1] if use_tx else None,
+                                           gy_first=gfs[r] if use_tx else None)
+                check('global mbstd bwd mask=%s gy=%s hvp=%s shard %d' % (am, use_gy, use_tx, r), got, ref[idx[r]], 1e-4)
+
+
 @pytest.mark.parametrize('G,n,C', [(1, 4, 16), (3, 3, 512), (3, 16, 512), (2, 5, 32)])
 def test_mbstd(G, n, C):
     cp = C + 16

@@ -271,3 +271,118 @@ def test_four_rank_run_crosses_growth_stages_in_lockstep(tmp_path):
         prev = nimg
     assert any(a not in ('1.0',) for _, _, a, _ in log0)        # fades happened
     assert nimg0 >= 4.6 * span and its0 == len(log0)
+
+
+def _global_stddev_worker(rank, world, port, out_path, depth, alpha):
+    """One D step + one G step per rank on ITS shard of a global batch, minibatch stddev in the exact-global mode."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import emu_ops
+    import pggan_amd as pg
+    from helpers import synthetic, reference_grads
+    torch.set_num_threads(2)
+    for modname in ('engine', 'optim'):
+        importlib.import_module('pggan-pytorch_amd.' + modname).ops = emu_ops
+    pg.engine._check_dev = lambda t, what: t.contiguous()
+    pg.trainer._to_device = lambda t: t
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dp = pg.DataParallel()
+    torch.manual_seed(31)
+    shape = (1, 3, 16, 16)
+    kw = dict(fmap_base=64, fmap_max=16)
+    G = pg.Generator(shape, latent_size=16, **kw)
+    D = pg.Discriminator(shape, **kw)
+    G.depth = D.depth = depth
+    G.alpha = D.alpha = alpha
+    n = 2
+    real, z_d, z_g, mix = synthetic(77, world * n, 3, 4 * 2 ** depth, 16)              # the GLOBAL batch; this rank's shard = its slice
+    sl = slice(rank * n, (rank + 1) * n)
+    opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+    opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+
+    class DS(object):
+        pass
+    DS.model_depth, DS.alpha = depth, alpha
+    state = dict(z=[z_d[sl], z_g[sl]])
+
+    def loader():
+        while True:
+            yield real[sl]
+
+    def d_loss(Dm, Gm, r_, z_):
+        pg.wgan_gp_loss.set_mixing_factors(mix[sl])
+        return pg.wgan_gp_D_loss(Dm, Gm, r_, z_)
+    tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, DS(), loader(), lambda: state['z'].pop(0) if state['z'] else z_g[sl],
+                    parallel=dp, global_stddev=True)
+    assert D._global_stddev is dp
+    got = {}
+    orig = dp.all_reduce_grads
+
+    def rec(net, average=False):
+        r = orig(net, average=average)
+        got['D' if net is D else 'G'] = {k: v.clone() for k, v in reference_grads(net).items()}      # SUM over ranks, before Adam
+        return r
+    dp.all_reduce_grads = rec
+    losses = []
+
+    class Rec(pg.Plugin):
+        def __init__(self):
+            super(Rec, self).__init__([(1, 'iteration')])
+
+        def register(self, trainer):
+            pass
+
+        def iteration(self, i, g_cost, d_cost, *rest):
+            losses.append((float(g_cost), float(d_cost)))
+    tr.register_plugin(Rec())
+    import heapq
+    for q in tr.plugin_queues.values():
+        heapq.heapify(q)
+    tr.train()
+    t = torch.tensor(losses[0], dtype=torch.float64)
+    dist.all_reduce(t)                                  # global loss = mean of the shard losses (equal shards)
+    if rank == 0:
+        torch.save(dict(grads=got, g_cost=float(t[0]) / world, d_cost=float(t[1]) / world), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('depth,alpha', [(2, 1.0), (1, 0.5)])
+def test_exact_global_minibatch_stddev_matches_one_process_at_global_batch(tmp_path, oracle, depth, alpha):
+    """SURVEY.md §8e optional mode (Trainer(parallel=dp, global_stddev=True)): with the group statistic and the scalars of its adjoint /
+    Hessian-vector term (G_sigma, <v, x - mu>, mean v) reduced over the ranks, 2 ranks x minibatch 2 reproduce ONE process at batch 4 --
+    losses and the averaged gradients of the D step (first-order terms, gradient penalty incl. the stddev Hessian-vector term) and of
+    the G step, against the oracle evaluated on the whole batch.  (Local-shard mode differs from this by O(1) in the stddev terms: the
+    default-mode test above checks that one against per-shard oracle gradients.)"""
+    world = 2
+    out_path = str(tmp_path / 'gs.pt')
+    mp.spawn(_global_stddev_worker, args=(world, _free_port(), out_path, depth, alpha), nprocs=world, join=True)
+    got = torch.load(out_path, weights_only=False)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import pggan_amd as pg
+    from helpers import synthetic
+    torch.manual_seed(31)
+    shape = (1, 3, 16, 16)
+    kw = dict(fmap_base=64, fmap_max=16)
+    G = pg.Generator(shape, latent_size=16, **kw)
+    D = pg.Discriminator(shape, **kw)
+    gp, dp_ = G.reference_state_dict(), D.reference_state_dict()
+    cfg = oracle.NetCfg(16, 3, latent_size=16, **kw)
+    real, z_d, z_g, mix = synthetic(77, 4, 3, 4 * 2 ** depth, 16)
+    ref = oracle.d_loss_and_grads(dp_, gp, cfg, real, z_d, mix, depth, alpha)
+    assert abs(got['d_cost'] - float(ref['D_cost'])) < 2e-4 * max(1.0, abs(float(ref['D_cost'])))
+    assert sorted(ref['grads']) == sorted(got['grads']['D'])
+    for k, v in ref['grads'].items():
+        assert _err(got['grads']['D'][k] / world, v) < 2e-3, ('D grad', k, _err(got['grads']['D'][k] / world, v))
+    # the shard-local statistic would NOT pass: make sure the case is sensitive to the mode
+    loc = [oracle.d_loss_and_grads(dp_, gp, cfg, real[s], z_d[s], mix[s], depth, alpha) for s in (slice(0, 2), slice(2, 4))]
+    key = [k for k in ref['grads'] if k.endswith('c1.conv.weight')][-1]
+    assert _err(sum(d['grads'][key] for d in loc) / world, ref['grads'][key]) > 5e-3
+    od = oracle.AdamState()
+    od.step(dp_, ref['grads'], 0.001)
+    refg = oracle.g_loss_and_grads(gp, dp_, cfg, z_g, depth, alpha)
+    assert abs(got['g_cost'] - float(refg['G_cost'])) < 2e-4 * max(1.0, abs(float(refg['G_cost'])))
+    for k, v in refg['grads'].items():
+        assert _err(got['grads']['G'][k] / world, v) < 5e-3, ('G grad', k, _err(got['grads']['G'][k] / world, v))

@@ -16,16 +16,15 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r.get('Queue_Id', r.get('Stream_Id', '0')), r['Kernel_Name']))
 rows.sort()
-# the last 10 steps of the timed loop: 20 Adam "big" launches (2 networks) -> cut at the 31st-last adam launch group
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[3]]
-per_step = 3                                          # measured: 3 adam launches per train step at depth 8
-nsteps = 10
-first = adam[-per_step * nsteps - 1] + 1 if len(adam) > per_step * nsteps else 0
-last = adam[-1]
+# the last 10 steps of the timed loop, delimited by the mixing-factor draw that opens every D step (one uniform_kernel per train step at every
+# growth stage; the number of Adam launches per step differs between stages)
+marks = [i for i, r in enumerate(rows) if 'uniform_kernel' in r[3]]
+nsteps = min(10, len(marks) - 1)
+first, last = marks[-nsteps - 1], marks[-1] - 1
 win = rows[first:last + 1]
 # rocprofv3 flushes its buffers every few thousand records: the device then idles for milliseconds inside ONE step.  Steps with a
 # hole > 1.5 ms anywhere are the tracer's, not the product's: they are reported and left out of the window statistics.
-bounds = [adam[-per_step * (nsteps - k) - 1] + 1 if len(adam) > per_step * (nsteps - k) else 0 for k in range(nsteps)] + [last + 1]
+bounds = [marks[-nsteps - 1 + k] for k in range(nsteps)] + [last + 1]
 good = []
 for k in range(nsteps):
     st = sorted(rows[bounds[k]:bounds[k + 1]])

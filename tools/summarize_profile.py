@@ -108,11 +108,10 @@ for r in rows[:14]:
 
 # ---- bench.py <-> rocprofv3 attribution check: every conv symbol the bench line times must be launched exactly as often per
 # step as the kernel trace of the same workload says (a wrapper missing from bench.KernelTimer shows up here)
-bench_json = os.path.join(out, 'bench_kernels.json')
+bench_json = os.path.join(out, 'bench_detail.json')          # bench.py's detail file of the un-traced run (the stdout line carries no tables)
 steps_traced = int(os.environ.get('PG_TRACED_STEPS', '23'))            # profile_round.sh: --prime 10 --warmup 3 --steps 10
 if os.path.exists(bench_json) and os.path.exists(ks):
-    line = [l for l in open(bench_json).read().splitlines() if l.startswith('{')][-1]
-    bk = json.loads(line).get('kernels', {})
+    bk = json.load(open(bench_json)).get('kernels', {})
     traced = {}
     with open(ks) as f:
         for row in csv.DictReader(f):
