@@ -97,7 +97,7 @@ def test_one_rank_allreduce_is_the_identity(dp):
     assert dp.stats['collectives'] == before['collectives'] + 1 and dp.stats['bytes'] == before['bytes'] + 8900 * 4
 
 
-def _train(parallel, buckets, monkeypatch, iters=3):
+def _train(parallel, buckets, monkeypatch, iters=3, global_stddev=False):
     monkeypatch.setenv('PGGAN_DP_BUCKETS', '1' if buckets else '0')
     monkeypatch.setattr(pg.parallel, 'BUCKET_BYTES', 1 << 16)                    # small buckets: several collectives per sweep
     torch.manual_seed(31)
@@ -117,7 +117,7 @@ def _train(parallel, buckets, monkeypatch, iters=3):
         return pg.wgan_gp_D_loss(Dm, Gm, real, z)
     opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
     opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
-    tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, None, reals, lambda: next(zs), parallel=parallel)
+    tr = pg.Trainer(D, G, d_loss, pg.wgan_gp_G_loss, opt_d, opt_g, None, reals, lambda: next(zs), parallel=parallel, global_stddev=global_stddev)
     grads = []
     for _ in range(iters):
         tr.train()
@@ -147,3 +147,21 @@ def test_trainer_with_one_rank_communicator_matches_plain_trainer(dp, monkeypatc
         assert_same_contributions(other[0][0], gr0[0][0])
         # (G's gradients go through D AFTER its first update, where a sign-like Adam has turned round-off noise into +-lr)
         assert_same_contributions(other[0][1], gr0[0][1], tol=0.3, total=5e-2)
+
+
+def test_exact_global_stddev_with_one_rank_equals_local_mode(dp, monkeypatch):
+    """``Trainer(parallel=dp, global_stddev=True)`` on the device: the split minibatch-stddev entry points + the statistic / Gs exchange
+    through the library's RCCL communicator (one rank: the exchange is the identity, the global batch IS the local one), every step
+    eager.  Must land where the default local-shard mode lands; the exchange really ran (a few floats per collective)."""
+    g0, d0, gr0 = _train(dp, True, monkeypatch)
+    c0, b0 = dp.stats['collectives'], dp.stats['bytes']
+    g1, d1, gr1 = _train(dp, True, monkeypatch, global_stddev=True)
+    c1, b1 = dp.stats['collectives'], dp.stats['bytes']
+    g2, d2, gr2 = _train(dp, True, monkeypatch)
+    extra = (c1 - c0) - (dp.stats['collectives'] - c1)
+    assert extra >= 3 * 6                        # per iteration: 3 statistic gathers (D fwd, tangent, G-step D fwd) + >= 3 Gs sums
+    for name, ref, got in (('G', g0, g1), ('D', d0, d1)):
+        assert float((got - ref).abs().max()) <= 2 * 0.001 * sum(((1 - 0.99 ** t) / 0.01) ** 0.5 for t in (1, 2, 3)) + 1e-6, name
+        assert float((got - ref).norm() / ref.norm()) < 1e-3, name
+    assert_same_contributions(gr1[0][0], gr0[0][0])
+    assert_same_contributions(gr1[0][1], gr0[0][1], tol=0.3, total=5e-2)

@@ -298,7 +298,7 @@ def test_pixelnorm(P, C):
     check('lrelu-only bwd', ops.pixelnorm_lrelu_bwd(dev(gy), y, None, 0.2), E.pixelnorm_lrelu_bwd(gy, ry, None, 0.2))
 
 
-@pytest.mark.parametrize('G,n,C,world', [(1, 4, 16, 2), (3, 2, 512, 3), (3, 16, 512, 2), (2, 6, 32, 3)])
+@pytest.mark.parametrize('G,n,C,world', [(1, 4, 16, 2), (3, 3, 512, 3), (3, 16, 512, 2), (2, 6, 32, 3)])
 def test_mbstd_exact_global_mode(G, n, C, world):
     """The exact-global minibatch stddev entry points (pg_mbstd_stats / _write / _tangent_stats / _tangent_write / _gsum / _bwd_global,
     SURVEY.md §8e optional mode) with the ranks of a data-parallel group played by slices of one batch on one device: every "rank" holds
