@@ -511,12 +511,12 @@ __global__ __launch_bounds__(256) void linear1_wgrad_kernel(const float* __restr
     if (c < C) {
         float a = 0.f;
         for (int n = 0; n < N; ++n) a = fmaf(gs[n], h[(size_t)n * C + c], a);
-        atomicAdd(dw + c, a);                  // (atomic: the [real | fake] sweep on the third stream and the tangent term on the main stream may meet here)
+        dw[c] += a;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && db) {
         float a = 0.f;
         for (int n = 0; n < N; ++n) a += gs[n];
-        atomicAdd(db, a);
+        db[0] += a;
     }
 }
 

@@ -327,28 +327,6 @@ def _wait_event(stream, ev):
     stream.wait_event(ev)
 
 
-# Third stream (round 5): the first-order adjoint sweep of the [real | fake] images of a D step.  It needs nothing but the D forward, so
-# it starts right behind it and runs UNDER the gradient-penalty chain of the mixed images (first backward -> seed -> tangent pass ->
-# Hessian-vector sweep, all on 3 images and latency-bound on the main stream); its weight gradients go to the weight-gradient stream as
-# always.  PGGAN_SPLIT_SWEEP=0: one batched [real | fake | mixed] sweep after the tangent pass (rounds 1-4).
-SPLIT_SWEEP = _os.environ.get('PGGAN_SPLIT_SWEEP', '1') != '0'
-_THIRD = {}
-
-
-def _third_stream():
-    dev = torch.cuda.current_device()
-    if dev not in _THIRD:
-        _THIRD[dev] = torch.cuda.Stream(device=dev)
-    return _THIRD[dev]
-
-
-def _ctx_tensors(ctx):
-    for rec in ctx['recs']:
-        for v in rec.values():
-            if torch.is_tensor(v):
-                yield v
-
-
 def _side_stream():
     dev = torch.cuda.current_device()
     if dev not in _SIDE:
@@ -483,13 +461,6 @@ def _ones(n, device):
     key = (n, str(device))
     if key not in _ONES:
         _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
-    return _ONES[key]
-
-
-def _zeros(n, device):
-    key = (n, str(device), 0)
-    if key not in _ONES:
-        _ONES[key] = torch.zeros(n, device=device, dtype=torch.float32)
     return _ONES[key]
 
 
@@ -764,14 +735,12 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
     recs = ctx['recs']
     adj = [dict() for _ in recs]
     lastrec = recs[-1]
-    nh = NB if hvp is None else hvp[0]             # nh == 0: every image belongs to the Hessian-vector group (nothing above minibatch-stddev)
+    nh = NB if hvp is None else hvp[0]
     a2 = lastrec['a2']
     lc2 = lastrec['blk'].c2
-    g = None
-    if nh > 0:
-        if full:
-            ops.linear1_wgrad(gscore, a2[:nh], D._lin_gw, D._lin_gb)
-        g = ops.linear1_bwd_data(gscore, D.linear.weight.data, a2[:nh], (nh,) + tuple(a2.shape[1:]), lc2.slope)
+    if full:
+        ops.linear1_wgrad(gscore, a2[:nh], D._lin_gw, D._lin_gb)
+    g = ops.linear1_bwd_data(gscore, D.linear.weight.data, a2[:nh], (nh,) + tuple(a2.shape[1:]), lc2.slope)
     gimg = None
     pending_prev = None
     carry = None
@@ -783,14 +752,12 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
         if rec['last']:
             gz2 = g                                                           # [nh,1,1,C]
             a1, mb, inp = rec['a1'], rec['mb'], rec['inp']
-            gz1 = gmb = None
-            if nh > 0:
-                if full:
-                    _wgrad(a1[:nh], gz2, c2, nh, H)
-                gz1 = _dgrad(D, gz2, c2, nh, 1, mask=a1[:nh], mask_slope=c1.slope)
-                if full:
-                    _wgrad(mb[:nh], gz1, c1, nh, H)
-                gmb = _dgrad(D, gz1, c1, nh, H)                               # [nh,4,4,CP]
+            if full:
+                _wgrad(a1[:nh], gz2, c2, nh, H)
+            gz1 = _dgrad(D, gz2, c2, nh, 1, mask=a1[:nh], mask_slope=c1.slope)
+            if full:
+                _wgrad(mb[:nh], gz1, c1, nh, H)
+            gmb = _dgrad(D, gz1, c1, nh, H)                                   # [nh,4,4,CP]
             cp = c1.cin_store
             if hvp is None:
                 gin = _mbstd_bwd(D, gmb, inp, rec['stats'], cp, rec['first'], fr_slope)
@@ -798,8 +765,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                 _, tx, tstats, gy_first = hvp
                 gin = torch.empty_like(inp)
                 ng = rec['stats'].shape[0] - 1
-                if nh > 0:
-                    _mbstd_bwd(D, gmb, inp[:nh], rec['stats'][:ng], cp, rec['first'], fr_slope, out=gin[:nh])
+                _mbstd_bwd(D, gmb, inp[:nh], rec['stats'][:ng], cp, rec['first'], fr_slope, out=gin[:nh])
                 _mbstd_bwd(D, None, inp[nh:], rec['stats'][ng:], cp, rec['first'], fr_slope,
                            tx=tx, tstats=tstats, gy_first=gy_first, out=gin[nh:])
             if save_adjoints:
@@ -1145,63 +1111,26 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                      # :19
     s, ctx = d_forward(D, x3, groups=3)                                       # :47,54,20
     sub = _slice_ctx(ctx, 2 * N, 3 * N, 2, 3)
-    # Split schedule: d D_cost / d score of the real and fake images depends on the scores alone (:48,55), so their adjoint sweep (with
-    # its weight gradients: trainer.py:98's first-order terms) starts HERE, on the third stream, and runs under the gradient-penalty
-    # chain below.  It accumulates into the flat gradient buffer, which is therefore cleared here; d_loss_backward adds the rest.
-    # Not inside a hipGraph capture (the capture streams of a device share one K-slice scratch: one slicing branch per graph), not
-    # for Discriminator(pixelnorm=True) (its sweep carries per-layer Hessian-vector injections for the whole batch).
-    early = None
-    if SPLIT_SWEEP and not getattr(D, 'pixelnorm', False) and not (x3.is_cuda and torch.cuda.is_current_stream_capturing()):
-        D._ensure_buffers()
-        ops.zero_(D._flat_grad)
-        for lay in _live_conv_layers(D):
-            lay._pending_wgrad = None
-        gs_early = ops.d_loss(s, _zeros(N, real.device), N, iwass_epsilon)[3]           # (the loss values need the penalty: computed below)
-        hook, D._grad_hook = getattr(D, '_grad_hook', None), None                       # (nothing is final before the mixed images' sweep)
-        rf = _slice_ctx(ctx, 0, 2 * N, 0, 2)
-        if x3.is_cuda and ASYNC_WGRAD:
-            main = torch.cuda.current_stream(torch._C._cuda_getDevice())
-            third = _third_stream()
-            _wait_stream(third, main)
-            with torch.cuda.stream(third):
-                d_backward(D, rf, gs_early[:2 * N], full=True, want_gimg=False)
-            for t in _ctx_tensors(ctx):                                                 # read on the third stream: the allocator must know
-                t.record_stream(third)
-            gs_early.record_stream(third)
-            early = third
-        else:                                                                           # (one stream / host emulation: the same sweeps, in order)
-            d_backward(D, rf, gs_early[:2 * N], full=True, want_gimg=False)
-            early = False
-        D._grad_hook = hook
     gimg, adj = d_backward(D, sub, _ones(N, real.device), full=False, want_gimg=True, save_adjoints=True)  # :25-28
     ss = ops.row_sumsq(gimg)
     gp, u = ops.gp_seed(gimg, ss, iwass_lambda, iwass_target, 1.0 / N)        # :29-31
     d_cost, d_real_loss, d_fake_loss, gscore = ops.d_loss(s, gp, N, iwass_epsilon)   # :48,55,62
-    state = dict(D=D, ctx=ctx, sub=sub, adj=adj, u=u, gscore=gscore, N=N, scores=s, gp=gp, early=early)
+    state = dict(D=D, ctx=ctx, sub=sub, adj=adj, u=u, gscore=gscore, N=N, scores=s, gp=gp)
     return d_cost, d_real_loss, d_fake_loss, state
 
 
 def d_loss_backward(state, scale=1.0):
     """``D_cost.backward()`` (trainer.py:98): tangent pass + batched [real|fake|mixed] adjoint sweep."""
     D, ctx, N = state['D'], state['ctx'], state['N']
-    early = state.get('early')
     D._ensure_buffers()
-    if early is None:
-        ops.zero_(D._flat_grad)
-        for lay in _live_conv_layers(D):         # (nothing of an aborted earlier step may ride along)
-            lay._pending_wgrad = None
+    ops.zero_(D._flat_grad)
     if scale != 1.0:
         D._grad_hook = None                      # the gradients are rescaled after the sweep: nothing may travel early
+    for lay in _live_conv_layers(D):             # (nothing of an aborted earlier step may ride along)
+        lay._pending_wgrad = None
     hvp = d_tangent_wgrad(D, state['sub'], state['adj'], state['u'])
-    if early is None:
-        gs = state['gscore'][:2 * N]
-        d_backward(D, ctx, gs, full=True, want_gimg=False, hvp=(2 * N,) + hvp)
-    else:
-        # the [real | fake] sweep already ran (d_loss_forward): what is left are the mixed images, every one in the Hessian-vector group
-        d_backward(D, state['sub'], state['gscore'][:0], full=True, want_gimg=False, hvp=(0,) + hvp)
-        if early is not False:
-            _wait_stream(torch.cuda.current_stream(torch._C._cuda_getDevice()), early)  # (long finished: its chain is the shorter one)
-        state['early'] = None
+    gs = state['gscore'][:2 * N]
+    d_backward(D, ctx, gs, full=True, want_gimg=False, hvp=(2 * N,) + hvp)
     for lay in _live_conv_layers(D):             # (a deferred tangent contribution that no launch of the sweep carried)
         _flush_wgrad(lay)
     if not (getattr(D, '_skip_join', False) and scale == 1.0):
