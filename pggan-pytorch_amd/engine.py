@@ -97,7 +97,18 @@ def _derived(net):
             ops.wino_transform_weights_batched(net._flat_param if WTU_FROM_PARAM else net._flat_wt, net._flat_wtu,
                                                [(woff, uoff, m.conv.weight.shape[3], m.conv.weight.shape[2]) for m, woff, uoff in wl],
                                                transposed=WTU_FROM_PARAM)
-    if wl:                                       # the forward convs' Winograd-domain weights: needed by the very next launch
+    one_launch = DERIVED_ONE_LAUNCH and WTU_FROM_PARAM and bool(wl) and net.__dict__.get('_bwd_wanted', False)
+    if one_launch:
+        # forward AND backward-data Winograd forms in one launch on this stream (the two forms share a buffer, network._flat_wuu): the
+        # parameter is read while it is hot, no second launch, no cross-stream hop for it at the iteration boundary
+        half = net._flat_wu.numel()
+        ops.wino_transform_weights_batched(
+            net._flat_param, net._flat_wuu,
+            [(woff, uoff, m.conv.weight.shape[2], m.conv.weight.shape[3]) for m, woff, uoff in wl] +
+            [(woff, half + uoff, m.conv.weight.shape[3], m.conv.weight.shape[2]) for m, woff, uoff in wl],
+            transposed=[False] * len(wl) + [True] * len(wl))
+        wl = []                                  # (backward_copies below: only the flipped copies of the direct-conv layers are left)
+    elif wl:                                     # the forward convs' Winograd-domain weights: needed by the very next launch
         ops.wino_transform_weights_batched(net._flat_param, net._flat_wu,
                                            [(woff, uoff, m.conv.weight.shape[2], m.conv.weight.shape[3]) for m, woff, uoff in wl])
     # The backward copies are not needed before the network's next backward sweep (milliseconds away): off the critical path, onto
@@ -308,6 +319,7 @@ def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
 # half-occupancy MFMA kernels share the CUs instead of running back to back.
 ASYNC_WGRAD = _os.environ.get('PGGAN_ASYNC_WGRAD', '1') != '0'
 ASYNC_DERIVED = _os.environ.get('PGGAN_ASYNC_DERIVED', '1') != '0'
+DERIVED_ONE_LAUNCH = _os.environ.get('PGGAN_DERIVED_ONE_LAUNCH', '1') != '0'      # forward + backward-data Winograd weights of a network: one launch
 # 0: every live layer gets a flipped / transposed copy and the backward-data Winograd form is derived from that copy (round 2)
 WTU_FROM_PARAM = _os.environ.get('PGGAN_WTU_FROM_PARAM', '1') != '0'
 _SIDE = {}

@@ -211,7 +211,7 @@ class _FlatParamsMixin(object):
         for m in self._layers():
             m._gw = m._gb = m._wt = None
             m._wu = m._wtu = None
-        self._flat_wu = self._flat_wtu = None
+        self._flat_wu = self._flat_wtu = self._flat_wuu = None
         self._derived_ver = None
         self._param_version = getattr(self, '_param_version', 0) + 1
         for m in self._layers():
@@ -247,8 +247,10 @@ class _FlatParamsMixin(object):
               m.conv.weight.shape[2] % 8 == 0 and m.conv.weight.shape[3] % 8 == 0 and
               max(m.conv.weight.shape[2], m.conv.weight.shape[3]) >= 16]     # a direction needs >= 16 OUTPUT channels (engine._wino)
         total = sum(16 * m.conv.weight.shape[2] * m.conv.weight.shape[3] for m in wl)
-        self._flat_wu = torch.zeros(max(total, 4), dtype=torch.float32, device=flat.device)
-        self._flat_wtu = torch.zeros(max(total, 4), dtype=torch.float32, device=flat.device)
+        # forward and backward-data forms in ONE buffer (two halves): a single batched launch can derive both (engine._derived)
+        self._flat_wuu = torch.zeros(2 * max(total, 4), dtype=torch.float32, device=flat.device)
+        self._flat_wu = self._flat_wuu[:max(total, 4)]
+        self._flat_wtu = self._flat_wuu[max(total, 4):]
         self._wino_layers = []
         off = 0
         for m in self._layers():
@@ -295,7 +297,7 @@ class _FlatParamsMixin(object):
         d = self.__dict__.copy()
         d['_flat_grad'] = None
         d['_flat_wt'] = None
-        d['_flat_wu'] = d['_flat_wtu'] = None
+        d['_flat_wu'] = d['_flat_wtu'] = d['_flat_wuu'] = None
         d['_wino_layers'] = None
         d['_derived_ver'] = None
         d['_pending'] = None

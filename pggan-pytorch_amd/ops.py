@@ -153,7 +153,10 @@ def wino_transform_weights_batched(flat_w, flat_u, layers, transposed=False):
     uoff = (ctypes.c_int64 * n)(*[l[1] for l in layers])
     co = (ctypes.c_int * n)(*[l[2] for l in layers])
     ci = (ctypes.c_int * n)(*[l[3] for l in layers])
-    tr = (ctypes.c_int * n)(*([1] * n)) if transposed else None
+    if isinstance(transposed, (list, tuple)):          # per-layer flags: forward and backward-data forms of a network in one launch
+        tr = (ctypes.c_int * n)(*[1 if t else 0 for t in transposed]) if any(transposed) else None
+    else:
+        tr = (ctypes.c_int * n)(*([1] * n)) if transposed else None
     _lib.call('pg_wino_transform_weights_batched', _p(flat_w), _p(flat_u), n, ctypes.cast(woff, ctypes.c_void_p),
               ctypes.cast(uoff, ctypes.c_void_p), ctypes.cast(co, ctypes.c_void_p), ctypes.cast(ci, ctypes.c_void_p),
               ctypes.cast(tr, ctypes.c_void_p) if tr is not None else None, _stream())

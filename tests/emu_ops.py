@@ -119,8 +119,9 @@ def wino_transform_weights(w, u=None):
 
 
 def wino_transform_weights_batched(flat_w, flat_u, layers, transposed=False):
-    for woff, uoff, co, ci in layers:
-        if transposed:                                   # backward-data form straight from the forward parameter [3][3][ci][co]
+    flags = list(transposed) if isinstance(transposed, (list, tuple)) else [bool(transposed)] * len(layers)
+    for (woff, uoff, co, ci), tr in zip(layers, flags):
+        if tr:                                           # backward-data form straight from the forward parameter [3][3][ci][co]
             w = flat_w[woff:woff + 9 * co * ci].view(3, 3, ci, co).flip(0, 1).permute(0, 1, 3, 2).contiguous()
         else:
             w = flat_w[woff:woff + 9 * co * ci].view(3, 3, co, ci)
