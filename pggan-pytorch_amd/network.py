@@ -304,6 +304,8 @@ class _FlatParamsMixin(object):
         d['_skip_join'] = False
         d['_lin_gw'] = d['_lin_gb'] = d['_lin_layer'] = None
         d['_grad_hook'] = d['_grad_exchange'] = None
+        d['_global_stddev'] = None               # (a process-group handle: a reloaded network starts in the local-shard mode)
+        d['_plan_unjoined'] = False
         d['_plist'] = None
         d['_layer_list'] = None
         d['_derived_bwd_ev'] = None

@@ -300,3 +300,20 @@ def test_time_monitor_stat_names():
     assert tr.stats['sec']['tick'] > 0 and abs(tr.stats['sec']['kimg'] - tr.stats['sec']['tick']) < 1e-9       # 1000 images in the tick
     assert abs(tr.stats['img/s']['val'] * tr.stats['sec']['tick'] - 1000) < 1e-6
     assert tr.stats['d_gp_ms']['val'] == 0.0                 # (no sampled iteration: the probe needs device events)
+
+
+def test_process_group_handle_is_not_pickled():
+    """SaverPlugin pickles whole modules (plugins.py:155-166).  In the exact-global stddev mode the Discriminator holds the data-parallel
+    group (communicator handle, streams): it must stay out of the pickle, and a reloaded network starts in the local-shard mode."""
+    import io
+
+    class Handle(object):
+        def __reduce__(self):
+            raise RuntimeError('the process-group handle must not be pickled')
+    D = pg.Discriminator((1, 3, 16, 16), fmap_base=64, fmap_max=16)
+    D._global_stddev = Handle()
+    buf = io.BytesIO()
+    torch.save(D, buf)
+    buf.seek(0)
+    D2 = torch.load(buf, weights_only=False)
+    assert D2.__dict__.get('_global_stddev') is None and isinstance(D._global_stddev, Handle)
