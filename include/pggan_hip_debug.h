@@ -18,7 +18,7 @@ const char* pg_debug_last_conv_kernel(void);
 const char* pg_debug_last_wino_kernel(void);
 const char* pg_debug_last_wino_wgrad_kernel(void);
 
-/* Tuning aids (tools/microbench_conv.py, tools/sweep_*.py): force a configuration for the calling thread's next launches.
+/* Tuning aids (tools/sweeps/microbench_conv.py, tools/sweep_*.py): force a configuration for the calling thread's next launches.
  * pg_debug_set_tuning: key 0 conv tile candidate, key 1 weight-gradient configuration, key 2 conv split-K factor (further
  * keys: see csrc/conv_igemm.hip); value -1 restores the built-in choice.  pg_debug_set_wino: K-chunk of 4*vec channels. */
 int pg_debug_set_tuning(int key, int value);

@@ -1488,7 +1488,7 @@ int launch_ksplit(ConvP& p, hipStream_t s)
 // share the matrix pipes, so a batch of r workgroups takes max(L, r x MFMA cycles) and the launch takes
 // (batches over 256 CUs) x that.  Small tiles have a longer MFMA-free fraction per workgroup but far more residents,
 // which is what wins on the 256/512-channel layers at minibatch 3; the constants were fitted to a sweep of every
-// candidate over every layer shape of the schedule (tools/sweep_conv_all.py, tools/fit_cost_model.py: 0.7 % regret).
+// candidate over every layer shape of the schedule (tools/sweeps/sweep_conv_all.py, tools/sweeps/fit_cost_model.py: 0.7 % regret).
 // Shapes with < 192 workgroups are K-split in launch_conv (memset + atomics + deferred epilogue: fixed penalty).
 struct TileCand { int bpx, bco; };
 
@@ -1912,7 +1912,7 @@ int dispatch_wgrad(WgP& p, hipStream_t s)
         const long long M = (long long)p.N * p.Hout * p.Wout;
         if (M <= 32) return launch_wgrad<KS, 1, 1, 2, 2, 16>(p, s);
         if constexpr (KS == 3) {
-            // measured (tools/sweep_wgrad_thin.py): block-MFMA wins on 32 -> 16 always, on 16 -> 32 below ~1.5 M pixels
+            // measured (tools/sweeps/sweep_wgrad_thin.py): block-MFMA wins on 32 -> 16 always, on 16 -> 32 below ~1.5 M pixels
             if (g_tune[1] != 8 && ((p.Cout == 16 && p.Cin == 32) || (p.Cout == 32 && p.Cin == 16 && M < 1500000)))
                 return launch_wgrad_thin<64>(p, s);
         }
@@ -1932,7 +1932,7 @@ int dispatch_wgrad(WgP& p, hipStream_t s)
             }
         }
         if constexpr (KS == 3) {
-            // measured (tools/sweep_wgrad.py): with >= ~4e8 MACs per tap the 64-cout block (two K-waves) wins on
+            // measured (tools/sweeps/sweep_wgrad.py): with >= ~4e8 MACs per tap the 64-cout block (two K-waves) wins on
             // >= 64 input channels and 128-pixel tiles win on the narrow layers; small launches keep 32x16 / 64 px
             const double macs = (double)M * p.Cout * p.Cin;
             if (g_tune[1] < 0 && macs >= 4e8) {
@@ -2002,7 +2002,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
         p.ypool = ypool;
         p.yup = yup;
         const bool thin_plain = !p.y_bytes && !yup && !ypool && ((Cout == 8 && (Cin == 8 || Cin == 16)) || (Cout == 16 && Cin == 8 && mask));
-        const bool thin_pool = g_tune[3] != 17 && !yup && ypool && Cout == 16 && Cin == 8;      // 8->16 + pool (forward: sign bytes out; tangent: masked): +8..14 % over the generic tile kernel (tools/bench_thin16pool.py)
+        const bool thin_pool = g_tune[3] != 17 && !yup && ypool && Cout == 16 && Cin == 8;      // 8->16 + pool (forward: sign bytes out; tangent: masked): +8..14 % over the generic tile kernel (tools/sweeps/bench_thin16pool.py)
         const bool thin_b = pad == 1 && (thin_plain || thin_pool) && (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;
         if (thin_b) return dispatch_thin(p, s);
         return dispatch_conv_generic_nosplit(p, s);
@@ -2030,7 +2030,7 @@ static int conv2d_impl(const float* x, const float* w, const float* bias, const 
         if (rc != PG_E_UNSUP) return rc;
         p.yup = nullptr;
     }
-    // measured (tools/sweep_thin8.py): 1.5-1.7x on 8 couts; on 16 couts only the masked 8->16 launch gains (the
+    // measured (tools/sweeps/sweep_thin8.py): 1.5-1.7x on 8 couts; on 16 couts only the masked 8->16 launch gains (the
     // 16x16x4 tile has no padding there), 32 input channels lose -> those stay on the generic kernel
     const bool thin_ok = KS == 3 && pad == 1 && ((Cout == 8 && (Cin == 8 || Cin == 16)) || (Cout == 16 && Cin == 8 && mask && !ypool)) &&
                          (p.Wout & 31) == 0 && (p.Hout & 7) == 0 && g_tune[3] != 2;

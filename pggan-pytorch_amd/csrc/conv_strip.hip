@@ -39,7 +39,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef PG_STRIP_ABL            // ablation build of tools/bench_strip.py: 1 no DMA after the prologue, 2 no stores, 4 one tap only
+#ifndef PG_STRIP_ABL            // ablation build of tools/sweeps/bench_strip.py: 1 no DMA after the prologue, 2 no stores, 4 one tap only
 #define PG_STRIP_ABL 0
 #endif
 

@@ -665,7 +665,7 @@ extern "C" int pg_wino_transform_weights_batched(const float* wbase, float* ubas
 
 namespace {
 // K slices of a launch with nblk (64-tile, 16-cout) blocks and nch 8-channel chunks when a scratch is registered (measured:
-// tools/bench_ksplit.py in isolation and in-step sweeps of the constants)
+// tools/sweeps/bench_ksplit.py in isolation and in-step sweeps of the constants)
 int wino_default_slices(int nblk, int nch)
 {
     static const int ks_pairs = getenv("PG_WINO_KS_PAIRS") ? atoi(getenv("PG_WINO_KS_PAIRS")) : 432;
@@ -783,7 +783,7 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
     if (vec >= 10 || vec == 0) {
         // second-generation kernel (LDS-DMA, 8-channel chunks, 16*NCB couts per workgroup); two cout blocks per workgroup
         // when that still leaves at least two workgroups per CU
-        int ncb = (vec >= 10 && vec < 20) ? vec - 10 : ((Cin >= 512 && (long long)ntb * ((Cout + 31) / 32) >= 768) ? 2 : 1);   // measured: tools/sweep_wino.py
+        int ncb = (vec >= 10 && vec < 20) ? vec - 10 : ((Cin >= 512 && (long long)ntb * ((Cout + 31) / 32) >= 768) ? 2 : 1);   // measured: tools/sweeps/sweep_wino.py
         if (ncb != 1 && ncb != 2) return PG_E_ARG;
         if (pn_r || pnb_y) ncb = Cout > 16 ? 2 : 1;           // PixelNorm epilogue / adjoint: all couts of a pixel in one workgroup
         // Staging the input region 16 channels at a time (XK = 2: every activation line comes from L2 twice instead of four times)
@@ -855,7 +855,7 @@ int wino_conv(const float* x, const float* u, const float* bias, const float* ma
     }
     const size_t smem = ((size_t)16 * 16 * (vec == 4 ? 24 : 12) + (size_t)TN * HT * WT * (vec == 4 ? 20 : 12)) * sizeof(float);
     p.ncob = (Cout + 15) / 16;
-    p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20);      // measured: tools/sweep_wino.py
+    p.cout_minor = (long long)16 * Cout * Cin * 4 <= (2ll << 20);      // measured: tools/sweeps/sweep_wino.py
     dim3 grid((unsigned)(ntb * p.ncob));
     snprintf(g_wino_last, sizeof(g_wino_last), "conv_wino_kernel<%d>", vec);
     if (vec == 4) {

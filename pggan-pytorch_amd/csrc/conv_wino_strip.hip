@@ -493,7 +493,7 @@ inline int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // Called by wino_conv (conv_wino.hip) with the epilogue fields of ``p`` filled in.  PG_E_UNSUP = "not this shape": the caller keeps
 // the tile kernel.  ``mode`` bit 0: specialised epilogues allowed (off: pg_debug_set_wino_epi(0)); bit 1: take the launch even when it
 // needs the general epilogue (pg_debug_set_wino(21): tests) -- by default those stay on the tile kernel, which measured 1.1-1.2x
-// faster there (tools/bench_wino_strip.py: the general epilogue costs the strip kernel half of its resident waves).
+// faster there (tools/sweeps/bench_wino_strip.py: the general epilogue costs the strip kernel half of its resident waves).
 int pgw::launch_wino_strip(WinoP& p, int mode, hipStream_t s, char* name, size_t name_len)
 {
     static const int ncb_env = getenv("PG_WSTRIP_WINO_NCB") ? atoi(getenv("PG_WSTRIP_WINO_NCB")) : 0;

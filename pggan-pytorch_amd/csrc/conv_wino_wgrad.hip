@@ -459,7 +459,7 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
 #endif
     const int nco = Cout <= 16 ? 1 : 2, nci = Cin <= 16 ? 1 : 2;
     const int gy = (Cout + 16 * nco - 1) / (16 * nco), gz_ = (Cin + 16 * nci - 1) / (16 * nci);
-    // ~384-512 workgroups: best of a 256/384/512/1024 sweep (tools/sweep_wino_wgrad.py); more workgroups pay for
+    // ~384-512 workgroups: best of a 256/384/512/1024 sweep (tools/sweeps/sweep_wino_wgrad.py); more workgroups pay for
     // themselves in the per-workgroup G^T M G commit (9216 atomics each), fewer leave CUs idle.  Round 2 measured the commit by
     // leaving it out: 5 % of the launch on n9 @64 128->256 (141 -> 134 us) but 35 % on n3 @128 64->64 (39 -> 25 us), where 128
     // workgroups add to the same 36 K addresses; the phase trace (tools/exp/wgrad_trace.py ... wino) puts a region at 14.1 k
@@ -477,7 +477,7 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
     chunks = (p.nregions + p.regions_per_block - 1) / p.regions_per_block;
     snprintf(g_ww_last, sizeof(g_ww_last), "conv_wino_wgrad_kernel<%d, %d>", nco, nci);
     const dim3 grid(chunks, gy, gz_);
-    // measured (tools/sweep_wino_wgrad.py, PG_WW_PAIR=0/1/2): the pair mapping wins 8-9 % from ~9 regions per workgroup on
+    // measured (tools/sweeps/sweep_wino_wgrad.py, PG_WW_PAIR=0/1/2): the pair mapping wins 8-9 % from ~9 regions per workgroup on
     // (n9 @64 128->256: 137 -> 126 us) and loses up to 15 % at 3 (its extra fold through LDS); 1: built-in choice, 0 / 2: never / always
     static const int pair_env = getenv("PG_WW_PAIR") ? atoi(getenv("PG_WW_PAIR")) : 1;
     if (nco == 2 && nci == 2 && (pair_env == 2 || (pair_env == 1 && p.regions_per_block >= 6))) {

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void fromrgb_fwd_kernel(
 }
 
 // thread -> pixel variant for the 8-channel stage (and 16 channels without a mask): all CO outputs of a pixel from one thread,
-// the image read once per pixel.  Measured (tools/bench_rgb_stream.py, n9 @1024^2, 8 channels): 105 us vs 239 us for the
+// the image read once per pixel.  Measured (tools/sweeps/bench_rgb_stream.py, n9 @1024^2, 8 channels): 105 us vs 239 us for the
 // (pixel, 4 couts) mapping, which is the better one from 16 masked channels on.
 template <int CO>
 __global__ __launch_bounds__(256) void fromrgb_fwd_pix_kernel(
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void fromrgb_bwd_data_wide_kernel(
 
 // Workgroups of the narrow-layer weight gradients (thread -> pixel, (features + 1) x C partial sums per thread, one shuffle + LDS fold
 // and features x C atomics per workgroup): the fold is a fixed cost per workgroup that grows with the feature count, so a thread
-// should see 192 / features pixels -- swept per shape with tools/bench_rgb_wgrad.py (n3 @512 16 features: 58 -> 35 us against the
+// should see 192 / features pixels -- swept per shape with tools/sweeps/bench_rgb_wgrad.py (n3 @512 16 features: 58 -> 35 us against the
 // former flat cap of 1024 workgroups, n3 @256 32 features: 83 -> 44 us, n3 @1024 8 features: 42 -> 36 us, n9 unchanged).
 inline int small_wgrad_grid(size_t total, int features)
 {
@@ -643,7 +643,7 @@ extern "C" int pg_fromrgb_fwd(const float* img, const float* w, const float* bia
         mask = nullptr;
     }
     const size_t npix = (size_t)N * H * W;
-    if (npix >= 65536 && npix < (1ull << 31) && (Cout == 8 || (Cout == 16 && !mask))) {       // measured: tools/bench_rgb_stream.py
+    if (npix >= 65536 && npix < (1ull << 31) && (Cout == 8 || (Cout == 16 && !mask))) {       // measured: tools/sweeps/bench_rgb_stream.py
         const int gr = grid_for(npix, 256, 256 * 16);
         hipStream_t s = (hipStream_t)stream;
         if (Cout == 8) hipLaunchKernelGGL(fromrgb_fwd_pix_kernel<8>, dim3(gr), dim3(256), 0, s, img, w, bias, mask, y, N, C, H, W, pool, scale, slope, mask_slope, mbytes, ysigns);
@@ -691,7 +691,7 @@ extern "C" int pg_fromrgb_wgrad(const float* gz, const float* img, float* dw, fl
     }
     // every workgroup ends with Cout*(C+1) atomics: >= 4 pixels per workgroup so the 4x4 stage still fills the chip,
     // ~128 workgroups beyond that so the atomics do not dominate (8x8 .. 32x32 stages)
-    int blocks = grid_for(total, 4, total < 4096 ? 128 : (total < 12288 ? 256 : 512));      // measured (tools/bench_rgb_wgrad.py)
+    int blocks = grid_for(total, 4, total < 4096 ? 128 : (total < 12288 ? 256 : 512));      // measured (tools/sweeps/bench_rgb_wgrad.py)
     const int ppb = (int)((total + blocks - 1) / blocks);
     blocks = (int)((total + ppb - 1) / ppb);
     hipLaunchKernelGGL(fromrgb_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -724,7 +724,7 @@ extern "C" int pg_torgb_bwd_data(const float* g, const float* w, float* gx,
     if (C < 1 || C > MAXC) return PG_E_UNSUP;
     if (Cin & 3) return PG_E_ALIGN;
     const size_t npix = (size_t)N * H * W;
-    if (npix >= 65536 && npix < (1ull << 29) && (Cin == 8 || Cin == 16 || Cin == 32)) {      // measured: tools/bench_rgb_stream.py
+    if (npix >= 65536 && npix < (1ull << 29) && (Cin == 8 || Cin == 16 || Cin == 32)) {      // measured: tools/sweeps/bench_rgb_stream.py
         hipStream_t s = (hipStream_t)stream;
         if (Cin == 8) hipLaunchKernelGGL((torgb_bwd_data_pix_kernel<8, false>), dim3(grid_for(npix, 256, 256 * 16)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale, (const float*)nullptr, (const float*)nullptr, 1.f);
         else if (Cin == 16) hipLaunchKernelGGL(torgb_bwd_data_narrow_kernel<16>, dim3(grid_for(npix * 4, 256, 256 * 32)), dim3(256), 0, s, g, w, gx, N, C, H, W, down, mul_scale);

@@ -47,7 +47,7 @@ struct WinoP {
 // 8-channel K chunk (16 positions x its couts x 8 channels) is then 16 contiguous pieces of couts*32 bytes, i.e. whole 128-byte
 // cache lines that are consumed completely while they are hot, instead of 32 bytes out of every Cin*4-byte row of a
 // [16][Cout][Cin] array (every line fetched from L2 four times, 2-4 us apart).  Measured on the second-generation kernel:
-// 128.6 -> 112.0 us on n9 @64 128->256 with 16-channel packs (tools/sweep_wino.py).
+// 128.6 -> 112.0 us on n9 @64 128->256 with 16-channel packs (tools/sweeps/sweep_wino.py).
 __host__ __device__ __forceinline__ size_t wino_u_index(size_t xi, size_t co, size_t ci, size_t Cout)
 {
     return (((ci >> 3) * 16 + xi) * Cout + co) * 8 + (ci & 7);

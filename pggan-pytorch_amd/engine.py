@@ -35,7 +35,7 @@ def _check_dev(t, what):
     return t.contiguous()
 
 
-# Winograd F(2x2,3x3) (csrc/conv_wino.hip) replaces the direct implicit GEMM where it measured faster (tools/sweep_wino.py):
+# Winograd F(2x2,3x3) (csrc/conv_wino.hip) replaces the direct implicit GEMM where it measured faster (tools/sweeps/sweep_wino.py):
 # 3x3 layers with a full 16-cout MFMA tile and enough 64-tile workgroups to fill the chip.  With the second-generation kernel
 # (8-channel chunks) that includes the 16-channel layers of the 512^2 stage (1.3-1.55x the direct kernel) and 8->16 at 1024^2
 # (1.16x); 16->8 and 8->8 (half of the cout tile empty) stay on the block-MFMA kernels (0.7-1.0x).

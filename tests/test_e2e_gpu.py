@@ -21,7 +21,7 @@ GRAD_TOL = 2e-3      # per-tensor gradient, rel. max-norm — small, well-condit
 # Wide / high-resolution cases: LeakyReLU' is discontinuous at 0, so among >1e6 pre-activations a few
 # lie within fp32 round-off of zero and land on different sides under a different (equally valid)
 # fp32 summation order.  Each flip perturbs the gradient by O(1/sqrt(#elements)); the reference's own
-# fp32 CPU path deviates from an fp64 evaluation by the same mechanism (tools/diag_grad_noise.py:
+# fp32 CPU path deviates from an fp64 evaluation by the same mechanism (tools/sweeps/diag_grad_noise.py:
 # 2e-3 max-norm at 128x128).  Gradients are therefore compared in relative L2 norm per tensor, with a
 # loose max-norm guard, and in global relative L2 norm.
 # Round 2 tested that claim (tests/test_fp64_adjudicator.py): ON the linear piece its forward pass selects, the HIP path matches an

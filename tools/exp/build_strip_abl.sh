@@ -1,6 +1,6 @@
 #!/bin/bash
 # Ablation builds of the row-streaming conv (csrc/conv_strip.hip, -DPG_STRIP_ABL=bits: 1 no DMA after the prologue, 2 no stores,
-# 4 one tap of nine) as ab/libpggan_abl<bits>.so; select one with PGGAN_HIP_LIB=ab/... python tools/bench_strip.py.
+# 4 one tap of nine) as ab/libpggan_abl<bits>.so; select one with PGGAN_HIP_LIB=ab/... python tools/sweeps/bench_strip.py.
 # (ab/ is git-ignored; delete the libraries afterwards: gpurun ships the directory.)
 cd "$(dirname "$0")/../.." && mkdir -p ab && python __graft_entry__.py > /dev/null || exit 1
 for a in "$@"; do

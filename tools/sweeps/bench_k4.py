@@ -1,12 +1,12 @@
 """The two 4x4 layers (latent -> 4x4 of the generator, 4x4 -> 1x1 of the discriminator) in isolation: 16 * Cout * Cin weights
-streamed against N samples.    python tools/bench_k4.py [reps]"""
+streamed against N samples.    python tools/sweeps/bench_k4.py [reps]"""
 import importlib
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 pg = importlib.import_module('pggan-pytorch_amd')
 ops, lib = pg.ops, pg._lib.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100

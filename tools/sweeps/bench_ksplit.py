@@ -1,13 +1,13 @@
 """Winograd conv with the K loop sliced across workgroups (pg_set_workspace) vs the unsplit launch vs the direct kernels, on the
 small-map layers of the 1024x1024 schedule (minibatch 3 per GPU: N = 3 in the G step, 9 in D's batched sweep).
-    python tools/bench_ksplit.py [reps]"""
+    python tools/sweeps/bench_ksplit.py [reps]"""
 import importlib
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 pg = importlib.import_module('pggan-pytorch_amd')
 ops, lib = pg.ops, pg._lib.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 50

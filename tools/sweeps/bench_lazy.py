@@ -1,6 +1,6 @@
 """Pool adjoint in the gather vs materialised gz2: backward-data conv and weight gradient of the 8->16 c2 layer at 1024^2."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch

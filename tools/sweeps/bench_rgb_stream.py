@@ -1,6 +1,6 @@
 """HBM rate of the 1x1 RGB kernels at the 1024^2 / 512^2 stages (bytes = the tensors each kernel must touch once)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

@@ -1,6 +1,6 @@
 """8->16 conv + pool with sign bytes out at 1024^2: generic tile kernel vs the block-MFMA kernel (default; tuning key 3 = 17 selects the generic kernel)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

@@ -1,13 +1,13 @@
 """Weight gradient of the 512-channel 3x3 layers on 4x4 / 8x8 maps (K = pixels: 48 .. 576) under the tile-range split
 (pg_debug_set_tuning(2, chunks)) and the block shapes of the sweep switch (pg_debug_set_tuning(1, cfg)).
-    python tools/bench_wgrad_small.py [reps]"""
+    python tools/sweeps/bench_wgrad_small.py [reps]"""
 import importlib
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 pg = importlib.import_module('pggan-pytorch_amd')
 ops, lib = pg.ops, pg._lib.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 50

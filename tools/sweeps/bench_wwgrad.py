@@ -1,13 +1,13 @@
 """Winograd weight gradient (pg_conv2d_wgrad_wino_nhwc) on the layers of the 1024x1024 schedule, n = 12 (D's batched sweep +
 tangent term) and n = 3: microseconds and algorithmic TFLOP/s per launch, inputs rotated over several sets (cold Infinity
-Cache).  A/B two builds with PGGAN_HIP_LIB.    python tools/bench_wwgrad.py [reps]"""
+Cache).  A/B two builds with PGGAN_HIP_LIB.    python tools/sweeps/bench_wwgrad.py [reps]"""
 import importlib
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 pg = importlib.import_module('pggan-pytorch_amd')
 ops, lib = pg.ops, pg._lib.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 30

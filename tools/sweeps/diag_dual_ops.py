@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): run one D-step + G-step with every kernel call shadowed by its CPU contract
 (tests/emu_ops.py) on the SAME inputs; report the per-call error.  Pinpoints a misbehaving launch."""
 import sys, os, importlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import pggan_amd as pg

@@ -2,7 +2,7 @@
 biases 1e-6, every weight tensor ~1.3e-4 at 256x256 depth 6.)  Prints, for the case of the test, the per-sample gradient norm of the
 penalty term, the penalty itself and the seed coefficient from the HIP path, the fp32 oracle and the fp64 oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): per-parameter gradient error of the HIP path vs the fp32 and fp64 CPU oracle."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import pggan_amd as pg

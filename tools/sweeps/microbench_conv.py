@@ -1,7 +1,7 @@
 """GPU microbenchmark of pg_conv2d_nhwc / wgrad on given shapes (tuning aid).
-usage: python tools/microbench_conv.py N H Cin Cout [mask]"""
+usage: python tools/sweeps/microbench_conv.py N H Cin Cout [mask]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

@@ -1,7 +1,7 @@
 """GPU timing of pg_conv2d_nhwc on the depth-8 layer shapes (tuning aid; PGGAN_HIP_LIB selects an experimental build).
-usage: python tools/sweep_conv.py [tile candidates...]   (pg_debug_set_tuning key 0; -1 = built-in cost model)"""
+usage: python tools/sweeps/sweep_conv.py [tile candidates...]   (pg_debug_set_tuning key 0; -1 = built-in cost model)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

@@ -1,6 +1,6 @@
 """All conv tile candidates (built-in split-K rule) on every 3x3 layer shape of the depth-0..8 schedule."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

@@ -1,6 +1,6 @@
 """In-workgroup K-split conv kernel for small-M layers vs the generic split-K path (tuning key 3: 8 = generic, 9 = extend to M <= 2304)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

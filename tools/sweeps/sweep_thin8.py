@@ -1,6 +1,6 @@
 """A/B of the 4x4x1 block-MFMA kernel for 8-cout layers vs the generic halo kernel (tuning key 3: 2 = generic, 4 = TH 8)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

@@ -1,7 +1,7 @@
 """GPU sweep of conv2d_wgrad tile configurations (pg_debug_set_tuning key 1) over the depth-8 layer shapes.
-usage: python tools/sweep_wgrad.py [cfgs...]"""
+usage: python tools/sweeps/sweep_wgrad.py [cfgs...]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg

@@ -1,6 +1,6 @@
 """Winograd F(2x2,3x3) conv vs the direct implicit-GEMM kernel on the wide layers."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import pggan_amd as pg
