@@ -711,6 +711,85 @@ def d_forward(D, x, groups=1):
     return s, ctx
 
 
+# ---- split forward: the real third of a D step's [real | fake | mixed] batch ahead of the other two thirds ------------------------
+# The real images' pass through D needs D's weights only -- final since the D update of the PREVIOUS iteration -- while the fake and mixed
+# thirds need G's update.  Trainer therefore evaluates the real third of iteration i + 1 on the second stream under iteration i's G step
+# (3 images, latency-bound launches: the G step leaves the chip mostly idle), and the D step then runs its forward on the other two thirds
+# only.  Both passes write into ONE set of batched activation tensors (ops.Arena), so the adjoint sweeps stay batched over all 3N images.
+class EarlyReal(object):
+    """State of a real-third pass: the image buffer [3N,C,r,r] (rows [0,N) filled), the arena with the batched activations, the first
+    pass's context, what it was computed with (weights version, stage) and the event that closes it."""
+
+    def __init__(self):
+        self.arena = ops.Arena()
+        self.x3 = None
+        self.key = None
+        self.real = None
+        self.ctx = self.scores = self.event = self.stamp = None
+
+
+_EARLY = {}
+
+
+def d_forward_real_third(D, real):
+    """First pass (current stream): D on the real images, outputs in rows [0, N) of the batched tensors.  Buffers are kept per (network,
+    stage, shape): launch plans bake their addresses, and every reader of the previous iteration is ordered before this writer (the
+    caller enqueues it behind D's update, which is behind every weight gradient of that iteration)."""
+    ops.require_gpu()
+    given = real
+    real = _check_dev(real, 'real images')
+    N = real.shape[0]
+    key = (id(D), int(D.depth), tuple(real.shape))
+    st = _EARLY.get(key)
+    if st is None:
+        for k in [k for k in _EARLY if k[0] == id(D)]:      # (one stage at a time per network: the buffers are a step's worth of activations)
+            del _EARLY[k]
+        st = _EARLY[key] = EarlyReal()
+        st.key = key
+        st.x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
+    ops.axpby_mask(real, a=1.0, out=st.x3[:N])
+    with st.arena.pass_(0):
+        st.scores, st.ctx = d_forward(D, st.x3[:N], groups=1)
+    st.real = given if given.is_contiguous() else None       # (identity of the caller's tensor: what the D step will be handed)
+    st.stamp = (D._param_version, int(D.depth), float(D.alpha))
+    return st
+
+
+def early_real_on_side(D, real):
+    """Enqueue the real-third pass of the NEXT D step on the second stream, behind everything queued there (D's deferred update) and
+    behind the upload of ``real`` (the current stream has waited for it).  Leaves the state in ``D._early_real``."""
+    main = torch.cuda.current_stream(torch._C._cuda_getDevice())
+    side = _side_stream()
+    _wait_stream(side, main)
+    pend, D._pending = D.__dict__.get('_pending'), None      # (the deferred update's event stays for the MAIN stream: this pass is behind the update in stream order)
+    try:
+        with torch.cuda.stream(side):
+            st = d_forward_real_third(D, real)
+            st.event = torch.cuda.Event()
+            _record_event(st.event, side)
+    finally:
+        D._pending = pend
+    real.record_stream(side)
+    D._early_real = st
+    return st
+
+
+def _merge_ctx(D, first, rest, x3, N):
+    """The context of the whole batch from the contexts of the two passes: every tensor of a pass is a row range of a batched tensor."""
+    def whole(a, b):
+        base = a._base if a._base is not None else a
+        if b._base is not None and b._base is base and base.shape[0] == a.shape[0] + b.shape[0]:
+            return base
+        raise RuntimeError('split D forward: the two passes did not write into one tensor')
+    ctx = dict(NB=3 * N, groups=3, depth=first['depth'], alpha=first['alpha'], x=x3, recs=[])
+    for ra, rb in zip(first['recs'], rest['recs']):
+        rec = {}
+        for k, v in ra.items():
+            rec[k] = whole(v, rb[k]) if torch.is_tensor(v) else v
+        ctx['recs'].append(rec)
+    return ctx
+
+
 def _slice_ctx(ctx, a, b, g0, g1):
     """View of a batched context restricted to images [a,b) == groups [g0,g1)."""
     sub = dict(NB=b - a, groups=g1 - g0, depth=ctx['depth'], alpha=ctx['alpha'], x=ctx['x'][a:b], recs=[])
@@ -1117,11 +1196,22 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     mix = _check_dev(mix, 'mixing factors').view(-1)
     N = real.shape[0]
     D._sync_version()
-    x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
-    ops.axpby_mask(real, a=1.0, out=x3[:N])                                   # device copy (plumbing; a C-ABI launch so that plans.py records it)
-    generator_forward(G, latents, out=x3[N:2 * N])                            # :51-52  (no graph kept)
-    ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                      # :19
-    s, ctx = d_forward(D, x3, groups=3)                                       # :47,54,20
+    early = take_early_real(D, real)
+    if early is not None:
+        # the real third is already through D (Trainer, under the previous G step): the other two thirds follow into the same tensors
+        x3 = early.x3
+        generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52  (no graph kept)
+        ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
+        with early.arena.pass_(1):
+            s_rest, ctx_rest = d_forward(D, x3[N:], groups=2)                 # :54,20
+        ctx = _merge_ctx(D, early.ctx, ctx_rest, x3, N)
+        s = early.scores._base if early.scores._base is not None else early.scores
+    else:
+        x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
+        ops.axpby_mask(real, a=1.0, out=x3[:N])                               # device copy (plumbing; a C-ABI launch so that plans.py records it)
+        generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52  (no graph kept)
+        ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
+        s, ctx = d_forward(D, x3, groups=3)                                   # :47,54,20
     sub = _slice_ctx(ctx, 2 * N, 3 * N, 2, 3)
     gimg, adj = d_backward(D, sub, _ones(N, real.device), full=False, want_gimg=True, save_adjoints=True)  # :25-28
     ss = ops.row_sumsq(gimg)
@@ -1129,6 +1219,20 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     d_cost, d_real_loss, d_fake_loss, gscore = ops.d_loss(s, gp, N, iwass_epsilon)   # :48,55,62
     state = dict(D=D, ctx=ctx, sub=sub, adj=adj, u=u, gscore=gscore, N=N, scores=s, gp=gp)
     return d_cost, d_real_loss, d_fake_loss, state
+
+
+def take_early_real(D, real):
+    """The real-third pass Trainer left for THIS real batch, if it is still valid (same tensor, same weights, same stage); the current
+    stream is ordered behind it.  None: the caller runs the whole batch."""
+    st = D.__dict__.pop('_early_real', None)
+    if st is None:
+        return None
+    if (st.real is not real or st.stamp != (D._param_version, int(D.depth), float(D.alpha)) or float(D.alpha) < 1.0
+            or getattr(D, 'pixelnorm', False)):
+        return None
+    if st.event is not None:
+        _wait_event(torch.cuda.current_stream(torch._C._cuda_getDevice()), st.event)
+    return st
 
 
 def d_loss_backward(state, scale=1.0):

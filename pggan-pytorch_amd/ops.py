@@ -98,6 +98,69 @@ def require_gpu():
     _lib.load()
 
 
+# ------------------------------------------------------------------------------------ output allocation
+# engine.d_forward can run as TWO passes over disjoint image ranges that must leave their outputs in ONE set of batched tensors (the
+# real third of a D step's [real | fake | mixed] batch is evaluated ahead of the other two thirds): inside an ``Arena`` context the
+# forward ops below take their outputs from the arena instead of the allocator.  The first pass (leading extent n) creates every buffer
+# with leading extent 3n and gets rows [0, n); the second pass (leading extent 2n) walks the same buffers in the same order and gets rows
+# [n, 3n).  Buffers are kept for the next iteration (the launch plans bake their addresses).  Outside a context: torch.empty.
+_ARENA = None
+
+
+def _empty(shape, device=None, dtype=torch.float32):
+    a = _ARENA
+    if a is None:
+        return torch.empty(shape, device=device, dtype=dtype)
+    return a.take(tuple(shape), device, dtype)
+
+
+class Arena(object):
+    def __init__(self):
+        self.bufs = []
+        self.i = 0
+        self.part = None
+
+    def take(self, shape, device, dtype):
+        lead, rest = shape[0], shape[1:]
+        if self.part == 0:
+            if self.i == len(self.bufs):
+                self.bufs.append(torch.empty((3 * lead,) + rest, device=device, dtype=dtype))
+            big = self.bufs[self.i]
+            unit = lead
+        else:
+            if self.i >= len(self.bufs) or lead % 2:
+                raise RuntimeError('split D forward: the second pass asks for an output the first pass did not create')
+            big = self.bufs[self.i]
+            unit = lead // 2
+        if tuple(big.shape) != (3 * unit,) + rest or big.dtype != dtype:
+            raise RuntimeError('split D forward: output %d differs between the passes (%s %s vs %s x3)' % (self.i, tuple(big.shape), big.dtype, shape))
+        self.i += 1
+        return big[:unit] if self.part == 0 else big[unit:]
+
+    def pass_(self, part):
+        return _ArenaPass(self, part)
+
+
+class _ArenaPass(object):
+    def __init__(self, arena, part):
+        self.arena, self.part = arena, part
+
+    def __enter__(self):
+        global _ARENA
+        if _ARENA is not None:
+            raise RuntimeError('nested output arenas')
+        self.arena.part, self.arena.i = self.part, 0
+        _ARENA = self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = None
+        if exc[0] is None and self.arena.i != len(self.arena.bufs):
+            raise RuntimeError('split D forward: the passes created a different number of outputs (%d of %d)' % (self.arena.i, len(self.arena.bufs)))
+        return False
+
+
 # ------------------------------------------------------------------------------------ conv
 def _is_bytes(t):
     return t is not None and t.dtype == torch.uint8
@@ -113,11 +176,11 @@ def conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, mask_s
     ``signs_out`` (forward mode) additionally returns the sign bytes of y: (y, bytes).  Both may raise ops.Unsupported."""
     cout, cin = w.shape[2], w.shape[3]
     ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
-    y = out if out is not None else torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
+    y = out if out is not None else _empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
     flags = (FLAG_UPSAMPLE if ups else 0) | (FLAG_MASK_BYTES if _is_bytes(mask) else 0)
     sb = None
     if signs_out:
-        sb = torch.empty((N, ho, wo, cout // 4), device=x.device, dtype=torch.uint8)
+        sb = _empty((N, ho, wo, cout // 4), device=x.device, dtype=torch.uint8)
         mask, flags = sb, flags | FLAG_SIGNS_OUT
     _lib.call('pg_conv2d_nhwc', _p(x), _p(w), _p(bias), _p(mask), _p(y), N, Hin, Win, cin, cout, ks, pad,
               flags, scale, slope, mask_slope, _stream_with_workspace() if ks == 4 else _stream())
@@ -177,14 +240,14 @@ def conv2d_wino(x, u, bias, N, H, W, scale, slope=1.0, mask=None, mask_slope=0.2
     cout, cin = u.shape[1], u.shape[2]
     flags = (FLAG_UPSAMPLE if ups else 0) | (FLAG_MASK_BYTES if _is_bytes(mask) or _is_bytes(upmask) else 0) | (FLAG_Y_BYTES if y_bytes else 0)
     if y_bytes:
-        y = torch.empty((N, H, W, cout // 4), device=x.device, dtype=torch.uint8)
+        y = _empty((N, H, W, cout // 4), device=x.device, dtype=torch.uint8)
     else:
-        y = out if out is not None else torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
-    yp = torch.empty((N, H // 2, W // 2, cout), device=x.device, dtype=torch.float32) if pool else None
-    yu = torch.empty((N, 2 * H, 2 * W, cout), device=x.device, dtype=torch.float32) if unpool else None
+        y = out if out is not None else _empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    yp = _empty((N, H // 2, W // 2, cout), device=x.device, dtype=torch.float32) if pool else None
+    yu = _empty((N, 2 * H, 2 * W, cout), device=x.device, dtype=torch.float32) if unpool else None
     sb = None
     if signs_out:                                  # plain forward launch: (y, sign bytes of y)
-        sb = torch.empty((N, H, W, cout // 4), device=x.device, dtype=torch.uint8)
+        sb = _empty((N, H, W, cout // 4), device=x.device, dtype=torch.uint8)
         mask, flags = sb, flags | FLAG_SIGNS_OUT
     _lib.call('pg_conv2d_wino_nhwc', _p(x), _p(u), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
               _p(yu), _p(upmask), up_mul, N, H, W, cin, cout, flags, scale, slope, mask_slope, _stream_with_workspace())
@@ -227,10 +290,10 @@ def conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, slope=1.0, mask=None, m
     ho, wo = Hin + 2 * pad - ks + 1, Win + 2 * pad - ks + 1
     flags = (FLAG_MASK_BYTES if _is_bytes(mask) else 0) | (FLAG_Y_BYTES if y_bytes else 0)
     if y_bytes:
-        y = torch.empty((N, ho, wo, cout // 4), device=x.device, dtype=torch.uint8)
+        y = _empty((N, ho, wo, cout // 4), device=x.device, dtype=torch.uint8)
     else:
-        y = torch.empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
-    yp = torch.empty((N, ho // 2, wo // 2, cout), device=x.device, dtype=torch.float32)
+        y = _empty((N, ho, wo, cout), device=x.device, dtype=torch.float32)
+    yp = _empty((N, ho // 2, wo // 2, cout), device=x.device, dtype=torch.float32)
     _lib.call('pg_conv2d_pool_nhwc', _p(x), _p(w), _p(bias), _p(mask), _p(y), _p(yp), _p(other), a, b, 1 if pool_only else 0,
               N, Hin, Win, cin, cout, ks, pad, flags, scale, slope, mask_slope, _stream())
     return y, yp
@@ -326,11 +389,11 @@ def pack_dgrad_weights_batched(flat_w, flat_wt, layers):
 # --------------------------------------------------------------------------------- from/toRGB
 def fromrgb_fwd(img, w, bias, N, C, H, W, scale, slope, pool=False, mask=None, mask_slope=0.2, signs_out=False):
     cout = w.shape[0]
-    y = torch.empty((N, H, W, cout), device=img.device, dtype=torch.float32)
+    y = _empty((N, H, W, cout), device=img.device, dtype=torch.float32)
     flags = (1 if pool else 0) | (FLAG_MASK_BYTES if _is_bytes(mask) else 0)
     sb = None
     if signs_out:
-        sb = torch.empty((N, H, W, cout // 4), device=img.device, dtype=torch.uint8)
+        sb = _empty((N, H, W, cout // 4), device=img.device, dtype=torch.uint8)
         mask, flags = sb, flags | FLAG_SIGNS_OUT
     _lib.call('pg_fromrgb_fwd', _p(img), _p(w), _p(bias), _p(mask), _p(y), N, C, H, W, cout, flags,
               scale, slope, mask_slope, _stream())
@@ -443,8 +506,8 @@ MBSTD_STATS_STRIDE = 136        # PG_MBSTD_STATS_STRIDE (include/pggan_hip.h): [
 
 def mbstd_fwd(x, groups, cp):
     NB, H, W, C = x.shape
-    y = torch.empty((NB, H, W, cp), device=x.device, dtype=torch.float32)
-    stats = torch.empty((groups, MBSTD_STATS_STRIDE), device=x.device, dtype=torch.float32)
+    y = _empty((NB, H, W, cp), device=x.device, dtype=torch.float32)
+    stats = _empty((groups, MBSTD_STATS_STRIDE), device=x.device, dtype=torch.float32)
     _lib.call('pg_mbstd_fwd', _p(x), _p(y), _p(stats), groups, NB // groups, H * W, C, cp, _stream())
     return y, stats
 
@@ -523,7 +586,7 @@ def mbstd_bwd_global(gy, x, stats, cp, apply_mask, gsums, nranks, mask_slope=0.2
 # ------------------------------------------------------------------------------------- linear
 def linear1_fwd(h, w, b):
     N, C = h.shape[0], h.numel() // h.shape[0]
-    s = torch.empty((N,), device=h.device, dtype=torch.float32)
+    s = _empty((N,), device=h.device, dtype=torch.float32)
     _lib.call('pg_linear1_fwd', _p(h), _p(w), _p(b), _p(s), N, C, _stream())
     return s
 

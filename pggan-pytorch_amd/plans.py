@@ -148,7 +148,7 @@ def _replay(plan):
 def _new_plan(key):
     """A plan pins one step's worth of activations: when a network pair moves to another growth stage / minibatch, the plans of
     the stage it left are dropped (one D plan and one G plan per network pair at any time)."""
-    for k in [k for k in _CACHE if k[:3] == key[:3] and k != key]:
+    for k in [k for k in _CACHE if k[:3] == key[:3] and k[:9] != key[:9]]:      # (the with / without early-real-third variants of a stage live side by side)
         del _CACHE[k]
     while len(_CACHE) >= MAX_PLANS:
         _CACHE.popitem(last=False)          # least recently used
@@ -168,16 +168,28 @@ def _prologue(*nets):
 
 def d_step(D, G, real, latents, mix, lam, eps, target):
     """Plan-replayed ``d_loss_forward`` + ``d_loss_backward``.  Returns (d_cost, d_real_loss, d_fake_loss)."""
-    key = ('D', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(D.depth), tuple(real.shape), tuple(latents.shape), float(lam), float(eps), float(target))
+    _prologue(D, G)
+    # the real third may already be through D (engine.EarlyReal, left by Trainer for exactly this batch): a plan of its own -- its body
+    # starts from the batched tensors of that pass, whose addresses are stable, and never touches ``real``
+    early = D.__dict__.get('_early_real')
+    if early is not None and not (early.real is real and early.stamp == (D._param_version, int(D.depth), float(D.alpha))):
+        early = D.__dict__.pop('_early_real') and None
+    key = ('D', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(D.depth), tuple(real.shape), tuple(latents.shape), float(lam), float(eps), float(target),
+           id(early.arena) if early is not None else 0)
     g = _CACHE.get(key)
     if g is None:
         g = _new_plan(key)
         g.static_in = (torch.empty_like(real), torch.empty_like(latents), torch.empty_like(mix))
     else:
         _CACHE.move_to_end(key)
-    for dst, src in zip(g.static_in, (real, latents, mix)):
+    for dst, src in zip(g.static_in, (real, latents, mix)) if early is None else zip(g.static_in[1:], (latents, mix)):
         dst.copy_(src)
-    _prologue(D, G)
+    if early is not None:
+        early.real = g.static_in[0]          # (what the body hands to d_loss_forward; identity is all take_early_real compares)
+        if g.entries is not None:            # replay: the wait d_loss_forward would issue
+            D.__dict__.pop('_early_real', None)
+            if early.event is not None:
+                torch.cuda.current_stream().wait_event(early.event)
 
     def body():
         # The plan itself never joins the weight-gradient stream: whether the caller's next launch needs the join is not known

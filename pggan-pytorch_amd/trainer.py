@@ -136,7 +136,7 @@ class Trainer(object):
 
     def __init__(self, D, G, D_loss, G_loss, optimizer_d, optimizer_g, dataset, dataiter, random_latents_generator,
                  D_training_repeats=1, tick_nimg_default=2 * 1000, resume_nimg=0, parallel=None, input_transform=None,
-                 prefetch_inputs=False, global_stddev=False):
+                 prefetch_inputs=False, global_stddev=False, early_real_forward=None):
         # networks, losses, optimizers, data sources: the names are API (plugins read and replace them)
         self.D, self.G = D, G
         self.D_loss, self.G_loss = D_loss, G_loss
@@ -160,6 +160,10 @@ class Trainer(object):
         self._inputs = _InputPrefetch()
         self.prefetch_inputs = bool(prefetch_inputs)
         self.input_transform = input_transform
+        # the real third of the next D step's batched D forward runs under this iteration's G step (engine.EarlyReal); None: on
+        # whenever the step qualifies (PGGAN_EARLY_REAL=0 turns it off)
+        self.early_real_forward = (os.environ.get('PGGAN_EARLY_REAL', '1') != '0') if early_real_forward is None else bool(early_real_forward)
+        self._next_reals = None               # (batch, iterator it was drawn from) consumed one iteration ahead for that pass
         self._average_in_allreduce = {}
         self._exchanges = {}
         # plugins.TimeMonitor: {'every': k, 'pairs': [(start event, end event), ...]} -- every k-th iteration the last D update
@@ -259,6 +263,35 @@ class Trainer(object):
         return (self.G_loss is wgan_gp_loss.wgan_gp_G_loss and hasattr(self.D, '_flat_param')
                 and not wgan_gp_loss._graphs_on(self.D) and not wgan_gp_loss._graphs_on(self.G))
 
+    def _draw_reals(self):
+        reals = self._inputs.take(self.dataiter)                                  # :92
+        if self.input_transform is not None:
+            reals = self.input_transform(reals)
+        return reals
+
+    def _early_real_ok(self):
+        """May the real third of the NEXT iteration's D forward run now?  Only when that iteration is known to use this stage's networks
+        unchanged: alpha == 1 now and after the image counter's next value (every plugin with a ``schedule`` -- DepthManager -- is asked),
+        one D update per iteration, the product's own networks and losses, eager or plan-replayed steps (not the captured 4x4 stage), no
+        statistic exchange inside the pass."""
+        from . import wgan_gp_loss
+        D = self.D
+        if not (self.early_real_forward and self.D_training_repeats == 1 and hasattr(D, '_flat_param') and D._flat_param.is_cuda
+                and self.D_loss is wgan_gp_loss.wgan_gp_D_loss and engine.ASYNC_WGRAD):
+            return False
+        if float(D.alpha) < 1.0 or getattr(D, 'pixelnorm', False) or D.__dict__.get('_global_stddev') is not None:
+            return False
+        if wgan_gp_loss._replay_mode(D) == 'graph':
+            return False
+        for unit in self.plugin_queues.values():
+            for _, _, plugin in unit:
+                sched = getattr(plugin, 'schedule', None)
+                if sched is not None:
+                    depth, alpha = sched(self.cur_nimg)
+                    if depth != int(D.depth) or alpha < 1.0:
+                        return False
+        return True
+
     def train(self):
         """One iteration: ``D_training_repeats`` discriminator updates, then one generator update
         (reference trainer.py:85-115; line numbers below refer to it)."""
@@ -266,9 +299,13 @@ class Trainer(object):
         latents = _to_device(self.random_latents_generator())                     # :86
         d_losses = (0, 0, 0)
         for rep in range(self.D_training_repeats):                                # :90
-            reals = self._inputs.take(self.dataiter)                              # :92
-            if self.input_transform is not None:
-                reals = self.input_transform(reals)
+            ahead, self._next_reals = self._next_reals, None
+            if ahead is not None and ahead[1] is self.dataiter:
+                reals = ahead[0]                                                  # drawn (in order) at the end of the previous iteration
+            else:
+                if ahead is not None:                                             # (the iterator was replaced in between: that batch is not this stage's)
+                    self.D.__dict__.pop('_early_real', None)
+                reals = self._draw_reals()
             self.cur_nimg += reals.size(0) * world                                # :93 (global images)
             last = rep == self.D_training_repeats - 1
             probe = self.d_step_probe
@@ -288,6 +325,15 @@ class Trainer(object):
                 # the tail of the last D update (all-reduce, Adam, derived weights) runs on the second stream under the
                 # generator forward that opens the G step; the main stream re-joins at its first use of D (engine.wait_pending)
                 engine.defer_to_side(self.D, self._d_update)
+                if self._early_real_ok():
+                    # ... and behind it the real third of the NEXT D step's forward (D's weights are final now; the G step that follows
+                    # is 3-image, latency-bound work on the main stream)
+                    nxt = self._draw_reals()
+                    if getattr(nxt, 'is_cuda', False):
+                        self._next_reals = (nxt, self.dataiter)
+                        engine.early_real_on_side(self.D, nxt)
+                    else:
+                        self._next_reals = (nxt, self.dataiter)
             else:
                 engine._join_side()                  # (a replayed plan leaves the weight gradients un-joined; a second join is free)
                 self._d_update()
