@@ -728,7 +728,7 @@ class EarlyReal(object):
         self.ctx = self.scores = self.event = self.stamp = None
 
 
-_EARLY = {}
+EARLY_STATS = {'passes': 0, 'used': 0, 'dropped': 0}
 
 
 def d_forward_real_third(D, real):
@@ -739,17 +739,16 @@ def d_forward_real_third(D, real):
     given = real
     real = _check_dev(real, 'real images')
     N = real.shape[0]
-    key = (id(D), int(D.depth), tuple(real.shape))
-    st = _EARLY.get(key)
-    if st is None:
-        for k in [k for k in _EARLY if k[0] == id(D)]:      # (one stage at a time per network: the buffers are a step's worth of activations)
-            del _EARLY[k]
-        st = _EARLY[key] = EarlyReal()
+    key = (int(D.depth), tuple(real.shape))
+    st = D.__dict__.get('_early_buffers')                   # (owned by the network: one stage at a time, a step's worth of activations)
+    if st is None or st.key != key:
+        st = D._early_buffers = EarlyReal()
         st.key = key
         st.x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
     ops.axpby_mask(real, a=1.0, out=st.x3[:N])
     with st.arena.pass_(0):
         st.scores, st.ctx = d_forward(D, st.x3[:N], groups=1)
+    EARLY_STATS['passes'] += 1
     st.real = given if given.is_contiguous() else None       # (identity of the caller's tensor: what the D step will be handed)
     st.stamp = (D._param_version, int(D.depth), float(D.alpha))
     return st
@@ -1229,9 +1228,11 @@ def take_early_real(D, real):
         return None
     if (st.real is not real or st.stamp != (D._param_version, int(D.depth), float(D.alpha)) or float(D.alpha) < 1.0
             or getattr(D, 'pixelnorm', False)):
+        EARLY_STATS['dropped'] += 1
         return None
     if st.event is not None:
         _wait_event(torch.cuda.current_stream(torch._C._cuda_getDevice()), st.event)
+    EARLY_STATS['used'] += 1
     return st
 
 

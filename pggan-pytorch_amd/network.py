@@ -306,6 +306,7 @@ class _FlatParamsMixin(object):
         d['_grad_hook'] = d['_grad_exchange'] = None
         d['_global_stddev'] = None               # (a process-group handle: a reloaded network starts in the local-shard mode)
         d['_plan_unjoined'] = False
+        d['_early_real'] = d['_early_buffers'] = None      # (device buffers / events of the real-third pass: rebuilt on demand)
         d['_plist'] = None
         d['_layer_list'] = None
         d['_derived_bwd_ev'] = None

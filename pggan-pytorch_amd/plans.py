@@ -174,6 +174,7 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
     early = D.__dict__.get('_early_real')
     if early is not None and not (early.real is real and early.stamp == (D._param_version, int(D.depth), float(D.alpha))):
         early = D.__dict__.pop('_early_real') and None
+        engine.EARLY_STATS['dropped'] += 1
     key = ('D', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(D.depth), tuple(real.shape), tuple(latents.shape), float(lam), float(eps), float(target),
            id(early.arena) if early is not None else 0)
     g = _CACHE.get(key)
@@ -188,6 +189,7 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
         early.real = g.static_in[0]          # (what the body hands to d_loss_forward; identity is all take_early_real compares)
         if g.entries is not None:            # replay: the wait d_loss_forward would issue
             D.__dict__.pop('_early_real', None)
+            engine.EARLY_STATS['used'] += 1
             if early.event is not None:
                 torch.cuda.current_stream().wait_event(early.event)
 

@@ -377,7 +377,10 @@ def test_launch_plan_replay_matches_eager(foreign_optimizer):
                     for (_, ma, va), (_, mb_, vb) in zip(oa._flat.values(), ob._flat.values()):
                         mb_.copy_(ma)
                         vb.copy_(va)
-        assert pg.plans.STATS['recorded'] == 4 and pg.plans.STATS['replayed'] == 2 * (3 + 1), pg.plans.STATS   # (D, G) x two stages; iterations 3..5 and 9
+        # (D, G) x two stages.  G: two eager steps, one recorded, then replay (iterations 3..5 and 9).  D: the first step of a stage runs the whole
+        # batch (nothing was evaluated ahead), from the second on the real third is through D already (engine.EarlyReal) -- a plan of its own,
+        # recorded one iteration later than G's (replays: iterations 4, 5)
+        assert pg.plans.STATS['recorded'] == 4 and pg.plans.STATS['replayed'] == (3 + 1) + 2, pg.plans.STATS
     finally:
         wl._use_plans = True
         wl.enable_graphs(False)
@@ -449,6 +452,79 @@ def test_time_monitor_d_step_probe():
     assert tr.cur_tick == 2
     assert 0.0 < tr.stats['d_gp_ms']['val'] < 1e3 and tr.stats['img/s']['val'] > 0
     assert tr.stats['sec']['tick'] > 0 and not tr.d_step_probe['pairs']          # consumed at the tick boundary
+
+
+@pytest.mark.parametrize('plans_on', [False, True])
+def test_early_real_third_matches_whole_batch_forward(plans_on, tmp_path):
+    """The real third of the next D step's batched D forward runs on the second stream under the G step (engine.EarlyReal: both passes
+    write ONE set of batched activations through ops.Arena, Trainer draws the next real batch one iteration ahead, DepthManager's schedule
+    says whether the next iteration still is this stage).  Two trainers with the same seeds, one with the early pass and one without, stepped
+    side by side through a stabilisation span, a fade (no early pass there) and a stage change: per-iteration pre-Adam gradients agree,
+    weights are re-synchronised after every iteration, the same real batches are consumed in the same order, the early pass is really
+    used (and dropped / not started where it must be), and a whole-module pickle taken while a pass is pending works."""
+    wl = pg.wgan_gp_loss
+    eng = pg.engine
+
+    def build(early):
+        torch.manual_seed(17)
+        shape = (1, 3, 32, 32)
+        kw = dict(fmap_base=512, fmap_max=64)
+        G = pg.Generator(shape, latent_size=64, **kw).cuda()
+        D = pg.Discriminator(shape, **kw).cuda()
+        opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+        opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+        ds = pg.utils.SyntheticDataset(32, 3, seed=5)
+        seen = []
+
+        def loader(n):
+            it = ds.loader(n)
+
+            def gen():
+                while True:
+                    b = next(it)
+                    seen.append(float(b.flatten()[0]))
+                    yield b
+            return gen()
+        tr = pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, None, None, early_real_forward=early)
+        span = 6 * 8
+        tr.register_plugin(pg.DepthManager(loader, lambda n: pg.utils.device_latents(n, 64, seed=3), 3, minibatch_default=8,
+                                           lod_training_nimg=span, lod_transition_nimg=span))
+        import heapq
+        for q in tr.plugin_queues.values():
+            heapq.heapify(q)
+        return tr, seen
+    wl.enable_graphs(False)
+    wl._use_graphs = 'auto' if plans_on else False
+    eng.EARLY_STATS.update(passes=0, used=0, dropped=0)
+    try:
+        (tra, seen_a), (trb, seen_b) = build(True), build(False)
+        for it in range(20):                                   # depth 0: 6 iterations, fade into depth 1: 6, depth 1: 6, fade into 2 ...
+            out = []
+            for tr in (tra, trb):
+                wl.manual_seed(200 + it)
+                tr.train()
+                torch.cuda.synchronize()
+                out.append((grads_by_name(tr.D), grads_by_name(tr.G)))
+            assert_same_contributions(out[0][0], out[1][0])
+            assert_same_contributions(out[0][1], out[1][1], tol=0.3, total=5e-2)
+            assert (int(tra.D.depth), float(tra.D.alpha), tra.cur_nimg) == (int(trb.D.depth), float(trb.D.alpha), trb.cur_nimg)
+            for a, b in ((tra.G, trb.G), (tra.D, trb.D)):
+                with torch.no_grad():
+                    b._flat_param.copy_(a._flat_param)
+                b.mark_params_changed()
+            for oa, ob in ((tra.optimizer_g, trb.optimizer_g), (tra.optimizer_d, trb.optimizer_d)):
+                for (_, ma, va), (_, mb_, vb) in zip(oa._flat.values(), ob._flat.values()):
+                    mb_.copy_(ma)
+                    vb.copy_(va)
+            if it == 9:                                        # a pass for iteration 10 is pending on the second stream right now
+                torch.save(tra.D, str(tmp_path / 'd.dat'))
+                assert torch.load(str(tmp_path / 'd.dat'), weights_only=False).__dict__.get('_early_real') is None
+        # the trainer that looks ahead has drawn at most one batch more, and the batches it CONSUMED are the other one's, in order
+        assert seen_a[:len(seen_b)] == seen_b and len(seen_a) - len(seen_b) in (0, 1)
+        st = eng.EARLY_STATS
+        assert st['passes'] >= 5 and st['used'] >= st['passes'] - 2 and st['dropped'] <= 2, st       # 5 per stabilisation span (depth 0 replays a hipGraph in 'auto': none there)
+    finally:
+        wl.enable_graphs(False)
 
 
 def test_whole_module_pickle_roundtrip(tmp_path):
