@@ -268,13 +268,24 @@ def _max_over_ranks(dt, dp):
     return float(t)
 
 
-def timed_steps(tr, steps, warmup, dp, fn=None):
+def _window_marker():
+    """One launch of a kernel no train step uses (minmax_kernel of sound.hip) on the current stream: delimits the timed region in
+    a rocprofv3 counter collection, so that tools/summarize_profile.py sums the kernels of the window and not those of the setup."""
+    import pggan_amd as pg
+    buf = _window_marker.__dict__.setdefault('buf', torch.zeros(4, device='cuda'))
+    pg._lib.call('pg_minmax_f32', buf.data_ptr(), 2, buf.data_ptr() + 8, torch.cuda.current_stream().cuda_stream)
+
+
+def timed_steps(tr, steps, warmup, dp, fn=None, markers=False):
     fn = tr.train if fn is None else fn
     for _ in range(warmup):
         fn()
     if dp is not None:
         dp.barrier()
     torch.cuda.synchronize()
+    if markers:
+        _window_marker()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     stamps = []
     for _ in range(steps):
@@ -285,9 +296,14 @@ def timed_steps(tr, steps, warmup, dp, fn=None):
     head = [b - a for a, b in zip([t0] + stamps[:9], stamps[:10])]
     HOST_ENQUEUE['free_ms'] = 1e3 * sorted(head)[len(head) // 2]   # median of the first ten steps after the synchronisation: the host running free
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    if markers:
+        _window_marker()
+        torch.cuda.synchronize()
     if dp is not None:
         dp.barrier()
-    return _max_over_ranks(time.perf_counter() - t0, dp)
+        dt_local = time.perf_counter() - t0
+    return _max_over_ranks(dt_local, dp)
 
 
 HOST_ENQUEUE = {'ms': None, 'free_ms': None}
@@ -647,7 +663,7 @@ def main():
         tr.train()
     if dp is not None:
         dp.stats.update(collectives=0, bytes=0)
-    dt = timed_steps(tr, args.steps, args.warmup, dp, fn=d_step_fn(tr) if args.d_step_only else None)
+    dt = timed_steps(tr, args.steps, args.warmup, dp, fn=d_step_fn(tr) if args.d_step_only else None, markers=args.d_step_only)
     ms_per_step = 1e3 * dt / args.steps
     host_ms, host_free_ms = HOST_ENQUEUE['ms'], HOST_ENQUEUE['free_ms']
     # D step + gradient penalty + Adam(D) of the headline stage (its own timed loop, after the contract's)

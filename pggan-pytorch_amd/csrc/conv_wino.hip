@@ -29,6 +29,9 @@ namespace {
 using namespace pgw;
 
 template <int VEC> struct WRow { static constexpr int value = VEC == 4 ? 24 : 12; };   // LDS row stride (floats), conflict-free b128 / b64
+#ifndef PG_WINO_PRIO
+#define PG_WINO_PRIO 3                         // s_setprio of the MFMA phase of conv_wino2_kernel (0: off; A/B builds)
+#endif
 constexpr int XMAX = 400;                      // halo pixels per workgroup: 18x18 (8x8 tiles) .. 4 x 10x10 (8x8 images)
 
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin)
@@ -395,6 +398,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
             d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
         }
         PG_STAMP(4);
+        // a wave in its MFMA phase issues ahead of the co-resident waves that wait for / read their patches (round 5: -1.7 % over the layer
+        // set alone, -0.045 ms per 1024^2 step, three same-box pairs; raising it before the input transform instead: +0.08 ms)
+        __builtin_amdgcn_s_setprio(PG_WINO_PRIO);
         const lds_cptr ub = (lds_cptr)lds + ubyte + ((k0 >> 3) & 1) * UBYTES;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                         // one row of Winograd positions at a time: 4 x NCB accumulators interleaved
@@ -415,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
                         }
         }
         PG_STAMP(5);
+        __builtin_amdgcn_s_setprio(0);
         PG_STAMP(6);
         };
     chunk(kbeg, std::true_type{});

@@ -469,7 +469,8 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
     //  of 3 + 9 images) 10.573 / 10.573 | 10.607 / 10.617; 512^2 and 256^2 stages equal; 128^2 stage (16 + 48 images) 21.17 / 21.16 | 20.97 / 21.01;
     //  256 and 768 lose at 1024^2: 10.66 / 10.75.  Alone on the device 512 is 1-2 % faster than 384.)
     static const int target_env = [] { const char* t = getenv("PG_WW_TARGET"); return t ? atoi(t) : 0; }();
-    const int target = target_env > 0 ? target_env : (N + N2 <= 12 ? 384 : 512);
+    static const int target3_env = [] { const char* t = getenv("PG_WW_TARGET3"); return t ? atoi(t) : 0; }();        // launches of <= 4 images (the G step's): sweeps
+    const int target = (target3_env > 0 && N + N2 <= 4) ? target3_env : target_env > 0 ? target_env : (N + N2 <= 12 ? 384 : 512);
     int chunks = (target + gy * gz_ - 1) / (gy * gz_);
     if (chunks > p.nregions) chunks = p.nregions;
     if (chunks < 1) chunks = 1;

@@ -18,7 +18,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --o
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq -o p --output-format csv -- $PMCB > $OUT/pmc_sq.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p --output-format csv -- $PMCB > $OUT/pmc_lds.log 2>&1
 # the north-star window by counter: D step + gradient penalty + Adam(D) only (3 passes)
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq_dstep -o p --output-format csv -- $PMCB --d-step-only > $OUT/pmc_sq_dstep.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_sq_dstep -o p --output-format csv -- $PMCB --d-step-only --warmup 3 --steps 3 > $OUT/pmc_sq_dstep.log 2>&1      # (argparse: the last --warmup / --steps win; the timed passes replay the launch plan and sit between two marker launches)
 # per-layer table of the Winograd conv launches of one step, each alone on cold inputs (tools/layer_table.py)
 if [ -z "$EXTRA" ]; then
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc_layers -o p --output-format csv -- python $R/tools/layer_table.py run $OUT/layers.json > $OUT/pmc_layers.log 2>&1

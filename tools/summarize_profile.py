@@ -19,13 +19,25 @@ def short(k):
     return k.split('(')[0]
 
 
-def load_pmc(path):
+def load_pmc(path, window=False):
+    """window: keep only the dispatches between the two marker launches (minmax_kernel) bench.py --d-step-only puts around its timed
+    steps -- the kernels of the window, not those of the set-up (network construction, first derivation of the weights, warm-up)."""
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(dict)
     if not os.path.exists(path):
         return agg, disp
+    lo = hi = None
+    if window:
+        with open(path) as f:
+            marks = sorted({int(row['Dispatch_Id']) for row in csv.DictReader(f) if 'minmax_kernel' in row['Kernel_Name']})
+        if len(marks) >= 2:
+            lo, hi = marks[0], marks[-1]
+        else:
+            print('load_pmc: no window markers in %s (whole process summed)' % path)
     with open(path) as f:
         for row in csv.DictReader(f):
+            if lo is not None and not (lo < int(row['Dispatch_Id']) < hi):
+                continue
             k = short(row['Kernel_Name'])
             agg[k][row['Counter_Name']] += float(row['Counter_Value'])
             disp[k][row['Dispatch_Id']] = int(row['End_Timestamp']) - int(row['Start_Timestamp'])
@@ -39,7 +51,7 @@ fetch, fd = load_pmc(os.path.join(out, 'pmc_fetch', 'p_counter_collection.csv'))
 write, wd = load_pmc(os.path.join(out, 'pmc_write', 'p_counter_collection.csv'))
 sq, sd = load_pmc(os.path.join(out, 'pmc_sq', 'p_counter_collection.csv'))
 lds, ld = load_pmc(os.path.join(out, 'pmc_lds', 'p_counter_collection.csv'))
-dsq, dsd = load_pmc(os.path.join(out, 'pmc_sq_dstep', 'p_counter_collection.csv'))     # bench.py --d-step-only: the D step + gradient penalty window
+dsq, dsd = load_pmc(os.path.join(out, 'pmc_sq_dstep', 'p_counter_collection.csv'), window=True)     # bench.py --d-step-only: the D step + gradient penalty window
 kernels = sorted(set(fetch) | set(write) | set(sq), key=lambda k: -sum(sd.get(k, fd.get(k, {})).values()))
 rows = []
 roof = {}
@@ -88,6 +100,7 @@ for k, v in roof.items():
     fam[base]['bytes'] += v['hbm_bytes_per_launch'] * n
     fam[base]['calls'] += n
 # ---- the north-star window by counter: D step + gradient penalty + Adam(D) only (bench.py --d-step-only under --pmc)
+DSTEP_PASSES = int(os.environ.get('PG_DSTEP_PASSES', '3'))      # profile_round.sh: --warmup 3 --steps 3 for the --d-step-only pass
 dwin = None
 if dsq:
     tot = sum(sum(v.values()) for v in dsd.values())
@@ -97,8 +110,8 @@ if dsq:
         return 100.0 * sum(dsq[k].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for k in keys) / (t * 2.4 * 1024) if t else 0.0
     dwin = {'mfma_busy_pct_all_kernels': busy(list(dsd)), 'mfma_busy_pct_conv_kernels': busy(conv),
             'conv_kernel_time_share': sum(sum(dsd[k].values()) for k in conv) / tot if tot else 0.0,
-            'kernel_time_ms_per_pass': tot / 1e6 / 3.0, 'passes': 3,
-            'is': 'SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs), summed over the kernels of 3 serialised D-step + gradient-penalty passes'}
+            'kernel_time_ms_per_pass': tot / 1e6 / DSTEP_PASSES, 'passes': DSTEP_PASSES,
+            'is': 'SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs), summed over the kernels launched between the two window markers of bench.py --d-step-only (its timed passes, serialised by the counter collection)'}
     print('D step + GP window:', dwin)
 json.dump({'tag': tag, 'd_step_gp_window': dwin, 'per_kernel': roof,
            'per_family': {b: {'hbm_bytes_per_launch': d['bytes'] / max(1, d['calls']), 'launches': d['calls']} for b, d in fam.items()}},
