@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 # (measured with a one-rank communicator: 184 vs 218 img/s; the control-plane backend makes no difference).  Single-GPU runs
 # keep the default: 8 queues slow the hipGraph replay of the 4x4 stage down (3.8 vs 2.3 ms per step).  Must be set before the
 # HIP runtime is loaded.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')    # kernel arguments in device memory (the runtime's default on this image; =0 costs 0.33 ms per 1024^2 step: 318 launches)
 if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('PGGAN_FORCE_DP', '') == '1':
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 

@@ -18,6 +18,7 @@ which is evaluated as (i) a tangent pass pushing u through the same masked linea
 minibatch-stddev Hessian-vector term injected into the ordinary batched backward of the mixed
 samples (SURVEY.md §7 "hard parts"; formulas verified against autograd in tests/).
 """
+import os
 import torch
 
 from . import ops
@@ -773,18 +774,19 @@ def early_real_on_side(D, real):
     return st
 
 
-def _merge_ctx(D, first, rest, x3, N):
-    """The context of the whole batch from the contexts of the two passes: every tensor of a pass is a row range of a batched tensor."""
-    def whole(a, b):
+def _merge_ctx(D, first, rest, x3, N, third=None):
+    """The context of the whole batch from the contexts of the two (three) passes: every tensor of a pass is a row range of a batched tensor."""
+    def whole(a, *bs):
         base = a._base if a._base is not None else a
-        if b._base is not None and b._base is base and base.shape[0] == a.shape[0] + b.shape[0]:
+        if all(b._base is not None and b._base is base for b in bs) and base.shape[0] == a.shape[0] + sum(b.shape[0] for b in bs):
             return base
-        raise RuntimeError('split D forward: the two passes did not write into one tensor')
+        raise RuntimeError('split D forward: the passes did not write into one tensor')
     ctx = dict(NB=3 * N, groups=3, depth=first['depth'], alpha=first['alpha'], x=x3, recs=[])
-    for ra, rb in zip(first['recs'], rest['recs']):
+    others = [rest['recs']] + ([third['recs']] if third is not None else [])
+    for i, ra in enumerate(first['recs']):
         rec = {}
         for k, v in ra.items():
-            rec[k] = whole(v, rb[k]) if torch.is_tensor(v) else v
+            rec[k] = whole(v, *[o[i][k] for o in others]) if torch.is_tensor(v) else v
         ctx['recs'].append(rec)
     return ctx
 
@@ -1186,6 +1188,13 @@ def _assign_grads(net, layers, linear=False):
         net.linear.bias.grad = net._lin_gb
 
 
+# With the real third already through D (EarlyReal), the fake third of the D step's forward runs on the second stream next to the mixed
+# third's forward and the first backward of the gradient penalty (3-image launches that leave the chip partly idle); its scores are
+# needed by d_loss only.  Same-box pairs, ms per step off | on: 1024^2 10.52 | 10.47, 512^2 13.82 | 13.74, 256^2 23.42 | 23.39, 128^2 equal,
+# 32^2 10.11 | 10.06.  PGGAN_FAKE_SIDE=0: one [fake | mixed] pass on the main stream.
+FAKE_THIRD_ON_SIDE = os.environ.get('PGGAN_FAKE_SIDE', '1') == '1'
+
+
 def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_target):
     """Forward half of wgan_gp_D_loss (wgan_gp_loss.py:36-65): three D passes batched as
     [real | fake | mixed], G without graph, and the first backward of the gradient penalty."""
@@ -1196,14 +1205,28 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     N = real.shape[0]
     D._sync_version()
     early = take_early_real(D, real)
+    fake_done = None
     if early is not None:
         # the real third is already through D (Trainer, under the previous G step): the other two thirds follow into the same tensors
         x3 = early.x3
         generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52  (no graph kept)
         ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
-        with early.arena.pass_(1):
-            s_rest, ctx_rest = d_forward(D, x3[N:], groups=2)                 # :54,20
-        ctx = _merge_ctx(D, early.ctx, ctx_rest, x3, N)
+        if FAKE_THIRD_ON_SIDE:
+            main = torch.cuda.current_stream(torch._C._cuda_getDevice())
+            side = _side_stream()
+            _wait_stream(side, main)
+            with torch.cuda.stream(side):
+                with early.arena.pass_(2):
+                    s_f, ctx_f = d_forward(D, x3[N:2 * N], groups=1)          # :54
+                fake_done = torch.cuda.Event()
+                _record_event(fake_done, side)
+            with early.arena.pass_(3):
+                s_m, ctx_m = d_forward(D, x3[2 * N:], groups=1)               # :20
+            ctx = _merge_ctx(D, early.ctx, ctx_f, x3, N, third=ctx_m)
+        else:
+            with early.arena.pass_(1):
+                s_rest, ctx_rest = d_forward(D, x3[N:], groups=2)             # :54,20
+            ctx = _merge_ctx(D, early.ctx, ctx_rest, x3, N)
         s = early.scores._base if early.scores._base is not None else early.scores
     else:
         x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
@@ -1215,6 +1238,8 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     gimg, adj = d_backward(D, sub, _ones(N, real.device), full=False, want_gimg=True, save_adjoints=True)  # :25-28
     ss = ops.row_sumsq(gimg)
     gp, u = ops.gp_seed(gimg, ss, iwass_lambda, iwass_target, 1.0 / N)        # :29-31
+    if fake_done is not None:
+        _wait_event(torch.cuda.current_stream(torch._C._cuda_getDevice()), fake_done)
     d_cost, d_real_loss, d_fake_loss, gscore = ops.d_loss(s, gp, N, iwass_epsilon)   # :48,55,62
     state = dict(D=D, ctx=ctx, sub=sub, adj=adj, u=u, gscore=gscore, N=N, scores=s, gp=gp)
     return d_cost, d_real_loss, d_fake_loss, state

@@ -128,14 +128,15 @@ class Arena(object):
             big = self.bufs[self.i]
             unit = lead
         else:
-            if self.i >= len(self.bufs) or lead % 2:
+            if self.i >= len(self.bufs) or (self.part == 1 and lead % 2):
                 raise RuntimeError('split D forward: the second pass asks for an output the first pass did not create')
             big = self.bufs[self.i]
-            unit = lead // 2
+            unit = lead // 2 if self.part == 1 else lead
         if tuple(big.shape) != (3 * unit,) + rest or big.dtype != dtype:
             raise RuntimeError('split D forward: output %d differs between the passes (%s %s vs %s x3)' % (self.i, tuple(big.shape), big.dtype, shape))
         self.i += 1
-        return big[:unit] if self.part == 0 else big[unit:]
+        # part 0: first third | 1: second and third thirds in one pass | 2 / 3: the second / the third third alone
+        return big[:unit] if self.part == 0 else big[unit:] if self.part == 1 else big[unit:2 * unit] if self.part == 2 else big[2 * unit:]
 
     def pass_(self, part):
         return _ArenaPass(self, part)
@@ -635,9 +636,8 @@ def gp_seed(g, ss, lam, target, inv_n):
 
 def d_loss(scores, gp, N, eps):
     dev = scores.device
-    d_cost = torch.empty((), device=dev, dtype=torch.float32)
-    d_real_loss = torch.empty((N, 1), device=dev, dtype=torch.float32)
-    d_fake_loss = torch.empty((N, 1), device=dev, dtype=torch.float32)
+    out = torch.empty((1 + 2 * N,), device=dev, dtype=torch.float32)     # one buffer: a replayed step hands out ONE copy of it (plans.d_step)
+    d_cost, d_real_loss, d_fake_loss = out[0], out[1:1 + N].view(N, 1), out[1 + N:].view(N, 1)
     gscore = torch.empty((3 * N,), device=dev, dtype=torch.float32)
     _lib.call('pg_d_loss', _p(scores), _p(gp), _p(d_cost), _p(d_real_loss), _p(d_fake_loss), _p(gscore), N, eps, _stream())
     return d_cost, d_real_loss, d_fake_loss, gscore

@@ -217,7 +217,12 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
     else:
         _replay(g)
     engine._assign_grads(D, engine.d_active_params(D, int(D.depth), 1.0), linear=True)
-    # the static outputs are overwritten by the next replay: hand out copies (a plugin may keep loss tensors)
+    # the static outputs are overwritten by the next replay: hand out copies (a plugin may keep loss tensors) -- one device copy when
+    # they are views of one buffer (ops.d_loss)
+    base = g.static_out[0]._base
+    if base is not None and all(t._base is base for t in g.static_out):
+        c = base.clone()
+        return tuple(c.as_strided(t.shape, t.stride(), t.storage_offset()) for t in g.static_out)
     return tuple(t.clone() for t in g.static_out)
 
 

@@ -454,16 +454,18 @@ def test_time_monitor_d_step_probe():
     assert tr.stats['sec']['tick'] > 0 and not tr.d_step_probe['pairs']          # consumed at the tick boundary
 
 
-@pytest.mark.parametrize('plans_on', [False, True])
-def test_early_real_third_matches_whole_batch_forward(plans_on, tmp_path):
+@pytest.mark.parametrize('plans_on,fake_side', [(False, True), (True, True), (True, False)])
+def test_early_real_third_matches_whole_batch_forward(plans_on, fake_side, tmp_path):
     """The real third of the next D step's batched D forward runs on the second stream under the G step (engine.EarlyReal: both passes
     write ONE set of batched activations through ops.Arena, Trainer draws the next real batch one iteration ahead, DepthManager's schedule
     says whether the next iteration still is this stage).  Two trainers with the same seeds, one with the early pass and one without, stepped
     side by side through a stabilisation span, a fade (no early pass there) and a stage change: per-iteration pre-Adam gradients agree,
     weights are re-synchronised after every iteration, the same real batches are consumed in the same order, the early pass is really
-    used (and dropped / not started where it must be), and a whole-module pickle taken while a pass is pending works."""
+    used (and dropped / not started where it must be), and a whole-module pickle taken while a pass is pending works.
+    ``fake_side``: the fake third of the D step's forward on the second stream as well (three passes into one set of tensors)."""
     wl = pg.wgan_gp_loss
     eng = pg.engine
+    fake_side_before, eng.FAKE_THIRD_ON_SIDE = eng.FAKE_THIRD_ON_SIDE, fake_side
 
     def build(early):
         torch.manual_seed(17)
@@ -525,6 +527,7 @@ def test_early_real_third_matches_whole_batch_forward(plans_on, tmp_path):
         assert st['passes'] >= 5 and st['used'] >= st['passes'] - 2 and st['dropped'] <= 2, st       # 5 per stabilisation span (depth 0 replays a hipGraph in 'auto': none there)
     finally:
         wl.enable_graphs(False)
+        eng.FAKE_THIRD_ON_SIDE = fake_side_before
 
 
 def test_whole_module_pickle_roundtrip(tmp_path):
