@@ -29,9 +29,6 @@ namespace {
 using namespace pgw;
 
 template <int VEC> struct WRow { static constexpr int value = VEC == 4 ? 24 : 12; };   // LDS row stride (floats), conflict-free b128 / b64
-#ifndef PG_WINO_PRIO
-#define PG_WINO_PRIO 3                         // s_setprio of the MFMA phase of conv_wino2_kernel (0: off; A/B builds)
-#endif
 constexpr int XMAX = 400;                      // halo pixels per workgroup: 18x18 (8x8 tiles) .. 4 x 10x10 (8x8 images)
 
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin)
@@ -398,9 +395,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
             d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
         }
         PG_STAMP(4);
-        // a wave in its MFMA phase issues ahead of the co-resident waves that wait for / read their patches (round 5: -1.7 % over the layer
-        // set alone, -0.045 ms per 1024^2 step, three same-box pairs; raising it before the input transform instead: +0.08 ms)
-        __builtin_amdgcn_s_setprio(PG_WINO_PRIO);
+        // Scheduling barrier between the input transform and the MFMAs: without it hipcc threads the transform's additions through the
+        // MFMA stream (46 VALU, a mix of v_pk_add_f32 and scalar adds, one or two per MFMA gap); with it the transform is 32 v_pk_add_f32
+        // up front and the 32 MFMAs follow back to back with only the U fragment reads between them: -1.1 ... -1.7 % over the layer set
+        // alone, -0.045 ms per 1024^2 step (round 5, three same-box pairs).  Found through s_setprio, which acts as such a barrier; the
+        // priority itself changes nothing (s_setprio 0 in its place measures the same), nor does loading the first row's U fragments
+        // before the transform (8 more VGPRs: past the 128 of four waves per SIMD, +3 % with the spills).
+        __builtin_amdgcn_sched_barrier(0);
         const lds_cptr ub = (lds_cptr)lds + ubyte + ((k0 >> 3) & 1) * UBYTES;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                         // one row of Winograd positions at a time: 4 x NCB accumulators interleaved
@@ -421,11 +422,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(WinoP p)      // 2 w
                         }
         }
         PG_STAMP(5);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
         PG_STAMP(6);
         };
     chunk(kbeg, std::true_type{});
     for (int k0 = kbeg + KC; k0 < kend; k0 += KC) chunk(k0, std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);                          // (the epilogue's address arithmetic stays out of the last chunk's MFMA stream)
     if constexpr (KSP) {
         // partial sums of this K slice: 2x2 outputs (the output transform is linear) -> slice (blk, ks) of the scratch, one float4
         // per lane and output pixel; the workgroup that arrives last adds the slices in split order (so the result does not depend

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_strip_kernel(WinoP p, WinoSt
                     d[a][0] = t0; d[a][1] = t1; d[a][2] = t2; d[a][3] = t3;
                 }
                 if (ch == 0) WS_STAMP(it, 5);
+                __builtin_amdgcn_sched_barrier(0);              // the transform's additions stay out of the MFMA stream (see conv_wino2_kernel)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {              // one row of Winograd positions at a time: 4 x NCB accumulators interleaved
                     v2 af[NCB][4];
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_strip_kernel(WinoP p, WinoSt
                                 acc[c][4 * gq + j] = MFMA16(af[c][j][s2_], d[gq][j][s2_], (ch == 0 && s2_ == 0) ? zero4 : acc[c][4 * gq + j]);
                             }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             WS_STAMP(it, 6);
             const int oy0 = r0 + 4 * it + 2 * tty;

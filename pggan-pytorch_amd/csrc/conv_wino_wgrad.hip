@@ -21,6 +21,13 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+#ifndef PG_WW_SCHED
+#define PG_WW_SCHED 2            // 3: both cout halves' transforms first, then one stream of 32 MFMAs (A/B builds)
+#endif
+#ifndef PG_WW_SCHED_NP
+#define PG_WW_SCHED_NP 1            // the same barriers in the 16 x 16 / 16 x 32 / 32 x 16 forms: +6 ... 9 % alone (140 -> 149 TF at n12 @512 16->32), neutral in the step
+#endif
+
 namespace {
 
 struct WWP {
@@ -185,8 +192,14 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
             wino_zprime(gq + ((2 * tty) * PW + 2 * tx0) * SZ, SZ, PW * SZ, z);
             if (bias_here) bsum += z[5];
             wino_vprime(xq + ((2 * tty) * HW_ + 2 * tx0) * SX, SX, HW_ * SX, d);
+#if PG_WW_SCHED_NP
+            __builtin_amdgcn_sched_barrier(0);                // (as in the pair kernel below)
+#endif
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) acc[xi] = MFMA16(z[xi], d[xi >> 2][xi & 3], acc[xi]);
+#if PG_WW_SCHED_NP
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         PG_RSTAMP(4);
         __syncthreads();
@@ -353,14 +366,34 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
         for (int s_ = 0; s_ < 4; ++s_) {
             float d[4][4];
             wino_vprime(xq + (2 * s_) * HW_ * SX, SX, HW_ * SX, d);          // B operand, shared by both cout halves
+#if PG_WW_SCHED == 3
+            float z2[2][16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                wino_zprime(gq + (2 * s_) * PW * SZ + h * 16, SZ, PW * SZ, z2[h]);
+                if (bias_here) bsum[h] += z2[h][5];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[h][xi] = MFMA16(z2[h][xi], d[xi >> 2][xi & 3], acc[h][xi]);
+            __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float z[16];
                 wino_zprime(gq + (2 * s_) * PW * SZ + h * 16, SZ, PW * SZ, z);
                 if (bias_here) bsum[h] += z[5];
+                // Scheduling barriers around the MFMAs of a k-step: without them hipcc threads the transforms' additions through the MFMA
+                // stream and pays an s_nop for every VALU result an MFMA reads at once (24 in the loop, 1 with the barriers): -5.3 % over
+                // the layer set alone (151 -> 164 TF algorithmic at n12 @32 256->512), -0.07 ms per 1024^2 step (round 5)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int xi = 0; xi < 16; ++xi) acc[h][xi] = MFMA16(z[xi], d[xi >> 2][xi & 3], acc[h][xi]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#endif
         }
         __syncthreads();
     }

@@ -13,7 +13,7 @@ ops, lib = pg.ops, pg._lib.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 SETS = int(os.environ.get('SETS', '4'))
 CASES = [(12, 16, 512, 512), (12, 32, 256, 512), (12, 64, 128, 256), (12, 128, 64, 128), (12, 256, 32, 64), (12, 128, 64, 64), (12, 64, 128, 128),
-         (12, 256, 32, 32), (3, 64, 128, 256), (3, 32, 512, 256), (12, 512, 16, 32), (3, 16, 512, 512)]
+         (12, 256, 32, 32), (3, 64, 128, 256), (3, 32, 512, 256), (12, 512, 16, 32), (3, 16, 512, 512), (12, 512, 16, 16), (3, 512, 32, 16), (3, 512, 16, 16), (3, 32, 256, 256), (12, 16, 512, 512)]
 for N, H, ci, co in CASES:
     xs = [torch.randn(N, H, H, ci, device='cuda') for _ in range(SETS)]
     gs = [torch.randn(N, H, H, co, device='cuda') for _ in range(SETS)]
