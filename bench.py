@@ -18,9 +18,13 @@ devices are visible.  Rank 0 prints ONE JSON line (the last line of stdout), at 
 ``cpu_baseline``, the D+GP window and one row per growth stage.  Every table behind it (per-kernel timings, secondary workloads, CPU
 per-depth numbers, timing windows) is written to ``bench_detail.json`` next to this file (a short digest goes to stderr).
 
-Fractions: ``roofline.frac`` / ``executed_mfma_frac`` / per-depth ``executed_frac`` = MFMA FLOP the HIP-event-timed conv launches
-EXECUTE (Winograd F(2x2,3x3) launches credited 16/36 of the 2*MAC count) / their time / the nominal 157.3 TF fp32-MFMA peak: <= 1 by
-construction.  The algorithmic 2*MAC work of the reference's convolutions is reported as a RATE (``algorithmic_tflops``; it can exceed
+Fractions (all <= 1 by construction; Winograd F(2x2,3x3) launches are credited 16/36 of the 2*MAC count, peak = the nominal 157.3 TF of
+fp32 MFMA): ``roofline.frac`` = MFMA FLOP the launches of the dominant conv symbol EXECUTE / their HIP-event time (per-launch event
+pairs on the launch's stream, inside the step as it is issued in the timed loop: ``_lib.CALL_HOOK`` also runs on launch-plan replay);
+``executed_mfma_frac`` / per-depth ``executed_frac`` / ``d_step_gp.executed_frac`` = MFMA FLOP all conv launches of a step (window)
+execute / the step's (window's) wall time -- the chip's utilisation over the step, indifferent to how launches overlap on the streams
+(``conv_kernel_executed_*`` in bench_detail.json: the same FLOP / the launches' summed time, which counts concurrent launches twice).
+The algorithmic 2*MAC work of the reference's convolutions is reported as a RATE (``algorithmic_tflops``; it can exceed
 what the matrix cores execute, so it is never called a fraction outside ``roofline.algorithmic_frac`` of the dominant kernel);
 ``mfma_busy_pct`` = time-weighted SQ_VALU_MFMA_BUSY_CYCLES of the conv kernels from the committed PMC pass
 (``mfma_busy_source``).  Setup before the W warmup steps: --prime (default 50) untimed steps (code objects, allocator
@@ -111,109 +115,98 @@ def conv_flops(n, hout, wout, ks, pad, c_a, c_b):
     return 2.0 * n * hout * wout * c_a * c_b * taps
 
 
+# C-ABI entry points that launch an MFMA conv kernel: positions of (N, H, W, Cin, Cout, KS, pad) in their argument lists
+# (include/pggan_hip.h; KS / pad None = 3 / 1), and which thread-local "last kernel" query names the symbol that ran
+CONV_ENTRY = {
+    'pg_conv2d_nhwc': (5, 6, 7, 8, 9, 10, 11, 'conv', ''),
+    'pg_conv2d_wgrad_nhwc': (4, 5, 6, 7, 8, 9, 10, 'conv', 'wgrad'),
+    'pg_conv2d_pool_nhwc': (10, 11, 12, 13, 14, 15, 16, 'conv', '+pool'),
+    'pg_conv2d_pixelnorm_nhwc': (5, 6, 7, 8, 9, 10, 11, 'conv', '+pixelnorm'),
+    'pg_conv2d_pnbwd_nhwc': (5, 6, 7, 8, 9, 10, 11, 'conv', '+pn adjoint'),
+    'pg_conv2d_unpool_nhwc': (5, 6, 7, 8, 9, 10, 11, 'conv', '+unpool'),
+    'pg_conv2d_unpooled_nhwc': (7, 8, 9, 10, 11, None, None, 'conv', 'pool adjoint in the gather'),
+    'pg_conv2d_wgrad_unpooled_nhwc': (7, 8, 9, 10, 11, None, None, 'conv', 'wgrad, pool adjoint in the gather'),
+    'pg_conv2d_wino_nhwc': (13, 14, 15, 16, 17, None, None, 'wino', 'winograd'),
+    'pg_conv2d_wino_pixelnorm_nhwc': (5, 6, 7, 8, 9, None, None, 'wino', 'winograd +pixelnorm'),
+    'pg_conv2d_wino_pnbwd_nhwc': (9, 10, 11, 12, 13, None, None, 'wino', 'winograd +pn adjoint'),
+    'pg_conv2d_wgrad_wino_nhwc': (4, 5, 6, 7, 8, None, None, 'wwino', 'wgrad winograd'),
+    'pg_conv2d_wgrad_wino2_nhwc': (None, 9, 10, 11, 12, None, None, 'wwino', 'wgrad winograd'),      # N = args[2] + args[5]
+}
+
+
 class KernelTimer(object):
-    """HIP-event timing of every MFMA conv launch of a step, recorded around the C-ABI call on the stream the
-    kernel is launched on (weight gradients run on the second stream, so wrapping happens at ``ops`` level, inside
-    the stream context).  The durations are the ones inside the two-stream step — what rocprofv3 --kernel-trace
-    reports for the same command; ``--serial-kernel-timing`` switches the second stream off for isolated numbers."""
+    """HIP-event timing of every MFMA conv launch of a step, recorded around the C-ABI call on the stream the kernel is launched on
+    (``_lib.CALL_HOOK``: eager calls and calls replayed from a launch plan alike, so the timed steps are issued exactly as the
+    measured ones -- the host stays ahead of the device and the event pair brackets the kernel, not a wait for the host; an eager
+    instrumented pass is host-bound on the 3-image launches and read 74 us where rocprofv3 has 58).  The durations are the ones
+    inside the multi-stream step -- what rocprofv3 --kernel-trace reports for the same command."""
 
     def __init__(self, pg):
-        self.pg, self.rec, self.saved = pg, [], {}
+        self.pg, self.rec, self.streams = pg, [], {}
 
-    def _wrap(self, name, describe):
-        ops = self.pg.ops
-        orig = getattr(ops, name)
-        self.saved[name] = orig
-        lib = self.pg._lib.load()
+    def _stream(self, handle):
+        h = int(handle or 0)
+        s = self.streams.get(h)
+        if s is None:
+            s = self.streams[h] = torch.cuda.default_stream() if h == 0 else torch.cuda.ExternalStream(h)
+        return s
 
-        def wrapped(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(*a, **k)
-            e1.record()
-            sym = (lib.pg_debug_last_wino_kernel() if name in ('conv2d_wino', 'conv2d_wino_pixelnorm', 'conv2d_wino_pnbwd') else
-                   lib.pg_debug_last_wino_wgrad_kernel() if name == 'conv2d_wgrad_wino' else
-                   lib.pg_debug_last_conv_kernel()).decode()
-            fl, tag = describe(a, k)
-            self.rec.append((sym, fl, e0, e1, '%s %s' % (tag, sym.replace('conv_', '').replace('_kernel', ''))))
-            return out
-        setattr(ops, name, wrapped)
+    def hook(self, fn, args, name):
+        spec = CONV_ENTRY.get(name)
+        if spec is None:
+            return fn(*args)
+        s = self._stream(args[-1])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        rc = fn(*args)
+        e1.record(s)
+        if rc:
+            return rc
+        lib = self.lib
+        sym = (lib.pg_debug_last_wino_kernel() if spec[7] == 'wino' else lib.pg_debug_last_wino_wgrad_kernel() if spec[7] == 'wwino'
+               else lib.pg_debug_last_conv_kernel()).decode()
+        n = args[2] + args[5] if spec[0] is None else args[spec[0]]
+        h, w, cin, cout = args[spec[1]], args[spec[2]], args[spec[3]], args[spec[4]]
+        ks = 3 if spec[5] is None else args[spec[5]]
+        pad = 1 if spec[6] is None else args[spec[6]]
+        ho, wo = h + 2 * pad - ks + 1, w + 2 * pad - ks + 1
+        fl = conv_flops(n, ho, wo, ks, pad, cout, cin)
+        self.rec.append((sym, fl, e0, e1, '%s %d->%d k%d @%d n%d %s' % (spec[8], cin, cout, ks, ho, n, sym.replace('conv_', '').replace('_kernel', ''))))
+        return 0
 
     def __enter__(self):
-        def conv_desc(a, k):          # conv2d(x, w, bias, N, Hin, Win, ks, pad, scale, ...)
-            w, n, hin, win, ks, pad = a[1], a[3], a[4], a[5], a[6], a[7]
-            ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
-            return (conv_flops(n, ho, wo, ks, pad, w.shape[2], w.shape[3]),
-                    'conv %d->%d k%d @%d n%d%s' % (w.shape[3], w.shape[2], ks, ho, n, ' masked' if k.get('mask') is not None else ''))
-
-        def wgrad_desc(a, k):         # conv2d_wgrad(x, gz, dw, db, N, Hin, Win, ks, pad, scale, ups=)
-            dw, n, hin, win, ks, pad = a[2], a[4], a[5], a[6], a[7], a[8]
-            ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
-            return (conv_flops(n, ho, wo, ks, pad, dw.shape[2], dw.shape[3]),
-                    'wgrad %d->%d k%d @%d n%d' % (dw.shape[3], dw.shape[2], ks, ho, n))
-        def wino_wgrad_desc(a, k):    # conv2d_wgrad_wino(x, gz, dw, db, N, H, W, scale, ups=, second=(x2, gz2, N2, bias2))
-            dw, n, h = a[2], a[4], a[5]
-            if k.get('second') is not None:      # a second batch of the same layer rides in the launch: its FLOPs count too
-                n += k['second'][2]
-            return (conv_flops(n, h, h, 3, 1, dw.shape[2], dw.shape[3]),
-                    'wgrad %d->%d k3 @%d n%d winograd' % (dw.shape[3], dw.shape[2], h, n))
-        def pool_desc(a, k):          # conv2d_pool(x, w, bias, N, Hin, Win, ks, pad, scale, ...): the conv of conv_desc + pooled output
-            fl, tag = conv_desc(a, k)
-            return fl, tag + ' +pool'
-        def generic(w_i, n_i, suffix):  # ops whose signature is (x, w, ..., N, Hin, Win, ks, pad, ...) with N at position n_i
-            def desc(a, k):
-                w, n, hin, win, ks, pad = a[w_i], a[n_i], a[n_i + 1], a[n_i + 2], a[n_i + 3], a[n_i + 4]
-                ho, wo = hin + 2 * pad - ks + 1, win + 2 * pad - ks + 1
-                return (conv_flops(n, ho, wo, ks, pad, w.shape[2], w.shape[3]),
-                        'conv %d->%d k%d @%d n%d %s' % (w.shape[3], w.shape[2], ks, ho, n, suffix))
-            return desc
-        def wino_desc(a, k):          # conv2d_wino(x, u, bias, N, H, W, scale, ...): 3x3 pad 1 on Winograd-domain weights
-            u, n, h = a[1], a[3], a[4]
-            return (conv_flops(n, h, h, 3, 1, u.shape[1], u.shape[2]),
-                    'conv %d->%d k3 @%d n%d winograd%s' % (u.shape[2], u.shape[1], h, n, ' masked' if k.get('mask') is not None else ''))
-        def wino_pn_desc(a, k):       # conv2d_wino_pixelnorm(x, u, bias, N, H, W, scale, slope, eps, ups=)
-            fl, tag = wino_desc(a, {})
-            return fl, tag + ' +pixelnorm'
-        def wino_pnbwd_desc(a, k):    # conv2d_wino_pnbwd(x, u, ysaved, r, N, H, W, scale, slope, pool=, ...)
-            u, n, h = a[1], a[4], a[5]
-            return (conv_flops(n, h, h, 3, 1, u.shape[1], u.shape[2]),
-                    'conv %d->%d k3 @%d n%d winograd +pn adjoint%s' % (u.shape[2], u.shape[1], h, n, ' +pool' if k.get('pool') else ''))
-        self._wrap('conv2d', conv_desc)
-        self._wrap('conv2d_wino', wino_desc)
-        self._wrap('conv2d_wino_pixelnorm', wino_pn_desc)
-        self._wrap('conv2d_wino_pnbwd', wino_pnbwd_desc)
-        self._wrap('conv2d_pool', pool_desc)
-        self._wrap('conv2d_pixelnorm', generic(1, 3, '+pixelnorm'))
-        self._wrap('conv2d_unpool', generic(1, 2, '+unpool'))
-        self._wrap('conv2d_pnbwd', generic(1, 4, '+pn adjoint'))
-        self._wrap('conv2d_wgrad', wgrad_desc)
-        self._wrap('conv2d_wgrad_wino', wino_wgrad_desc)
-
-        def unpooled_desc(a, k):      # conv2d_unpooled(g, w, gbytes, gmul, gslope, N, Hin, Win, scale, ...)
-            w, n, h = a[1], a[5], a[6]
-            return (conv_flops(n, h, h, 3, 1, w.shape[2], w.shape[3]), 'conv %d->%d k3 @%d n%d pool adjoint in the gather' % (w.shape[3], w.shape[2], h, n))
-
-        def wgrad_unpooled_desc(a, k):   # conv2d_wgrad_unpooled(x, g, gbytes, gmul, gslope, dw, db, N, Hin, Win, scale)
-            dw, n, h = a[5], a[7], a[8]
-            return (conv_flops(n, h, h, 3, 1, dw.shape[2], dw.shape[3]), 'wgrad %d->%d k3 @%d n%d pool adjoint in the gather' % (dw.shape[3], dw.shape[2], h, n))
-        self._wrap('conv2d_unpooled', unpooled_desc)
-        self._wrap('conv2d_wgrad_unpooled', wgrad_unpooled_desc)
+        self.lib = self.pg._lib.load()
+        # What an event pair adds to the kernel between its records (the two packets' processing + the dispatch of the kernel behind
+        # the first): calibrated as the pair around a 16 K-element add (whose own ~2 us are left in: the correction never exceeds
+        # the overhead) and subtracted from every launch, so that the figure is the kernel's duration as rocprofv3 --kernel-trace
+        # reports it rather than kernel + event packets
+        torch.cuda.synchronize()
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        buf = torch.zeros(1 << 14, device='cuda')
+        for a, b in pairs:
+            buf.add_(1.0)                                   # (a kernel ahead of the pair, as in the step: the pair never starts on an idle queue)
+            a.record()
+            buf.add_(1.0)
+            b.record()
+        torch.cuda.synchronize()
+        self.pair_ms = max(0.0, sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2] - 0.002)
+        self.saved = self.pg._lib.CALL_HOOK
+        self.pg._lib.CALL_HOOK = self.hook
         return self
 
     def __exit__(self, *exc):
-        for name, orig in self.saved.items():
-            setattr(self.pg.ops, name, orig)
+        self.pg._lib.CALL_HOOK = self.saved
 
     def summary(self, nsteps):
         torch.cuda.synchronize()
         fam = {}
         self.table = {}
         per_tag = {}
-        for family, fl, e0, e1, tag in self.rec:
-            per_tag.setdefault(tag, []).append(e0.elapsed_time(e1))
+        raw = [max(e0.elapsed_time(e1) - self.pair_ms, 0.5 * e0.elapsed_time(e1)) for _, _, e0, e1, _ in self.rec]
+        for (family, fl, e0, e1, tag), ms in zip(self.rec, raw):
+            per_tag.setdefault(tag, []).append(ms)
         med = {tag: sorted(v)[len(v) // 2] for tag, v in per_tag.items()}
-        for family, fl, e0, e1, tag in self.rec:
-            ms = e0.elapsed_time(e1)
+        for (family, fl, e0, e1, tag), ms in zip(self.rec, raw):
             if ms > 10.0 * med[tag]:                       # a one-off stall (allocator / first touch) is not the kernel
                 ms = med[tag]
             t = self.table.setdefault(tag, dict(flops=0.0, ms=0.0, launches=0))
@@ -409,7 +402,8 @@ def executed_fraction(pg, tr, steps=2):
     construction, for every growth stage (the algorithmic rate of a Winograd stage can exceed the peak; it is reported as a rate,
     never as a fraction)."""
     mode = pg.wgan_gp_loss._use_graphs
-    pg.wgan_gp_loss._use_graphs = False                # per-launch events need eager launches (the switch itself: recorded plans stay)
+    if pg.wgan_gp_loss._replay_mode(tr.G) == 'graph':  # a hipGraph replay has no per-launch hook: eager launches there (the switch itself: recorded plans stay)
+        pg.wgan_gp_loss._use_graphs = False
     try:
         with KernelTimer(pg) as kt:
             for _ in range(steps):
@@ -419,8 +413,8 @@ def executed_fraction(pg, tr, steps=2):
         pg.wgan_gp_loss._use_graphs = mode
     tot = sum(v['ms'] for v in fam.values())
     if not tot:
-        return None, None
-    return (sum(v['exec_flops'] for v in fam.values()) / (tot * 1e-3) / MFMA_F32_PEAK, tot / steps)
+        return None, None, None
+    return (sum(v['exec_flops'] for v in fam.values()) / (tot * 1e-3) / MFMA_F32_PEAK, tot / steps, sum(v['exec_flops'] for v in fam.values()) / steps)
 
 
 def stage_entry(pg, tr, dp, n_gpus, mb, depth, alpha, extra=None, executed=True):
@@ -435,7 +429,12 @@ def stage_entry(pg, tr, dp, n_gpus, mb, depth, alpha, extra=None, executed=True)
          'algorithmic_tflops_per_gpu': w * (mb / (ms * 1e-3)) / 1e12,
          'd_step_gp_algorithmic_tflops_per_gpu': w_d * (mb / (dms * 1e-3)) / 1e12}
     if executed:               # every rank runs the instrumented steps (collectives stay matched); the line quotes rank 0's
-        e['executed_frac'], e['conv_kernel_ms_per_step'] = executed_fraction(pg, tr)
+        kf, kms, xfl = executed_fraction(pg, tr)
+        # executed_frac: MFMA FLOP the conv launches of a step execute (Winograd credited 16/36) / step time / peak -- a utilisation of
+        # the chip over the step, <= 1 by construction and indifferent to how the launches overlap on the streams; the kernel-time
+        # form (same FLOP / summed HIP-event time of the launches) next to it counts concurrent launches' time twice
+        e['executed_frac'] = xfl / (ms * 1e-3) / MFMA_F32_PEAK if xfl else None
+        e['conv_kernel_executed_frac'], e['conv_kernel_ms_per_step'] = kf, kms
     if extra:
         e.update(extra)
     return e
@@ -560,7 +559,7 @@ def compact_line(out, detail_path=None):
     if roof:
         line['roofline'] = _pick(roof, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'algorithmic_frac'))
         line['roofline']['traffic'] = _r(roof.get('traffic'))                        # (null = no PMC pass to quote)
-        line['roofline'].update(_pick(roof, ('traffic_source', 'mfma_busy_pct', 'valu_per_mfma', 'avg_launch_us', 'launches_per_step',
+        line['roofline'].update(_pick(roof, ('traffic_source', 'mfma_busy_pct', 'valu_per_mfma', 'avg_launch_us', 'event_pair_us_subtracted', 'launches_per_step',
                                              'ms_per_step_in_kernel')))
     cpu = out.get('cpu_baseline')
     line['cpu_baseline'] = _pick(cpu, ('value', 'unit', 'cores', 'kind', 'sample', 'measured_at_n_gpus')) if cpu else None
@@ -731,7 +730,9 @@ def main():
 
     if rank == 0 and not args.no_kernel_timing:
         psteps = 3
-        pg.wgan_gp_loss.enable_graphs(False)               # per-launch HIP events need eager launches
+        graph_mode = pg.wgan_gp_loss._replay_mode(tr.G) == 'graph'
+        if graph_mode or args.serial_kernel_timing:
+            pg.wgan_gp_loss.enable_graphs(False)           # a hipGraph replay has no per-launch hook (launch plans do: _lib.CALL_HOOK)
         async_wgrad = pg.engine.ASYNC_WGRAD
         if args.serial_kernel_timing:
             pg.engine.ASYNC_WGRAD = False
@@ -765,12 +766,14 @@ def main():
                            'traffic': traffic, 'traffic_source': src if traffic is not None else None,
                            'mfma_busy_pct': prof[dom]['mfma_busy_pct'] if prof and dom in prof else None,
                            'valu_per_mfma': prof[dom].get('valu_per_mfma') if prof and dom in prof else None,
-                           'avg_launch_us': d['avg_launch_us'], 'launches_per_step': d['launches_per_step'],
+                           'avg_launch_us': d['avg_launch_us'], 'launches_per_step': d['launches_per_step'], 'event_pair_us_subtracted': 1e3 * kt.pair_ms,
                            'ms_per_step_in_kernel': d['ms_per_step'],
                            'algorithmic_gflop_per_step': d['flops_per_step'] / 1e9}
         tot_ms = sum(v['ms'] for v in fam.values())
-        out['executed_mfma_frac'] = sum(v['exec_flops'] for v in fam.values()) / (tot_ms * 1e-3) / MFMA_F32_PEAK
-        out['executed_mfma_frac_is'] = 'MFMA FLOP issued by the HIP-event-timed conv launches (Winograd credited 16/36) / their summed time / peak'
+        xfl = sum(v['exec_flops'] for v in fam.values()) / psteps
+        out['executed_mfma_frac'] = xfl / (ms_per_step * 1e-3) / MFMA_F32_PEAK
+        out['executed_mfma_frac_is'] = 'MFMA FLOP the conv launches of a step execute (Winograd credited 16/36) / step time / peak'
+        out['conv_kernel_executed_mfma_frac'] = xfl * psteps / (tot_ms * 1e-3) / MFMA_F32_PEAK      # / summed HIP-event time of the launches (concurrent launches count twice)
         if prof:
             num = sum(v['ms'] * prof[k]['mfma_busy_pct'] for k, v in fam.items() if k in prof)
             den = sum(v['ms'] for k, v in fam.items() if k in prof)
@@ -779,7 +782,8 @@ def main():
         # the north-star window: D step + gradient penalty + Adam(D).  (a) this run's conv launches of that window (HIP events),
         # weighted with the per-symbol SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC pass; (b) the counter figure of a
         # --d-step-only PMC pass over ALL kernels of the window (tools/profile_round.sh, profiles/<tag>_roofline.json)
-        pg.wgan_gp_loss.enable_graphs(False)
+        if graph_mode or args.serial_kernel_timing:
+            pg.wgan_gp_loss.enable_graphs(False)
         try:
             with KernelTimer(pg) as ktd:
                 one = d_step_fn(tr)
@@ -789,7 +793,8 @@ def main():
         finally:
             pg.engine.ASYNC_WGRAD = async_wgrad
         totd = sum(v['ms'] for v in famd.values())
-        out['d_step_gp_executed_mfma_frac'] = sum(v['exec_flops'] for v in famd.values()) / (totd * 1e-3) / MFMA_F32_PEAK if totd else None
+        out['d_step_gp_executed_mfma_frac'] = (sum(v['exec_flops'] for v in famd.values()) / psteps / (d_gp_ms * 1e-3) / MFMA_F32_PEAK
+                                               if (totd and d_gp_ms) else None)                 # / the window's wall time
         if prof:
             num = sum(v['ms'] * prof[k]['mfma_busy_pct'] for k, v in famd.items() if k in prof)
             den = sum(v['ms'] for k, v in famd.items() if k in prof)

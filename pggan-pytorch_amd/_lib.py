@@ -151,7 +151,10 @@ def check(rc, name):
         raise (Unsupported if rc == -3 else RuntimeError)('%s failed: %s' % (name, what))
 
 
+CALL_HOOK = None        # measurement aid (bench.py): ``hook(fn, args, name) -> rc`` runs every C-ABI call, eager or replayed from a launch plan
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point and raise on a non-zero return."""
     fn = getattr(load(), name)
-    check(fn(*args), name)
+    check(fn(*args) if CALL_HOOK is None else CALL_HOOK(fn, args, name), name)

@@ -66,7 +66,7 @@ class _Recorder(object):
 
         def call(name, *args):
             fn = getattr(lib, name)
-            _lib.check(fn(*args), name)
+            _lib.check(fn(*args) if _lib.CALL_HOOK is None else _lib.CALL_HOOK(fn, args, name), name)
             rec.entries.append((CALL, fn, args, name))
 
         def p(t):
@@ -124,10 +124,11 @@ class _Recorder(object):
 
 def _replay(plan):
     check = _lib.check
+    hook = _lib.CALL_HOOK            # (bench.py's per-launch timing: None in production)
     for e in plan.entries:
         kind = e[0]
         if kind == CALL:
-            rc = e[1](*e[2])
+            rc = e[1](*e[2]) if hook is None else hook(e[1], e[2], e[3])
             if rc:
                 check(rc, e[3])
         elif kind == RECORD:
