@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     const int li = lane & 15, kk = lane >> 4;
     const int wave_co = wave % NCO, wave_ci = (wave / NCO) % NCI, wk = wave / (NCO * NCI);
     const int co0 = blockIdx.y * (16 * NCO), ci0 = blockIdx.z * (16 * NCI);
-    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
+    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W, xsh = p.ups ? 1 : 0;
     const bool do_bias = p.db != nullptr && blockIdx.z == 0 && wave_ci == 0;
 
     f32x4 acc[16];
@@ -134,7 +134,11 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
         const bool live = q < HH_ * HW_ && ci0 + 4 * v < p.Cin;
         xpy[i] = live ? py - 1 : -(1 << 20);                // a row far outside every image: the bounds test below fails
         xpx[i] = px - 1;
-        xcv[i] = 4 * v;
+        // byte offset of the lane's pixel relative to the region's first pixel (negative for the halo row / column above / left of it).
+        // Region origins are even, so (oy0 + py - 1) >> ups == (oy0 >> ups) + ((py - 1) >> ups) with an arithmetic shift: the per-region
+        // part of the address is one scalar, and no multiplication is left in the per-region code (it compiled to v_mad_u64_u32 +
+        // v_mul_lo_u32 behind two divergent branches per load)
+        xcv[i] = 4 * ((((py - 1) >> xsh) * xW + ((px - 1) >> xsh)) * p.Cin + 4 * v);
     }
     const unsigned zimg = (unsigned)((size_t)p.H * p.W * p.Cout * 4), ximg = (unsigned)((size_t)xH * xW * p.Cin * 4);
     float4 zreg[ZPT], xreg[XPT];
@@ -151,12 +155,11 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
         const unsigned zbase = 4u * (unsigned)((oy0 * p.W + ox0) * p.Cout);
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) zreg[i] = pg_buf_load4(rz, zoff[i], zbase);
+        const int xbase = 4 * (((oy0 >> xsh) * xW + (ox0 >> xsh)) * p.Cin);
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            int ih = oy0 + xpy[i], iw = ox0 + xpx[i];
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            if (p.ups) { ih >>= 1; iw >>= 1; }
-            xreg[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)((ih * xW + iw) * p.Cin + xcv[i]) : PG_OOB, 0);
+            const bool ok = (unsigned)(oy0 + xpy[i]) < (unsigned)p.H && (unsigned)(ox0 + xpx[i]) < (unsigned)p.W;
+            xreg[i] = pg_buf_load4(rx, ok ? (unsigned)(xbase + xcv[i]) : PG_OOB, 0);
         }
     };
     const int r_begin = (int)pg_xcd_remap(blockIdx.x, gridDim.x) * p.regions_per_block;   // neighbouring region ranges on one XCD
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
     const int li = lane & 15, kk = lane >> 4;
     const int wave_ci = wave & 1, wk = wave >> 1;
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
-    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W;
+    const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W, xsh = p.ups ? 1 : 0;
     const bool do_bias = p.db != nullptr && blockIdx.z == 0 && wave_ci == 0;
 
     f32x4 acc[2][16];
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
         const bool live = q < HH_ * HW_ && ci0 + 4 * v < p.Cin;
         xpy[i] = live ? py - 1 : -(1 << 20);
         xpx[i] = px - 1;
-        xcv[i] = 4 * v;
+        xcv[i] = 4 * ((((py - 1) >> xsh) * xW + ((px - 1) >> xsh)) * p.Cin + 4 * v);      // (see conv_wino_wgrad_kernel)
     }
     const unsigned zimg = (unsigned)((size_t)p.H * p.W * p.Cout * 4), ximg = (unsigned)((size_t)xH * xW * p.Cin * 4);
     float4 zreg[ZPT], xreg[XPT];
@@ -334,12 +337,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
         const unsigned zbase = 4u * (unsigned)((oy0 * p.W + ox0) * p.Cout);
 #pragma unroll
         for (int i = 0; i < ZPT; ++i) zreg[i] = pg_buf_load4(rz, zoff[i], zbase);
+        const int xbase = 4 * (((oy0 >> xsh) * xW + (ox0 >> xsh)) * p.Cin);
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            int ih = oy0 + xpy[i], iw = ox0 + xpx[i];
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            if (p.ups) { ih >>= 1; iw >>= 1; }
-            xreg[i] = pg_buf_load4(rx, ok ? 4u * (unsigned)((ih * xW + iw) * p.Cin + xcv[i]) : PG_OOB, 0);
+            const bool ok = (unsigned)(oy0 + xpy[i]) < (unsigned)p.H && (unsigned)(ox0 + xpx[i]) < (unsigned)p.W;
+            xreg[i] = pg_buf_load4(rx, ok ? (unsigned)(xbase + xcv[i]) : PG_OOB, 0);
         }
     };
     const int r_begin = (int)pg_xcd_remap(blockIdx.x, gridDim.x) * p.regions_per_block;
