@@ -65,6 +65,12 @@ constexpr int stride_for(int nw) { return nw == 2 ? 40 : 24; }
 // gz values only, and V' absorbs the signs by swapping the operands of the row-3 / column-3 subtractions.  (The ISA of the first
 // form had 8 v_xor sign flips per 32 MFMAs; VALU cycles and MFMA cycles of co-resident waves add on gfx950,
 // profiles/r04_mfma_valu_share.txt.)  12 VALU for Z', 32 for V'.
+// dW commit: buffer_atomic_add_f32 with the whole offset in the VGPR (the flat atomicAdd cost a v_mad_u64_u32 per address, 72 per lane
+// of the pair kernel; a register soffset is avoided for the reason given at st4 in conv_wino_strip.hip)
+__device__ __forceinline__ void pg_atomic_add(__amdgpu_buffer_rsrc_t r, unsigned voff, float v)
+{
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r, (int)voff, 0, 0);
+}
 __device__ __forceinline__ void wino_zprime(const float* gp, int stride, int row, float (&z)[16])
 {
     const float y00 = gp[0], y01 = gp[stride], y10 = gp[row], y11 = gp[row + stride];
@@ -107,6 +113,8 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     const int co0 = blockIdx.y * (16 * NCO), ci0 = blockIdx.z * (16 * NCI);
     const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W, xsh = p.ups ? 1 : 0;
     const bool do_bias = p.db != nullptr && blockIdx.z == 0 && wave_ci == 0;
+    const __amdgpu_buffer_rsrc_t rdw = pg_make_rsrc(p.dw, 36u * (unsigned)(p.Cout * p.Cin));     // the commit: buffer atomics on 32-bit offsets
+    const unsigned tapbytes = 4u * (unsigned)(p.Cout * p.Cin);
 
     f32x4 acc[16];
 #pragma unroll
@@ -261,9 +269,9 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(WWP p)
     for (int r = 0; r < 4; ++r) {
         const int co = co0 + wave_co * 16 + 4 * kk + r;
         if (co < p.Cout && ci < p.Cin) {
-            float* dst = p.dw + (size_t)co * p.Cin + ci;
+            const unsigned off = 4u * (unsigned)(co * p.Cin + ci);
 #pragma unroll
-            for (int v = 0; v < 9; ++v) atomicAdd(dst + (size_t)v * p.Cout * p.Cin, g[r][v] * p.scale);
+            for (int v = 0; v < 9; ++v) pg_atomic_add(rdw, off + (unsigned)v * tapbytes, g[r][v] * p.scale);
         }
     }
     if (do_bias) {                                            // lane (li = co, kk): sum over its tiles; fold the 4 kk lanes
@@ -293,6 +301,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
     const int xH = p.ups ? (p.H >> 1) : p.H, xW = p.ups ? (p.W >> 1) : p.W, xsh = p.ups ? 1 : 0;
     const bool do_bias = p.db != nullptr && blockIdx.z == 0 && wave_ci == 0;
+    const __amdgpu_buffer_rsrc_t rdw = pg_make_rsrc(p.dw, 36u * (unsigned)(p.Cout * p.Cin));     // the commit: buffer atomics on 32-bit offsets
+    const unsigned tapbytes = 4u * (unsigned)(p.Cout * p.Cin);
 
     f32x4 acc[2][16];
 #pragma unroll
@@ -435,9 +445,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_pair_kernel(WWP p)
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + h * 16 + 4 * kk + r;
                 if (co < p.Cout && ci < p.Cin) {
-                    float* dst = p.dw + (size_t)co * p.Cin + ci;
+                    const unsigned off = 4u * (unsigned)(co * p.Cin + ci);
 #pragma unroll
-                    for (int v = 0; v < 9; ++v) atomicAdd(dst + (size_t)v * p.Cout * p.Cin, (g[r][v] + slot[(9 * r + v) * 64]) * p.scale);
+                    for (int v = 0; v < 9; ++v) pg_atomic_add(rdw, off + (unsigned)v * tapbytes, (g[r][v] + slot[(9 * r + v) * 64]) * p.scale);
                 }
             }
         }
@@ -480,6 +490,7 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
     if (ups && ((H | W) & 1)) return PG_E_ARG;
     if ((long long)N * H * W * Cin >= (1ll << 31) || (long long)N * H * W * Cout >= (1ll << 31)) return PG_E_UNSUP;
     if ((long long)H * W * Cin * 4 >= (1ll << 31) || (long long)H * W * Cout * 4 >= (1ll << 31)) return PG_E_UNSUP;      // 32-bit buffer offsets per image
+    if ((long long)36 * Cout * Cin >= (1ll << 31)) return PG_E_UNSUP;                                                   // ... and into dW
     WWP p;
     p.x = x; p.gz = gz; p.dw = dw; p.db = db_batches ? db : nullptr;
     p.x2 = N2 > 0 ? x2 : x; p.gz2 = N2 > 0 ? gz2 : gz; p.db_batches = db_batches;
