@@ -1193,6 +1193,13 @@ def _assign_grads(net, layers, linear=False):
 # needed by d_loss only.  Same-box pairs, ms per step off | on: 1024^2 10.52 | 10.47, 512^2 13.82 | 13.74, 256^2 23.42 | 23.39, 128^2 equal,
 # 32^2 10.11 | 10.06.  PGGAN_FAKE_SIDE=0: one [fake | mixed] pass on the main stream.
 FAKE_THIRD_ON_SIDE = os.environ.get('PGGAN_FAKE_SIDE', '1') == '1'
+# The real third on the second stream next to the generator's forward of the SAME step (3-image launches with nothing beside them), the
+# fake third behind it on that stream, the mixed third on the main stream: the step time of the look-ahead form (EarlyReal through
+# Trainer: 10.36 | 10.36 ms at 1024^2, 13.41 | 13.41 at 512^2, 23.1 | 23.1 at 256^2, 14.57 | 14.46 at 64^2) without drawing the next batch
+# early, and for every caller of wgan_gp_D_loss: the D step + gradient penalty alone 7.32 -> 7.21 ms at 1024^2, 9.58 -> 9.34 at 512^2,
+# 16.63 -> 16.32 at 256^2.  Default; PGGAN_REAL_SIDE=0 restores the whole-batch forward (and Trainer(early_real_forward=True) /
+# PGGAN_EARLY_REAL=1 the look-ahead pass, which takes precedence when one is pending).
+REAL_THIRD_IN_STEP = os.environ.get('PGGAN_REAL_SIDE', '1') == '1'
 
 
 def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_target):
@@ -1228,6 +1235,35 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
                 s_rest, ctx_rest = d_forward(D, x3[N:], groups=2)             # :54,20
             ctx = _merge_ctx(D, early.ctx, ctx_rest, x3, N)
         s = early.scores._base if early.scores._base is not None else early.scores
+    elif (REAL_THIRD_IN_STEP and float(D.alpha) >= 1.0 and not getattr(D, 'pixelnorm', False) and ASYNC_WGRAD and real.is_cuda
+          and hasattr(ops, 'Arena')):                           # (host tests run the schedules on a CPU emulation of ops: one pass there)
+        # the three thirds as three passes into one set of batched tensors (see REAL_THIRD_IN_STEP)
+        key = (int(D.depth), tuple(real.shape))
+        st = D.__dict__.get('_early_buffers')
+        if st is None or st.key != key:
+            st = D._early_buffers = EarlyReal()
+            st.key = key
+            st.x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
+        x3 = st.x3
+        main = torch.cuda.current_stream(torch._C._cuda_getDevice())
+        side = _side_stream()
+        ops.axpby_mask(real, a=1.0, out=x3[:N])
+        _wait_stream(side, main)
+        with torch.cuda.stream(side):
+            with st.arena.pass_(0):
+                s_r, ctx_r = d_forward(D, x3[:N], groups=1)                   # :47
+        generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52
+        _wait_stream(side, main)
+        with torch.cuda.stream(side):
+            with st.arena.pass_(2):
+                s_f, ctx_f = d_forward(D, x3[N:2 * N], groups=1)              # :54
+            fake_done = torch.cuda.Event()
+            _record_event(fake_done, side)
+        ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
+        with st.arena.pass_(3):
+            s_m, ctx_m = d_forward(D, x3[2 * N:], groups=1)                   # :20
+        ctx = _merge_ctx(D, ctx_r, ctx_f, x3, N, third=ctx_m)
+        s = s_r._base if s_r._base is not None else s_r
     else:
         x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
         ops.axpby_mask(real, a=1.0, out=x3[:N])                               # device copy (plumbing; a C-ABI launch so that plans.py records it)

@@ -160,9 +160,10 @@ class Trainer(object):
         self._inputs = _InputPrefetch()
         self.prefetch_inputs = bool(prefetch_inputs)
         self.input_transform = input_transform
-        # the real third of the next D step's batched D forward runs under this iteration's G step (engine.EarlyReal); None: on
-        # whenever the step qualifies (PGGAN_EARLY_REAL=0 turns it off)
-        self.early_real_forward = (os.environ.get('PGGAN_EARLY_REAL', '1') != '0') if early_real_forward is None else bool(early_real_forward)
+        # look-ahead form of the split D forward: the real third of the NEXT D step under this iteration's G step (engine.EarlyReal).
+        # Off by default since the in-step form (engine.REAL_THIRD_IN_STEP: the real third next to the generator's forward of the same
+        # step) measures the same step time without drawing a batch early; True / PGGAN_EARLY_REAL=1 turn it on
+        self.early_real_forward = (os.environ.get('PGGAN_EARLY_REAL', '0') == '1') if early_real_forward is None else bool(early_real_forward)
         self._next_reals = None               # (batch, iterator it was drawn from) consumed one iteration ahead for that pass
         self._average_in_allreduce = {}
         self._exchanges = {}

@@ -377,10 +377,8 @@ def test_launch_plan_replay_matches_eager(foreign_optimizer):
                     for (_, ma, va), (_, mb_, vb) in zip(oa._flat.values(), ob._flat.values()):
                         mb_.copy_(ma)
                         vb.copy_(va)
-        # (D, G) x two stages.  G: two eager steps, one recorded, then replay (iterations 3..5 and 9).  D: the first step of a stage runs the whole
-        # batch (nothing was evaluated ahead), from the second on the real third is through D already (engine.EarlyReal) -- a plan of its own,
-        # recorded one iteration later than G's (replays: iterations 4, 5)
-        assert pg.plans.STATS['recorded'] == 4 and pg.plans.STATS['replayed'] == (3 + 1) + 2, pg.plans.STATS
+        # (D, G) x two stages: two eager steps, one recorded, then replay (iterations 3..5 and 9) for each of the two networks
+        assert pg.plans.STATS['recorded'] == 4 and pg.plans.STATS['replayed'] == 2 * (3 + 1), pg.plans.STATS
     finally:
         wl._use_plans = True
         wl.enable_graphs(False)
@@ -528,6 +526,47 @@ def test_early_real_third_matches_whole_batch_forward(plans_on, fake_side, tmp_p
     finally:
         wl.enable_graphs(False)
         eng.FAKE_THIRD_ON_SIDE = fake_side_before
+
+
+@pytest.mark.parametrize('plans_on', [False, True])
+def test_three_pass_d_forward_matches_whole_batch_forward(plans_on):
+    """engine.REAL_THIRD_IN_STEP (default): real | fake | mixed thirds of the D forward as three passes into one set of batched tensors,
+    two of them on the second stream, against the one-pass forward of the whole batch (PGGAN_REAL_SIDE=0): same losses, every
+    parameter of D receives the same contributions, over several steps of the public loss -> backward loop (eager and replayed)."""
+    wl, eng = pg.wgan_gp_loss, pg.engine
+    before = eng.REAL_THIRD_IN_STEP
+    wl.enable_graphs(False)
+    wl._use_graphs = 'auto' if plans_on else False
+    try:
+        res = []
+        for three in (True, False):
+            eng.REAL_THIRD_IN_STEP = three
+            pg.plans.clear()
+            torch.manual_seed(23)
+            shape = (1, 3, 32, 32)
+            kw = dict(fmap_base=512, fmap_max=64)
+            G = pg.Generator(shape, latent_size=64, **kw).cuda()
+            D = pg.Discriminator(shape, **kw).cuda()
+            G.depth = D.depth = 3
+            ds = pg.utils.SyntheticDataset(32, 3, seed=9)
+            ds.model_depth = 3
+            it = ds.loader(6)
+            lat = pg.utils.device_latents(6, 64, seed=4)
+            out = []
+            for step in range(5):
+                wl.manual_seed(300 + step)
+                c, rl, fl = pg.wgan_gp_D_loss(D, G, next(it), lat())
+                c.backward()
+                out.append((float(c), rl.clone(), fl.clone(), grads_by_name(D)))
+            res.append(out)
+        for (ca, ra, fa, ga), (cb, rb, fb, gb) in zip(*res):
+            assert abs(ca - cb) <= 2e-4 * max(1.0, abs(cb))
+            assert _l2(ra, rb.cpu()) < 2e-4 and _l2(fa, fb.cpu()) < 2e-4
+            assert_same_contributions(ga, gb)
+    finally:
+        eng.REAL_THIRD_IN_STEP = before
+        wl.enable_graphs(False)
+        pg.plans.clear()
 
 
 def test_whole_module_pickle_roundtrip(tmp_path):
