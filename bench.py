@@ -382,7 +382,7 @@ def cpu_baseline(depth, mb, per_depth=True):
 def relaunch(n):
     """``python bench.py --gpus N`` without a torchrun environment: start the N ranks here."""
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get('PGGAN_DP_SHARE_GPU', '') != '1':       # (test aid: all ranks on device 0, see parallel.from_env; its numbers mean nothing)
         sys.stderr.write('bench.py: --gpus %d requested but only %d GPU(s) are visible on this node; refusing to '
                          'report an N=%d number measured on fewer devices\n' % (n, have, n))
         sys.exit(2)
@@ -643,7 +643,7 @@ def main():
         dp.all_reduce_flat(probe)
         torch.cuda.synchronize()
         got = float(probe[0])
-        if got != float(world) or dp.comm_ranks != world:
+        if got != float(world) or (dp.comm is not None and dp.comm_ranks != world):
             raise RuntimeError('RCCL all-reduce over %d ranks returned %r (communicator size %d)' % (world, got, dp.comm_ranks))
         rccl = {'rccl_ranks': dp.comm_ranks, 'allreduce_probe_sum': got}
         dp.stats.update(collectives=0, bytes=0)
@@ -678,7 +678,8 @@ def main():
                    'images/sec, PGGAN full train step (D+GP step + G step + Adam) at %dx%d') % (res, res),
         'value': value, 'unit': 'images/sec', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'priming_steps': args.prime,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic (seeded uniform images / normal latents, ring of 8 device-resident batches)',
+        'dtype': 'f32', 'data': 'synthetic (seeded uniform images / normal latents, ring of 8 device-resident batches)' + (
+            ' -- PGGAN_DP_SHARE_GPU=1: ALL RANKS ON ONE DEVICE, a collective-matching smoke test, NOT a measurement' if os.environ.get('PGGAN_DP_SHARE_GPU', '') == '1' else ''),
         'config': {'workload': 'BASELINE config %d: PGGAN %dx%d net (fmap_base %d, C=%d, latent %d), stage depth %d = %dx%d, '
                                'alpha %.2f, minibatch %d/GPU%s, Trainer.train(): WGAN-GP + Adam(0,0.99), fp32'
                                % (args.config, net_res, net_res, args.fmap_base, c['ch'], tr.G.latent_size, depth, res, res, args.alpha, mb,
@@ -812,8 +813,11 @@ def main():
                           for k, v in fam.items()}
     elif dp is not None and not args.no_kernel_timing:
         pg.wgan_gp_loss.enable_graphs(False)
-        for _ in range(3):                                  # keep collectives matched with rank 0
+        for _ in range(3):                                  # keep collectives matched with rank 0: its instrumented train steps ...
             tr.train()
+        one = d_step_fn(tr)
+        for _ in range(3):                                  # ... and its instrumented D steps (each exchanges D's gradients)
+            one()
     pg.wgan_gp_loss.enable_graphs(True if args.graphs else 'auto')
     del tr
     pg.plans.clear()

@@ -110,6 +110,10 @@ class DataParallel(object):
             os.environ['WORLD_SIZE'] = '1'
         local = int(os.environ.get('LOCAL_RANK', '0'))
         if torch.cuda.is_available():
+            if os.environ.get('PGGAN_DP_SHARE_GPU', '') == '1':
+                # test aid, never a measurement: every rank on device 0 (with PGGAN_DP_CONTROL=gloo PGGAN_DP_TORCH_ALLREDUCE=1, RCCL
+                # refuses two ranks on one device) -- checks that the ranks of a multi-process run issue matching collectives
+                local = 0
             if local >= torch.cuda.device_count():
                 raise RuntimeError('rank with LOCAL_RANK %d but only %d GPU(s) are visible' % (local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
