@@ -516,7 +516,9 @@ extern "C" int pg_conv2d_wgrad_wino2_nhwc(const float* x, const float* gz, int N
     //  256 and 768 lose at 1024^2: 10.66 / 10.75.  Alone on the device 512 is 1-2 % faster than 384.)
     static const int target_env = [] { const char* t = getenv("PG_WW_TARGET"); return t ? atoi(t) : 0; }();
     static const int target3_env = [] { const char* t = getenv("PG_WW_TARGET3"); return t ? atoi(t) : 0; }();        // launches of <= 4 images (the G step's): sweeps
-    const int target = (target3_env > 0 && N + N2 <= 4) ? target3_env : target_env > 0 ? target_env : (N + N2 <= 12 ? 384 : 512);
+    const int target = (target3_env > 0 && N + N2 <= 4) ? target3_env : target_env > 0 ? target_env : (N + N2 <= 12 ? 320 : N + N2 <= 24 ? 384 : 512);
+    // (round 5, after the k-step got faster; same-box pairs: 1024^2 stage 320 | 384: 10.286 | 10.308 ms over five pairs, 288 equal, 256 +0.08;
+    //  512^2 stage (launches of 6 and 24 images) 384 | 512: 13.44 | 13.54; 256^2 stage (14 and 56 images) 512 | 384 | 768: 23.0 | 23.1 | 23.1)
     int chunks = (target + gy * gz_ - 1) / (gy * gz_);
     if (chunks > p.nregions) chunks = p.nregions;
     if (chunks < 1) chunks = 1;
