@@ -528,6 +528,59 @@ def test_early_real_third_matches_whole_batch_forward(plans_on, fake_side, tmp_p
         eng.FAKE_THIRD_ON_SIDE = fake_side_before
 
 
+def test_call_hook_sees_the_same_launches_eager_and_replayed():
+    """``_lib.CALL_HOOK`` (bench.py's per-launch timing) runs on every C-ABI call of an eager step AND of a step replayed from a launch plan:
+    the same entry points the same number of times, with the stream handle as the last argument, and the results with the hook in
+    place equal those without it."""
+    wl = pg.wgan_gp_loss
+    torch.manual_seed(31)
+    shape = (1, 3, 32, 32)
+    kw = dict(fmap_base=512, fmap_max=64)
+    G = pg.Generator(shape, latent_size=64, **kw).cuda()
+    D = pg.Discriminator(shape, **kw).cuda()
+    G.depth = D.depth = 3
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    real = torch.rand((6, 3, 32, 32), device=DEV, generator=gen) * 2 - 1
+    z = torch.randn((6, 64), device=DEV, generator=gen)
+    mix = torch.rand((6, 1), device=DEV, generator=gen)
+    seen = {}
+
+    def hook(fn, args, name):
+        seen.setdefault(mode_tag[0], []).append((name, len(args)))
+        assert args[-1] is None or isinstance(args[-1], int)
+        return fn(*args)
+
+    def step():
+        wl.set_mixing_factors(mix)
+        c = pg.wgan_gp_D_loss(D, G, real, z)[0]
+        c.backward()
+        torch.cuda.synchronize()
+        return float(c), D._flat_grad.clone()
+    mode_tag = ['none']
+    pg.plans.clear()
+    try:
+        wl._use_graphs = False
+        ref = step()
+        pg._lib.CALL_HOOK = hook
+        mode_tag[0] = 'eager'
+        eager = step()
+        wl._use_graphs = 'auto'
+        mode_tag[0] = 'warm'
+        for _ in range(3):                                     # two eager warm-up calls, one recorded
+            step()
+        mode_tag[0] = 'replay'
+        replay = step()
+        assert pg.plans.STATS['replayed'] >= 1
+    finally:
+        pg._lib.CALL_HOOK = None
+        wl.enable_graphs(False)
+        pg.plans.clear()
+    assert abs(eager[0] - ref[0]) <= 2e-4 * max(1.0, abs(ref[0])) and abs(replay[0] - ref[0]) <= 2e-4 * max(1.0, abs(ref[0]))
+    assert _l2(eager[1], ref[1].cpu()) < 2e-3 and _l2(replay[1], ref[1].cpu()) < 2e-3
+    conv = lambda calls: sorted(n for n, _ in calls if n.startswith('pg_conv2d'))
+    assert conv(seen['replay']) == conv(seen['eager']) and len(conv(seen['replay'])) > 20
+
+
 @pytest.mark.parametrize('plans_on', [False, True])
 def test_three_pass_d_forward_matches_whole_batch_forward(plans_on):
     """engine.REAL_THIRD_IN_STEP (default): real | fake | mixed thirds of the D forward as three passes into one set of batched tensors,
