@@ -1236,7 +1236,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
             ctx = _merge_ctx(D, early.ctx, ctx_rest, x3, N)
         s = early.scores._base if early.scores._base is not None else early.scores
     elif (REAL_THIRD_IN_STEP and float(D.alpha) >= 1.0 and not getattr(D, 'pixelnorm', False) and ASYNC_WGRAD and real.is_cuda
-          and hasattr(ops, 'Arena')):                           # (host tests run the schedules on a CPU emulation of ops: one pass there)
+          and hasattr(ops, 'Arena') and D.__dict__.get('_global_stddev') is None):   # (exact-global stddev: its collectives stay on one stream, one pass)                           # (host tests run the schedules on a CPU emulation of ops: one pass there)
         # the three thirds as three passes into one set of batched tensors (see REAL_THIRD_IN_STEP)
         key = (int(D.depth), tuple(real.shape))
         st = D.__dict__.get('_early_buffers')
