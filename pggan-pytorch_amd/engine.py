@@ -1247,11 +1247,14 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
         x3 = st.x3
         main = torch.cuda.current_stream(torch._C._cuda_getDevice())
         side = _side_stream()
-        ops.axpby_mask(real, a=1.0, out=x3[:N])
         _wait_stream(side, main)
         with torch.cuda.stream(side):
+            ops.axpby_mask(real, a=1.0, out=x3[:N])                           # (the copy into the batched image buffer too, so that the generator starts at once: -0.03 ms)
+            real_copied = torch.cuda.Event()
+            _record_event(real_copied, side)
             with st.arena.pass_(0):
                 s_r, ctx_r = d_forward(D, x3[:N], groups=1)                   # :47
+        real.record_stream(side)
         generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52
         _wait_stream(side, main)
         with torch.cuda.stream(side):
@@ -1259,6 +1262,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
                 s_f, ctx_f = d_forward(D, x3[N:2 * N], groups=1)              # :54
             fake_done = torch.cuda.Event()
             _record_event(fake_done, side)
+        _wait_event(main, real_copied)
         ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
         with st.arena.pass_(3):
             s_m, ctx_m = d_forward(D, x3[2 * N:], groups=1)                   # :20
