@@ -1247,15 +1247,17 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
         x3 = st.x3
         main = torch.cuda.current_stream(torch._C._cuda_getDevice())
         side = _side_stream()
-        _wait_stream(side, main)
+        step_start = torch.cuda.Event()
+        _record_event(step_start, main)                                       # (everything the previous step left on the main stream)
+        generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52  -- issued first: the host feeds the critical path before the side work
         with torch.cuda.stream(side):
+            _wait_event(side, step_start)
             ops.axpby_mask(real, a=1.0, out=x3[:N])                           # (the copy into the batched image buffer too, so that the generator starts at once: -0.03 ms)
             real_copied = torch.cuda.Event()
             _record_event(real_copied, side)
             with st.arena.pass_(0):
                 s_r, ctx_r = d_forward(D, x3[:N], groups=1)                   # :47
         real.record_stream(side)
-        generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52
         _wait_stream(side, main)
         with torch.cuda.stream(side):
             with st.arena.pass_(2):
