@@ -613,8 +613,8 @@ def test_three_pass_d_forward_matches_whole_batch_forward(plans_on):
                 out.append((float(c), rl.clone(), fl.clone(), grads_by_name(D)))
             res.append(out)
         for (ca, ra, fa, ga), (cb, rb, fb, gb) in zip(*res):
-            assert abs(ca - cb) <= 2e-4 * max(1.0, abs(cb))
-            assert _l2(ra, rb.cpu()) < 2e-4 and _l2(fa, fb.cpu()) < 2e-4
+            assert abs(ca - cb) <= 5e-4 * max(1.0, abs(cb))                # (different launch groupings: K-slice counts, summation orders)
+            assert _l2(ra, rb.cpu()) < 5e-4 and _l2(fa, fb.cpu()) < 5e-4
             assert_same_contributions(ga, gb)
     finally:
         eng.REAL_THIRD_IN_STEP = before
