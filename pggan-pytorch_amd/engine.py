@@ -19,6 +19,8 @@ minibatch-stddev Hessian-vector term injected into the ordinary batched backward
 samples (SURVEY.md §7 "hard parts"; formulas verified against autograd in tests/).
 """
 import os
+import weakref as _weakref
+
 import torch
 
 from . import ops
@@ -137,6 +139,41 @@ def _derived(net):
         backward_copies()
     net._derived_ver = key
     net._derived_live = live
+    # Everything above that was NOT handed to the side stream (the forward forms always; the backward copies in the inline case) was
+    # launched on ``cur``.  A consumer on ANOTHER stream must be ordered behind it (_await_derived): the three-pass D forward refreshes D's
+    # derived weights from inside its real-third pass on the second stream whenever the update did not come through Trainer's deferred
+    # update -- the public ``loss.backward(); optimizer.step()`` loop, a foreign optimizer, load_state_dict -- while the mixed third on
+    # the main stream was ordered behind the image copy only (round-5 lock-step failure, docs/experiments_r6.md §1).
+    net._derived_ev = None
+    net._derived_waited = set()
+    if dev is not None and DERIVED_EVENT and not torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        _record_event(ev, cur)
+        net._derived_ev = ev
+        net._derived_waited = {cur.cuda_stream}
+
+
+def _await_derived(net):
+    """The current stream waits (once) for the last refresh of the derived weights if that ran on another stream."""
+    ev = net.__dict__.get('_derived_ev')
+    if ev is not None:
+        cur = torch.cuda.current_stream(torch._C._cuda_getDevice())
+        waited = net._derived_waited
+        if cur.cuda_stream not in waited and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(ev)
+            waited.add(cur.cuda_stream)
+
+
+def order_side_behind_derived(net):
+    """plans.py, before a replay: the recorded body's per-launch ``_await_derived`` calls are not part of a plan (they are no-ops in
+    the orders a plan is entered with), so the one ordering a replay could miss -- the second stream behind a refresh ``_prologue`` just
+    issued on the main stream -- is established here, once per step."""
+    ev = net.__dict__.get('_derived_ev')
+    if ev is not None and ASYNC_WGRAD:
+        side = _side_stream()
+        if side.cuda_stream not in net._derived_waited:
+            side.wait_event(ev)
+            net._derived_waited.add(side.cuda_stream)
 
 
 def _assert_live(net, layer):
@@ -173,6 +210,7 @@ def _wt(net, layer):
     _want_backward_copies(net)
     _derived(net)
     _assert_live(net, layer)
+    _await_derived(net)
     _await_backward_copies(net)
     return layer._wt
 
@@ -194,6 +232,7 @@ def _wino(layer, N, H, cout, transposed=False):
         _want_backward_copies(net)
     _derived(net)
     _assert_live(net, layer)
+    _await_derived(net)
     if transposed:
         _await_backward_copies(net)
     return layer._wtu if transposed else layer._wu
@@ -320,6 +359,7 @@ def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
 # half-occupancy MFMA kernels share the CUs instead of running back to back.
 ASYNC_WGRAD = _os.environ.get('PGGAN_ASYNC_WGRAD', '1') != '0'
 ASYNC_DERIVED = _os.environ.get('PGGAN_ASYNC_DERIVED', '1') != '0'
+DERIVED_EVENT = _os.environ.get('PGGAN_DERIVED_EVENT', '1') != '0'    # 0: the round-5 behaviour (ablation for tests/test_e2e_gpu.py::test_derived_refresh_ordering only)
 DERIVED_ONE_LAUNCH = _os.environ.get('PGGAN_DERIVED_ONE_LAUNCH', '1') != '0'      # forward + backward-data Winograd weights of a network: one launch
 # 0: every live layer gets a flipped / transposed copy and the backward-data Winograd form is derived from that copy (round 2)
 WTU_FROM_PARAM = _os.environ.get('PGGAN_WTU_FROM_PARAM', '1') != '0'
@@ -338,6 +378,20 @@ def _record_event(ev, stream):
 
 def _wait_event(stream, ev):
     stream.wait_event(ev)
+
+
+# Un-traced phase timeline (tools/phase_timeline.py): with ``PROBES`` set to a dict, the step schedules drop a timing event on the
+# current stream at every phase boundary -- through ``_record_event``, so a launch plan re-records the same events on every replay and
+# the probes cost ~25 event packets per step instead of the host slow-down of a tracer (rocprofv3 --kernel-trace makes the host the
+# bottleneck of the 340-launch 1024^2 step: its "queue waiting" gaps are partly its own).  None (default): nothing is recorded.
+PROBES = None
+
+
+def probe(tag):
+    if PROBES is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        _record_event(ev, torch.cuda.current_stream(torch._C._cuda_getDevice()))
+        PROBES.setdefault(tag, []).append(ev)
 
 
 def _side_stream():
@@ -727,6 +781,22 @@ class EarlyReal(object):
         self.key = None
         self.real = None
         self.ctx = self.scores = self.event = self.stamp = None
+        self.owner = None                   # weakref to the _ArenaUse token of the D-loss state whose activations live in these buffers
+
+
+class _ArenaUse(object):
+    """Token a D-loss state holds while its saved activations alias the per-network arena: as long as the state is alive and its
+    ``backward()`` has not run, another D-loss forward on the same network must not write into those buffers (it allocates fresh
+    tensors instead -- two losses then backward, a validation loss between forward and backward)."""
+    __slots__ = ('consumed', '__weakref__')
+
+    def __init__(self):
+        self.consumed = False
+
+
+def _arena_free(st):
+    tok = st.owner() if st.owner is not None else None
+    return tok is None or tok.consumed
 
 
 EARLY_STATS = {'passes': 0, 'used': 0, 'dropped': 0}
@@ -1213,6 +1283,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     D._sync_version()
     early = take_early_real(D, real)
     fake_done = None
+    arena_st = early
     if early is not None:
         # the real third is already through D (Trainer, under the previous G step): the other two thirds follow into the same tensors
         x3 = early.x3
@@ -1236,38 +1307,43 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
             ctx = _merge_ctx(D, early.ctx, ctx_rest, x3, N)
         s = early.scores._base if early.scores._base is not None else early.scores
     elif (REAL_THIRD_IN_STEP and float(D.alpha) >= 1.0 and not getattr(D, 'pixelnorm', False) and ASYNC_WGRAD and real.is_cuda
-          and hasattr(ops, 'Arena') and D.__dict__.get('_global_stddev') is None):   # (exact-global stddev: its collectives stay on one stream, one pass)                           # (host tests run the schedules on a CPU emulation of ops: one pass there)
+          and hasattr(ops, 'Arena') and D.__dict__.get('_global_stddev') is None     # (exact-global stddev: its collectives stay on one stream, one pass; host tests run the schedules on a CPU emulation of ops: one pass there)
+          and _three_pass_buffers(D, real) is not None):
         # the three thirds as three passes into one set of batched tensors (see REAL_THIRD_IN_STEP)
-        key = (int(D.depth), tuple(real.shape))
-        st = D.__dict__.get('_early_buffers')
-        if st is None or st.key != key:
-            st = D._early_buffers = EarlyReal()
-            st.key = key
-            st.x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
+        st = arena_st = D._early_buffers
         x3 = st.x3
         main = torch.cuda.current_stream(torch._C._cuda_getDevice())
         side = _side_stream()
+        wait_pending(D)                                                       # on the MAIN stream, before the fork: the side pass's own wait_pending would consume the event there and leave the mixed third un-ordered
         step_start = torch.cuda.Event()
         _record_event(step_start, main)                                       # (everything the previous step left on the main stream)
+        probe('D.start')
         generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52  -- issued first: the host feeds the critical path before the side work
+        probe('D.g_fwd_end')
         with torch.cuda.stream(side):
             _wait_event(side, step_start)
+            probe('D.side_start')
             ops.axpby_mask(real, a=1.0, out=x3[:N])                           # (the copy into the batched image buffer too, so that the generator starts at once: -0.03 ms)
             real_copied = torch.cuda.Event()
             _record_event(real_copied, side)
             with st.arena.pass_(0):
                 s_r, ctx_r = d_forward(D, x3[:N], groups=1)                   # :47
+            probe('D.real_end')
         real.record_stream(side)
         _wait_stream(side, main)
         with torch.cuda.stream(side):
+            probe('D.fake_start')
             with st.arena.pass_(2):
                 s_f, ctx_f = d_forward(D, x3[N:2 * N], groups=1)              # :54
             fake_done = torch.cuda.Event()
             _record_event(fake_done, side)
+            probe('D.fake_end')
         _wait_event(main, real_copied)
         ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
+        probe('D.mix_end')
         with st.arena.pass_(3):
             s_m, ctx_m = d_forward(D, x3[2 * N:], groups=1)                   # :20
+        probe('D.mixed_fwd_end')
         ctx = _merge_ctx(D, ctx_r, ctx_f, x3, N, third=ctx_m)
         s = s_r._base if s_r._base is not None else s_r
     else:
@@ -1280,11 +1356,30 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     gimg, adj = d_backward(D, sub, _ones(N, real.device), full=False, want_gimg=True, save_adjoints=True)  # :25-28
     ss = ops.row_sumsq(gimg)
     gp, u = ops.gp_seed(gimg, ss, iwass_lambda, iwass_target, 1.0 / N)        # :29-31
+    probe('D.gp_bwd_end')
     if fake_done is not None:
         _wait_event(torch.cuda.current_stream(torch._C._cuda_getDevice()), fake_done)
     d_cost, d_real_loss, d_fake_loss, gscore = ops.d_loss(s, gp, N, iwass_epsilon)   # :48,55,62
+    probe('D.loss_end')
     state = dict(D=D, ctx=ctx, sub=sub, adj=adj, u=u, gscore=gscore, N=N, scores=s, gp=gp)
+    if arena_st is not None:
+        tok = state['arena_use'] = _ArenaUse()
+        state['arena_st'] = arena_st
+        arena_st.owner = _weakref.ref(tok)
     return d_cost, d_real_loss, d_fake_loss, state
+
+
+def _three_pass_buffers(D, real):
+    """The per-(network, stage, shape) arena of the three-pass forward, or None when the activations of an earlier D loss of this
+    network still live in it (that loss is alive and has not been back-propagated): the caller then takes the allocating one-pass form."""
+    key = (int(D.depth), tuple(real.shape))
+    st = D.__dict__.get('_early_buffers')
+    if st is None or st.key != key:
+        st = D._early_buffers = EarlyReal()
+        st.key = key
+        st.x3 = torch.empty((3 * real.shape[0],) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
+        return st
+    return st if _arena_free(st) else None
 
 
 def take_early_real(D, real):
@@ -1307,16 +1402,26 @@ def d_loss_backward(state, scale=1.0):
     """``D_cost.backward()`` (trainer.py:98): tangent pass + batched [real|fake|mixed] adjoint sweep."""
     D, ctx, N = state['D'], state['ctx'], state['N']
     D._ensure_buffers()
+    tok = state.get('arena_use')
+    if tok is not None:
+        if state['arena_st'].owner() is not tok:     # (second line of defence: a retained loss back-propagated again after a later forward)
+            raise RuntimeError('the activations of this D loss were overwritten by a later D-loss forward on the same network')
+        tok.consumed = True
     ops.zero_(D._flat_grad)
     if scale != 1.0:
         D._grad_hook = None                      # the gradients are rescaled after the sweep: nothing may travel early
     for lay in _live_conv_layers(D):             # (nothing of an aborted earlier step may ride along)
         lay._pending_wgrad = None
     hvp = d_tangent_wgrad(D, state['sub'], state['adj'], state['u'])
+    probe('D.tangent_end')
     gs = state['gscore'][:2 * N]
     d_backward(D, ctx, gs, full=True, want_gimg=False, hvp=(2 * N,) + hvp)
     for lay in _live_conv_layers(D):             # (a deferred tangent contribution that no launch of the sweep carried)
         _flush_wgrad(lay)
+    probe('D.sweep_end')
+    if PROBES is not None and ASYNC_WGRAD and D._flat_param.is_cuda:
+        with torch.cuda.stream(_side_stream()):
+            probe('D.wgrad_end')
     if not (getattr(D, '_skip_join', False) and scale == 1.0):
         _join_side()         # default: the gradients are complete for whatever the caller does next on this stream
     # (Trainer sets _skip_join when the whole D update follows on the second stream, in order behind the weight
@@ -1333,9 +1438,12 @@ def g_loss_forward(G, D, latents):
     latents = _check_dev(latents, 'latents')
     D._sync_version()
     G._sync_version()
+    probe('G.start')
     fake, gctx = generator_forward(G, latents, save=True)
+    probe('G.g_fwd_end')
     s, dctx = d_forward(D, fake, 1)
     g_cost, gscore = ops.g_loss(s)
+    probe('G.d_fwd_end')
     return g_cost, dict(G=G, D=D, gctx=gctx, dctx=dctx, gscore=gscore)
 
 
@@ -1348,7 +1456,12 @@ def g_loss_backward(state, scale=1.0):
     if scale != 1.0:
         G._grad_hook = None
     gimg, _ = d_backward(D, state['dctx'], state['gscore'], full=False, want_gimg=True)
+    probe('G.d_bwd_end')
     active = generator_backward(G, state['gctx'], gimg)
+    probe('G.g_bwd_end')
+    if PROBES is not None and ASYNC_WGRAD and G._flat_param.is_cuda:
+        with torch.cuda.stream(_side_stream()):
+            probe('G.wgrad_end')
     _join_side()
     if scale != 1.0:
         ops.axpby_mask(G._flat_grad, a=scale, out=G._flat_grad)

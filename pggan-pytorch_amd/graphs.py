@@ -21,6 +21,7 @@ class _Graphed(object):
         self.graph = None
         self.static_in = None
         self.static_out = None
+        self.keep = None
         self.warm = 0
 
 
@@ -73,6 +74,10 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
         with torch.cuda.graph(graph):
             g.static_out = body()
         g.graph = graph
+        # the three-pass forward's activations live in the network's single-slot arena (engine._three_pass_buffers), allocated during the
+        # eager warm-up, i.e. OUTSIDE the graph's private pool: the graph bakes their addresses, so it keeps them alive -- a D step of
+        # another batch shape at this depth replaces D._early_buffers, and a replay of this graph must not touch freed memory
+        g.keep = D.__dict__.get('_early_buffers')
     g.graph.replay()
     engine._assign_grads(D, engine.d_active_params(D, int(D.depth), 1.0), linear=True)
     # the static outputs are overwritten by the next replay: hand out copies (a plugin may keep loss tensors)

@@ -311,6 +311,8 @@ class _FlatParamsMixin(object):
         d['_layer_list'] = None
         d['_derived_bwd_ev'] = None
         d['_derived_bwd_waited'] = set()
+        d['_derived_ev'] = None
+        d['_derived_waited'] = set()
         d['_bwd_wanted'] = False
         return d
 

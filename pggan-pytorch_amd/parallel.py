@@ -275,9 +275,10 @@ class GradExchange(object):
         if not runs:
             return
         if flat.is_cuda:
+            from . import engine
             ex = self.dp.exchange_stream()
             src = self.side if self.side is not None else torch.cuda.current_stream()
-            ex.wait_stream(src)                   # behind the weight-gradient launches enqueued so far
+            engine._wait_stream(ex, src)          # behind the weight-gradient launches enqueued so far (through engine's helper: a launch plan records the edge)
             with torch.cuda.stream(ex):
                 for s, e in runs:
                     self.dp.all_reduce_flat(flat[s:e], stream=ex)
@@ -286,6 +287,15 @@ class GradExchange(object):
                 self.dp.all_reduce_flat(flat[s:e])
         self.buckets += len(runs)
         self.sent_bytes += sum(e - s for s, e in runs) * 4
+
+    # A launch plan (plans.py) that was recorded with this exchange open replays the bucket collectives the sweep issued; the host-side
+    # bookkeeping they went with is put back from a snapshot taken at the end of the recording, so that ``finish()`` -- which runs
+    # eagerly, outside the plan -- sends exactly what the replayed sweep has not sent.
+    def snapshot(self):
+        return (list(self.state), self.ready_bytes, self.sent_bytes, self.buckets, self.side)
+
+    def restore(self, snap):
+        self.state, self.ready_bytes, self.sent_bytes, self.buckets, self.side = list(snap[0]), snap[1], snap[2], snap[3], snap[4]
 
     def finish(self):
         """Send the remaining layers (those never reported count as ready now: the sweep is over) and join."""

@@ -19,8 +19,10 @@ static buffers, losses come back in static tensors (copies are handed out), grad
 exactly as in the eager path.
 
 Not in a plan: Adam and the derived-weight refresh (host scalars / version checks: ``Trainer`` runs them eagerly after each update,
-``_prologue`` re-checks the versions before every replay so that a foreign optimizer or ``load_state_dict`` is noticed), the RCCL
-exchange (data-parallel runs stay eager: the bucketed exchange hooks into the backward sweep), fade-in phases (a new alpha per
+``_prologue`` re-checks the versions before every replay so that a foreign optimizer or ``load_state_dict`` is noticed), the tail of
+the RCCL exchange (``GradExchange.finish``: what the sweep has not sent, and the join -- part of the update Trainer runs eagerly; the bucket
+collectives the sweep itself issues ARE recorded, round 6: ``pg_allreduce_sum_f32`` is a C-ABI call like any other and the edges to the
+exchange stream go through ``engine._wait_stream``), fade-in phases (a new alpha per
 iteration), the mixing-factor draw (a counter-based RNG call with a new counter per step, written into the static buffer)."""
 import collections
 
@@ -37,6 +39,7 @@ class _Plan(object):
         self.keep = {}               # id -> tensor: everything whose pointer is baked into the entries
         self.static_in = None
         self.static_out = None
+        self.dp_state = None         # (GradExchange snapshot, collectives, bytes) of the recorded step under data parallelism
         self.warm = 0
 
 
@@ -165,6 +168,31 @@ def _prologue(*nets):
         net._ensure_buffers()
         if net._derived_ver != (net._param_version, int(net.depth)):
             engine._derived(net)
+        engine.order_side_behind_derived(net)
+
+
+def _dp_tag(net):
+    """What a plan recorded under data parallelism depends on: the bucketed exchange the sweep feeds (``Trainer._open_exchange`` installs it
+    BEFORE the loss call in plan mode) and whether its collectives are being left out (bench.py's exposed-exchange estimate)."""
+    ex = net.__dict__.get('_grad_exchange') if net.__dict__.get('_grad_hook') is not None else None
+    return (0, None) if ex is None else ((id(ex), bool(ex.dp.skip_exchange)), ex)
+
+
+def _dp_begin(ex):
+    return None if ex is None else (ex.dp.stats['collectives'], ex.dp.stats['bytes'])
+
+
+def _dp_recorded(g, ex, before):
+    if ex is not None:
+        g.dp_state = (ex.snapshot(), ex.dp.stats['collectives'] - before[0], ex.dp.stats['bytes'] - before[1])
+
+
+def _dp_replayed(g, ex):
+    if ex is not None:
+        snap, ncoll, nbytes = g.dp_state
+        ex.restore(snap)
+        ex.dp.stats['collectives'] += ncoll
+        ex.dp.stats['bytes'] += nbytes
 
 
 def d_step(D, G, real, latents, mix, lam, eps, target):
@@ -176,8 +204,9 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
     if early is not None and not (early.real is real and early.stamp == (D._param_version, int(D.depth), float(D.alpha))):
         early = D.__dict__.pop('_early_real') and None
         engine.EARLY_STATS['dropped'] += 1
+    dp_tag, ex = _dp_tag(D)
     key = ('D', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(D.depth), tuple(real.shape), tuple(latents.shape), float(lam), float(eps), float(target),
-           id(early.arena) if early is not None else 0)
+           id(early.arena) if early is not None else 0, dp_tag)
     g = _CACHE.get(key)
     if g is None:
         g = _new_plan(key)
@@ -213,10 +242,13 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
         if g.warm < 2:                       # eager warm-up (kernel attributes, first-request derived copies, allocator pools)
             g.warm += 1
             return body()
+        before = _dp_begin(ex)
         with _Recorder(g):
             g.static_out = body()
+        _dp_recorded(g, ex, before)
     else:
         _replay(g)
+        _dp_replayed(g, ex)
     engine._assign_grads(D, engine.d_active_params(D, int(D.depth), 1.0), linear=True)
     # the static outputs are overwritten by the next replay: hand out copies (a plugin may keep loss tensors) -- one device copy when
     # they are views of one buffer (ops.d_loss)
@@ -229,7 +261,8 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
 
 def g_step(G, D, latents):
     """Plan-replayed ``g_loss_forward`` + ``g_loss_backward``.  Returns g_cost."""
-    key = ('G', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(G.depth), tuple(latents.shape))
+    dp_tag, ex = _dp_tag(G)
+    key = ('G', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(G.depth), tuple(latents.shape), dp_tag)
     g = _CACHE.get(key)
     if g is None:
         g = _new_plan(key)
@@ -249,9 +282,12 @@ def g_step(G, D, latents):
         if g.warm < 2:
             g.warm += 1
             return body()[0]
+        before = _dp_begin(ex)
         with _Recorder(g):
             g.static_out = body()
+        _dp_recorded(g, ex, before)
     else:
         _replay(g)
+        _dp_replayed(g, ex)
     engine._assign_grads(G, g.static_out[1])
     return g.static_out[0].clone()

@@ -177,7 +177,11 @@ class Trainer(object):
             D._global_stddev = parallel if global_stddev else None
         if parallel is not None:
             from . import wgan_gp_loss
-            wgan_gp_loss.enable_plans(False)         # the bucketed exchange hooks into the eager backward sweep
+            if getattr(parallel, 'comm', None) is None:
+                # the reduction goes through torch.distributed (CPU hosts / PGGAN_DP_TORCH_ALLREDUCE=1): not a C-ABI call, a launch plan
+                # cannot replay it.  With the library's own RCCL communicator the bucket collectives are recorded like any other
+                # launch (round 6: plans.py), and the data-parallel step is issued from a plan exactly as the single-GPU one.
+                wgan_gp_loss.enable_plans(False)
             for net, opt in ((D, optimizer_d), (G, optimizer_g)):
                 if hasattr(opt, 'grad_scale'):
                     opt.grad_scale = parallel.grad_scale          # FusedAdam folds 1/world into its update
@@ -227,7 +231,7 @@ class Trainer(object):
         if self.parallel is None or not hasattr(net, '_flat_param'):
             return
         from . import parallel as par, wgan_gp_loss
-        if wgan_gp_loss._replay_mode(net) is not None and float(net.alpha) >= 1.0 and net._flat_param.is_cuda:
+        if wgan_gp_loss._replay_mode(net) == 'graph' and float(net.alpha) >= 1.0 and net._flat_param.is_cuda:
             return
         if os.environ.get('PGGAN_DP_BUCKETS', '1') == '0':
             return
@@ -246,6 +250,7 @@ class Trainer(object):
         self.optimizer_d.step()                                                   # reference trainer.py:100
         if getattr(self.D, '_flat_param', None) is not None and self.D._flat_param.is_cuda:
             engine._derived(self.D)
+            engine.probe('D.update_end')
         if self._probe_open is not None:             # end of the D+GP window, on the stream the update ran on
             end = torch.cuda.Event(enable_timing=True)
             end.record()
@@ -313,10 +318,16 @@ class Trainer(object):
             if probe and last and self.iterations % probe['every'] == 0 and getattr(reals, 'is_cuda', False):
                 self._probe_open = torch.cuda.Event(enable_timing=True)
                 self._probe_open.record()
-            d_losses = _as_tuple(self.D_loss(self.D, self.G, reals, latents))     # :95
+            # (the exchange is opened BEFORE the loss call: a plan-replayed loss has its backward sweep -- and the bucket collectives the
+            #  sweep feeds -- inside that call; an eager forward never reports a finished block)
+            self._open_exchange(self.D, engine.d_exchange_layers)
+            try:
+                d_losses = _as_tuple(self.D_loss(self.D, self.G, reals, latents)) # :95
+            except BaseException:
+                self.D._grad_hook = None
+                raise
             defer = last and self._can_overlap_d_update()
             self.D._skip_join = defer                # the update runs on the second stream, behind the weight gradients
-            self._open_exchange(self.D, engine.d_exchange_layers)
             try:
                 d_losses[0].backward()                                            # :98
             finally:
@@ -339,9 +350,9 @@ class Trainer(object):
                 engine._join_side()                  # (a replayed plan leaves the weight gradients un-joined; a second join is free)
                 self._d_update()
             latents = _to_device(self.random_latents_generator())                 # :103
-        g_losses = _as_tuple(self.G_loss(self.G, self.D, latents))                # :105-110
         self._open_exchange(self.G, engine.g_exchange_layers)
         try:
+            g_losses = _as_tuple(self.G_loss(self.G, self.D, latents))            # :105-110
             g_losses[0].backward()                                                # :111
         finally:
             self.G._grad_hook = None
@@ -349,6 +360,7 @@ class Trainer(object):
         self.optimizer_g.step()                                                   # :112
         if getattr(self.G, '_flat_param', None) is not None and self.G._flat_param.is_cuda:
             engine._derived(self.G)                  # (the next generator pass needs them first thing; never part of a replayed plan)
+            engine.probe('G.update_end')
         engine.wait_pending(self.D)                  # (a G_loss that never ran D: nothing may outlive the iteration)
         self.iterations += 1
         self.call_plugins('iteration', self.iterations, *(g_losses + d_losses))   # :115

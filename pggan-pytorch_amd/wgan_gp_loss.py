@@ -31,8 +31,9 @@ def enable_graphs(flag=True):
 
 
 def enable_plans(flag=True):
-    """Launch-plan replay of the stages above 4x4 (see ``enable_graphs``).  Off under data parallelism: the bucketed gradient
-    exchange hooks into the eager backward sweep."""
+    """Launch-plan replay of the stages above 4x4 (see ``enable_graphs``).  Under data parallelism the bucket collectives of the
+    sweep are part of the plan (the library's RCCL communicator); Trainer turns plans off only when the reduction goes through
+    torch.distributed (CPU hosts)."""
     global _use_plans
     _use_plans = bool(flag)
     if not flag:
@@ -50,6 +51,12 @@ def _replay_mode(net):
     if _use_graphs is True or int(net.depth) == 0:
         return 'graph'
     return 'plan' if _use_plans else None
+
+
+def _exchange_instrumented(net):
+    """bench.py times every collective with a fresh HIP event pair (``DataParallel.record_events``): those steps are issued eagerly."""
+    ex = net.__dict__.get('_grad_exchange') if net.__dict__.get('_grad_hook') is not None else None
+    return ex is not None and ex.dp.record_events
 
 
 def _graphs_on(net):
@@ -146,6 +153,8 @@ def wgan_gp_D_loss(D, G, real_images_in, fake_latents_in,
         mix = _draw_mixing_factors(n, real_images_in.device)
     mode = _replay_mode(D) if (float(D.alpha) >= 1.0 and real_images_in.is_cuda and hasattr(D, '_flat_param')
                                and D.__dict__.get('_global_stddev') is None) else None      # (exact-global stddev: collectives inside the step -> eager)
+    if mode == 'plan' and _exchange_instrumented(D):
+        mode = None
     if mode is not None:
         from . import graphs, plans
         real_c = engine._check_dev(real_images_in, 'real images')
@@ -169,6 +178,8 @@ def wgan_gp_G_loss(G, D, fake_latents_in):
     G.zero_grad()                                                        # :69
     mode = _replay_mode(G) if (float(G.alpha) >= 1.0 and fake_latents_in.is_cuda and hasattr(G, '_flat_param')
                                and D.__dict__.get('_global_stddev') is None) else None
+    if mode == 'plan' and _exchange_instrumented(G):
+        mode = None
     if mode is not None:
         from . import graphs, plans
         g_cost = (graphs if mode == 'graph' else plans).g_step(G, D, engine._check_dev(fake_latents_in, 'latents'))

@@ -17,6 +17,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption('--repeat', type=int, default=1, help='run every selected test N times in this process (tools/loop_tests.sh)')
+
+
+def pytest_generate_tests(metafunc):
+    n = metafunc.config.getoption('repeat')
+    if n > 1:
+        metafunc.fixturenames.append('_repeat_i')
+        metafunc.parametrize('_repeat_i', range(n))
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -165,3 +165,61 @@ def test_exact_global_stddev_with_one_rank_equals_local_mode(dp, monkeypatch):
         assert float((got - ref).norm() / ref.norm()) < 1e-3, name
     assert_same_contributions(gr1[0][0], gr0[0][0])
     assert_same_contributions(gr1[0][1], gr0[0][1], tol=0.3, total=5e-2)
+
+
+def test_launch_plan_under_data_parallelism_matches_eager_twin(dp, monkeypatch):
+    """Round 6: ``Trainer(parallel=dp)`` no longer turns launch plans off when the data plane is the library's RCCL communicator -- the
+    bucket collectives the backward sweep feeds (``GradExchange._flush`` -> ``pg_allreduce_sum_f32`` on the exchange stream, behind an edge
+    from the weight-gradient stream) are recorded and replayed with the rest of the step; ``finish()`` (what is left + the join) stays eager
+    in the update.  A plan-issued data-parallel trainer against an eagerly issued twin at identical weights: per-iteration pre-Adam
+    gradients of D and G, the number of collectives and bytes per step (the host-side counters are put back from the recording), and
+    lock-step weights.  One rank: every collective is the identity, so any difference is an ordering defect."""
+    wl = pg.wgan_gp_loss
+    monkeypatch.setattr(pg.parallel, 'BUCKET_BYTES', 1 << 16)                    # small buckets: several collectives inside each sweep
+
+    def build():
+        torch.manual_seed(21)
+        shape = (1, 3, 32, 32)
+        kw = dict(fmap_base=512, fmap_max=64)
+        G = pg.Generator(shape, latent_size=64, **kw).cuda()
+        D = pg.Discriminator(shape, **kw).cuda()
+        G.depth = D.depth = 3
+        opt_g = pg.FusedAdam(G.parameters(), 0.001, betas=(0.0, 0.99))
+        opt_d = pg.FusedAdam(D.parameters(), 0.001, betas=(0.0, 0.99))
+        ds = pg.utils.SyntheticDataset(32, 3, seed=5)
+        ds.model_depth = 3
+        return pg.Trainer(D, G, pg.wgan_gp_D_loss, pg.wgan_gp_G_loss, opt_d, opt_g, ds, ds.loader(8), pg.utils.device_latents(8, 64, seed=3), parallel=dp)
+    wl.enable_graphs('auto')
+    wl.enable_plans(True)
+    pg.plans.STATS.update(recorded=0, replayed=0)
+    try:
+        tra, trb = build(), build()
+        assert wl._use_plans, 'Trainer(parallel=<RCCL data plane>) must leave launch plans on'
+        per_step = []
+        for it in range(7):
+            out = []
+            for tr, plans_on in ((tra, True), (trb, False)):
+                wl._use_plans = plans_on
+                wl.manual_seed(100 + it)
+                c0, b0 = dp.stats['collectives'], dp.stats['bytes']
+                tr.train()
+                torch.cuda.synchronize()
+                out.append((grads_by_name(tr.D), grads_by_name(tr.G), dp.stats['collectives'] - c0, dp.stats['bytes'] - b0))
+            assert_same_contributions(out[0][0], out[1][0])
+            assert_same_contributions(out[0][1], out[1][1], tol=0.3, total=5e-2)     # (through D after its update: sign-like Adam on round-off noise)
+            assert out[0][2:] == out[1][2:] and out[0][2] > 4, (it, out[0][2:], out[1][2:])   # same collectives / bytes, several buckets per step
+            per_step.append(out[0][2:])
+            for a, b in ((tra.G, trb.G), (tra.D, trb.D)):
+                assert float((a._flat_param - b._flat_param).abs().max()) <= 2 * 0.001 * ((1 - 0.99 ** (it + 1)) / 0.01) ** 0.5 + 1e-6
+                with torch.no_grad():
+                    b._flat_param.copy_(a._flat_param)
+                b.mark_params_changed()
+            for oa, ob in ((tra.optimizer_g, trb.optimizer_g), (tra.optimizer_d, trb.optimizer_d)):
+                for (_, ma, va), (_, mb_, vb) in zip(oa._flat.values(), ob._flat.values()):
+                    mb_.copy_(ma)
+                    vb.copy_(va)
+        assert len(set(per_step)) == 1, per_step                                  # eager warm-up, recording and replayed steps exchange the same
+        assert pg.plans.STATS['recorded'] == 2 and pg.plans.STATS['replayed'] == 2 * 4, pg.plans.STATS
+    finally:
+        wl._use_plans = True
+        wl.enable_graphs(False)

@@ -146,6 +146,8 @@ def test_thin1024_against_fp64(oracle, tag):
 
 @pytest.mark.parametrize('res,depth,alpha,n,C,fmap_base', [
     (128, 5, 1.0, 2, 3, 4096), (256, 6, 1.0, 2, 1, 4096), (128, 4, 0.5, 3, 3, 4096),
+    (32, 3, 1.0, 64, 3, 4096),         # BASELINE config 2: the 32x32 network at its full-width last stage, minibatch 64 (round 6: every BASELINE config has a case)
+    (32, 2, 0.5, 64, 3, 4096),         # ... and in the fade-in that leads there
     (1024, 8, 1.0, 3, 3, 4096),        # the BENCHMARKED network (BASELINE config 5): 1024^2 stage, minibatch 3, default widths
     (1024, 6, 1.0, 1, 3, 8192),        # the paper's widths (bench.py's fmap_base 8192 line), 256^2 stage of the 1024^2 network (one image: 25 s of fp64 oracle time per image)
     pytest.param(1024, 8, 1.0, 2, 3, 8192, marks=pytest.mark.skipif(os.environ.get('PGGAN_TEST_HEAVY', '') != '1', reason=(
