@@ -55,13 +55,44 @@ import torch  # noqa: E402
 MFMA_F32_PEAK = 157.3e12          # gfx950 f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 REF_MINIBATCH = {6: 14, 7: 6, 8: 3}          # reference plugins.py:19-20 (default 16)
 def _latest_profile_tag():
-    """profiles/<tag>_roofline.json of the newest round: the PMC pass the traffic / MFMA-busy figures are quoted from."""
+    """profiles/<tag>_roofline.json of the newest round: the PMC pass the traffic / MFMA-busy figures are quoted from.  A round may
+    commit several sets of the same workload from different boxes of the pool (``r06``, ``r06b``, ...: the counter figure's denominator is
+    kernel time x the NOMINAL clock, so a box that clocks lower reads lower): the line quotes the WORSE one -- the set whose
+    ``d_step_gp_window.mfma_busy_pct_all_kernels`` is smallest -- and lists every set's figure in ``d_step_gp.boxes``."""
     import glob
-    tags = sorted(os.path.basename(f)[:-len('_roofline.json')] for f in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_roofline.json')))
-    return tags[-1] if tags else 'none'
+    tags = sorted(os.path.basename(f)[:-len('_roofline.json')] for f in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]*_roofline.json'))
+                  if len(os.path.basename(f)) <= len('r00x_roofline.json'))
+    if not tags:
+        return 'none', {}
+    rnd = tags[-1][:3]
+    figures = {}
+    for t in tags:
+        if t[:3] != rnd:
+            continue
+        try:
+            with open(os.path.join(ROOT, 'profiles', t + '_roofline.json')) as f:
+                figures[t] = json.load(f).get('d_step_gp_window', {}).get('mfma_busy_pct_all_kernels')
+        except Exception:
+            figures[t] = None
+    known = {t: v for t, v in figures.items() if v is not None}
+    return (min(known, key=known.get) if known else rnd), figures
 
 
-PROFILE_TAG = _latest_profile_tag()
+PROFILE_TAG, PROFILE_BOXES = _latest_profile_tag()
+
+
+def _rocprof_avg_us(symbol):
+    """Average duration (us) of a conv symbol in profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command)."""
+    import csv
+    try:
+        with open(os.path.join(ROOT, 'profiles', PROFILE_TAG + '_kernel_stats.csv')) as f:
+            for row in csv.DictReader(f):
+                name = row['Name']
+                if symbol in name and name.split(symbol, 1)[1][:1] in ('(', ''):
+                    return float(row['AverageNs']) / 1e3
+    except Exception:
+        pass
+    return None
 
 
 def forward_flops(G, D, depth, alpha):
@@ -559,14 +590,15 @@ def compact_line(out, detail_path=None):
     if roof:
         line['roofline'] = _pick(roof, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'algorithmic_frac'))
         line['roofline']['traffic'] = _r(roof.get('traffic'))                        # (null = no PMC pass to quote)
-        line['roofline'].update(_pick(roof, ('traffic_source', 'mfma_busy_pct', 'valu_per_mfma', 'avg_launch_us', 'event_pair_us_subtracted', 'launches_per_step',
-                                             'ms_per_step_in_kernel')))
+        line['roofline'].update(_pick(roof, ('traffic_source', 'mfma_busy_pct', 'valu_per_mfma', 'avg_launch_us', 'event_pair_us_subtracted', 'avg_launch_us_rocprof',
+                                             'frac_rocprof', 'launches_per_step', 'ms_per_step_in_kernel')))
     cpu = out.get('cpu_baseline')
     line['cpu_baseline'] = _pick(cpu, ('value', 'unit', 'cores', 'kind', 'sample', 'measured_at_n_gpus')) if cpu else None
     dwin = out.get('d_step_gp_counters') or {}
     d = {'ms': _r(out.get('d_step_gp_ms')), 'executed_frac': _r(out.get('d_step_gp_executed_mfma_frac')),
          'mfma_busy_pct_conv': _r(dwin.get('mfma_busy_pct_conv_kernels', out.get('d_step_gp_mfma_busy_pct'))),
-         'mfma_busy_pct_all': _r(dwin.get('mfma_busy_pct_all_kernels')), 'counter_source': dwin.get('source_short')}
+         'mfma_busy_pct_all': _r(dwin.get('mfma_busy_pct_all_kernels')), 'mfma_busy_wall_pct_hybrid': _r(dwin.get('mfma_busy_wall_pct')),
+         'counter_source': dwin.get('source_short'), 'boxes': {k: _r(v) for k, v in (dwin.get('boxes') or {}).items()} or None}
     line['d_step_gp'] = {k: v for k, v in d.items() if v is not None}
     line.update(_pick(out, ('executed_mfma_frac', 'mfma_busy_pct', 'step_issue', 'rccl_ranks', 'allreduce_ms', 'allreduce_bytes_per_step',
                             'exposed_exchange_ms', 'ms_per_step_without_exchange')))
@@ -759,6 +791,9 @@ def main():
             prof, src = None, None
         if prof is not None and dom in prof:
             traffic = prof[dom]['hbm_bytes_per_launch']
+        # rocprofv3's in-step average duration of the same symbol from the committed kernel trace of this round (the live
+        # HIP-event bracket also holds the dispatch latency behind a busy second queue and under-reads ``frac`` by 4-8 %)
+        rocprof_us = _rocprof_avg_us(dom)
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['exec_tflops'], 'peak': MFMA_F32_PEAK / 1e12,
                            'unit': 'TFLOP/s', 'frac': d['exec_tflops'] * 1e12 / MFMA_F32_PEAK,
                            'frac_is': 'MFMA FLOP the launches EXECUTE (Winograd F(2x2,3x3): 16/36 of the algorithmic 2*MAC count) / HIP-event time / nominal peak',
@@ -768,6 +803,11 @@ def main():
                            'mfma_busy_pct': prof[dom]['mfma_busy_pct'] if prof and dom in prof else None,
                            'valu_per_mfma': prof[dom].get('valu_per_mfma') if prof and dom in prof else None,
                            'avg_launch_us': d['avg_launch_us'], 'launches_per_step': d['launches_per_step'], 'event_pair_us_subtracted': 1e3 * kt.pair_ms,
+                           'avg_launch_us_raw': d['avg_launch_us'] + 1e3 * kt.pair_ms,      # before the calibrated event-pair overhead is taken off
+                           'frac_raw_events': d['exec_tflops'] * 1e12 / MFMA_F32_PEAK * d['avg_launch_us'] / (d['avg_launch_us'] + 1e3 * kt.pair_ms),
+                           'avg_launch_us_rocprof': rocprof_us,
+                           'frac_rocprof': (d['exec_tflops'] * 1e12 / MFMA_F32_PEAK * d['avg_launch_us'] / rocprof_us) if rocprof_us else None,
+                           'frac_rocprof_is': 'this run\'s executed FLOP per launch / the in-step average duration of the symbol in profiles/%s_kernel_stats.csv (rocprofv3 --kernel-trace of the same command, builder-side box)' % PROFILE_TAG,
                            'ms_per_step_in_kernel': d['ms_per_step'],
                            'algorithmic_gflop_per_step': d['flops_per_step'] / 1e9}
         tot_ms = sum(v['ms'] for v in fam.values())
@@ -807,7 +847,15 @@ def main():
         except Exception:
             dwin = None
         if dwin:
-            out['d_step_gp_counters'] = dict(dwin, source=src + ' (rocprofv3 --pmc pass of bench.py --d-step-only: every kernel of the window)', source_short=src)
+            out['d_step_gp_counters'] = dict(dwin, source=src + ' (rocprofv3 --pmc pass of bench.py --d-step-only: every kernel of the window)', source_short=src,
+                                             boxes={t: v for t, v in PROFILE_BOXES.items() if v is not None})
+            if d_gp_ms and dwin.get('kernel_time_ms_per_pass') and dwin.get('mfma_busy_pct_all_kernels') is not None:
+                # HYBRID, labelled as such: MFMA-busy cycles of the window summed in the SERIALISED counter pass / (THIS run's
+                # un-serialised wall time of the window x nominal clock x SIMDs) -- the share of the window's wall time the matrix pipes are
+                # busy when the two streams overlap.  The strict figure is mfma_busy_pct_all (busy cycles / serialised kernel time).
+                out['d_step_gp_counters']['mfma_busy_wall_pct'] = dwin['kernel_time_ms_per_pass'] * dwin['mfma_busy_pct_all_kernels'] / d_gp_ms
+                out['d_step_gp_counters']['mfma_busy_wall_is'] = ('hybrid: busy cycles of the serialised --pmc pass (' + src + ') / this run\'s '
+                                                                  'un-serialised D+GP wall time; not a counter figure of one run')
         out['kernels'] = {k: {'tflops': v['tflops'], 'executed_tflops': v['exec_tflops'], 'ms_per_step': v['ms_per_step'],
                               'launches_per_step': v['launches_per_step'], 'avg_launch_us': v['avg_launch_us']}
                           for k, v in fam.items()}

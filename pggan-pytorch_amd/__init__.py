@@ -8,7 +8,7 @@ from . import _lib, ops, engine, network, wgan_gp_loss, trainer, plugins, optim,
 from .network import Generator, Discriminator, PGConv2d  # noqa: F401
 from .wgan_gp_loss import wgan_gp_D_loss, wgan_gp_G_loss  # noqa: F401
 from .trainer import Trainer  # noqa: F401
-from .plugins import (Plugin, DepthManager, LRScheduler, RampupLR, TimeMonitor, SaverPlugin, OutputGenerator,  # noqa: F401
+from .plugins import (Plugin, DepthManager, LRScheduler, RampupLR, TimeMonitor, AbsoluteTimeMonitor, SaverPlugin, OutputGenerator,  # noqa: F401
                       load_models, load_trainer_state)
 from .optim import FusedAdam  # noqa: F401
 from .parallel import DataParallel  # noqa: F401
@@ -16,5 +16,5 @@ from .sound import SoundSaver, spectrogram_u8  # noqa: F401
 from ._lib import PgganLibraryError, LIB_PATH  # noqa: F401
 
 __all__ = ['Generator', 'Discriminator', 'PGConv2d', 'wgan_gp_D_loss', 'wgan_gp_G_loss', 'Trainer', 'Plugin',
-           'DepthManager', 'LRScheduler', 'RampupLR', 'TimeMonitor', 'SaverPlugin', 'OutputGenerator', 'load_models',
+           'DepthManager', 'LRScheduler', 'RampupLR', 'TimeMonitor', 'AbsoluteTimeMonitor', 'SaverPlugin', 'OutputGenerator', 'load_models',
            'load_trainer_state', 'FusedAdam', 'DataParallel', 'SoundSaver', 'spectrogram_u8']

@@ -487,7 +487,36 @@ def _wino_wgrad_ok(layer, Hin):
             and min(layer._gw.shape[2], layer._gw.shape[3]) >= WINO_WGRAD_MIN_CHANNELS)
 
 
-def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False, defer=False):
+# The weight gradients of the entry (finest) block are the last and largest launches of the batched sweep: when the main stream finishes
+# the sweep the second stream still has ~0.4 ms of them queued (tools/phase_timeline.py: D.wgrad_end - D.sweep_end at 1024^2), and with the
+# G step's generator pass already done (EarlyG) the main stream has nothing to run until D's update is through.  The last
+# TAIL_WGRAD_ON_MAIN of them (fromRGB, c1, c2 of the entry block, in that order of preference) are therefore launched on the main stream;
+# the deferred update is ordered behind both streams (defer_to_side).  Not under a bucketed gradient exchange (its flushes wait for the
+# second stream only).
+# Same-box runs with the early generator pass on, ms per step, 0 | 1 | 2 launches on the main stream: 1024^2 10.182 | 10.135 | 10.134 and
+# 10.185 | 10.118 | 10.076; 512^2 13.322 | 13.288 | 13.384.  Default (-1): 2 at 1024^2, 1 at 512^2, none below (the 16-image stages keep both
+# streams busy to the end).
+TAIL_WGRAD_ON_MAIN = int(os.environ.get('PGGAN_TAIL_WGRAD_MAIN', '-1'))
+
+
+def _tail_wgrad_on_main(H):
+    if TAIL_WGRAD_ON_MAIN >= 0:
+        return TAIL_WGRAD_ON_MAIN
+    return 2 if H >= 1024 else 1 if H >= 512 else 0
+
+
+class _on_main(object):
+    def __init__(self, *tensors):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False, defer=False, on_main=False):
     """Weight (and bias) gradient of one conv layer on the side stream.  The wide 3x3 layers take the Winograd form
     (2.25x fewer MFMAs, 1.3-1.7x faster from 16x16 up, 16-channel sides included); the 8-channel layers and the
     4x4 / 8x8 maps keep the direct kernels.  ``defer``: a bias-free contribution that a later ``_wgrad`` of the same layer
@@ -501,7 +530,7 @@ def _wgrad(x, gz, layer, N, Hin, bias=True, ups=False, defer=False):
         _flush_wgrad(layer)
         pend = None
     layer._pending_wgrad = None
-    with _on_side(x, gz, *(pend[:2] if pend is not None else ())):
+    with (_on_main if on_main else _on_side)(x, gz, *(pend[:2] if pend is not None else ())):
         if wino:
             ops.conv2d_wgrad_wino(x, gz, layer._gw, layer._gb if bias else None, N, Hin, Hin, layer.c, ups=ups,
                                   second=(pend[0], pend[1], pend[2], False) if pend is not None else None)
@@ -675,6 +704,11 @@ def _mbstd_fwd(D, x, groups, cp):
     dp = _mb_dp(D)
     if dp is None:
         return ops.mbstd_fwd(x, groups, cp)
+    # the split kernels take the element count of the whole group as local count x ranks (csrc/elementwise.hip mbstd_write_kernel):
+    # equal per-rank batches are part of the mode's contract -- checked here, once per batch shape (it was only claimed)
+    if D.__dict__.get('_gs_checked') != (int(x.shape[0]), groups):
+        dp.assert_same_on_all_ranks(int(x.shape[0]) // groups, 'exact-global minibatch stddev: the per-rank minibatch size')
+        D._gs_checked = (int(x.shape[0]), groups)
     st = ops.mbstd_stats(x, groups)
     return ops.mbstd_write(x, st, dp.all_gather_rows(st), cp)
 
@@ -900,6 +934,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
     nh = NB if hvp is None else hvp[0]
     a2 = lastrec['a2']
     lc2 = lastrec['blk'].c2
+    tail = _tail_wgrad_on_main(recs[0]['H']) if (full and ASYNC_WGRAD and getattr(D, '_grad_hook', None) is None and len(recs) > 1) else 0
     if full:
         ops.linear1_wgrad(gscore, a2[:nh], D._lin_gw, D._lin_gb)
     g = ops.linear1_bwd_data(gscore, D.linear.weight.data, a2[:nh], (nh,) + tuple(a2.shape[1:]), lc2.slope)
@@ -942,7 +977,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                                               mask=rec.get('a1b') if rec.get('a1b') is not None else rec['a1'], mask_slope=c1.slope)
                     if full:
                         _flush_wgrad(c2)           # (this launch does not go through _wgrad: a deferred tangent term rides nowhere)
-                        with _on_side(rec['a1'], gc, gb):
+                        with (_on_main if rec['first'] and tail >= 3 else _on_side)(rec['a1'], gc, gb):
                             ops.conv2d_wgrad_unpooled(rec['a1'], gc, gb, gmul, gsl, c2._gw, c2._gb, NB, H, H, c2.c)
                 except ops.Unsupported:                    # (shape checks are identical for both entry points: nothing was accumulated)
                     FALLBACKS['lazy unpool %dx%d' % (H, H)] += 1
@@ -955,7 +990,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                     _wgrad(rec['a1'], gz2, c2, NB, H)
                 gz1 = _dgrad(D, gz2, c2, NB, H, mask=(rec['a1'], rec.get('a1b')), mask_slope=c1.slope)
             if full:
-                _wgrad(rec['inp'], gz1, c1, NB, H)
+                _wgrad(rec['inp'], gz1, c1, NB, H, on_main=rec['first'] and tail >= 2)
             g_fused = None
             if not rec['first'] and not (recs[idx - 1]['first'] and alpha < 1.0):
                 pv = recs[idx - 1]
@@ -978,7 +1013,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             if save_adjoints:
                 adj[idx]['gf'] = gf
             if full:
-                with _on_side(gf, x):
+                with (_on_main if tail >= 1 else _on_side)(gf, x):
                     ops.fromrgb_wgrad(gf, x, fr._gw, fr._gb, NB, C, H, H, fr.c)
             if want_gimg:
                 gimg = torch.empty_like(x)
@@ -1298,6 +1333,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
                     s_f, ctx_f = d_forward(D, x3[N:2 * N], groups=1)          # :54
                 fake_done = torch.cuda.Event()
                 _record_event(fake_done, side)
+            _early_g_on_side(D, main, side)
             with early.arena.pass_(3):
                 s_m, ctx_m = d_forward(D, x3[2 * N:], groups=1)               # :20
             ctx = _merge_ctx(D, early.ctx, ctx_f, x3, N, third=ctx_m)
@@ -1338,6 +1374,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
             fake_done = torch.cuda.Event()
             _record_event(fake_done, side)
             probe('D.fake_end')
+        _early_g_on_side(D, main, side)
         _wait_event(main, real_copied)
         ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
         probe('D.mix_end')
@@ -1398,6 +1435,72 @@ def take_early_real(D, real):
     return st
 
 
+# ---- the G step's generator forward, ahead of time -------------------------------------------------------------------------------------
+# The un-traced phase timeline of the 1024^2 step (tools/phase_timeline.py, round 6) shows the main stream busy from the first launch to the
+# last -- it IS the critical path -- while the second stream idles under the gradient penalty's first backward and the tangent pass (1.6 ms
+# of 3-image launches: the weight gradients of the tangent pass ride in the sweep's launches) and again under the whole first half of the G
+# step.  The G step opens with G(z') on fresh latents (trainer.py:103-105) with the SAME generator weights the D step used (G is updated at the
+# end of the G step only), so that pass does not have to wait for anything the D step computes: Trainer hands the latents to the D step
+# (``request_early_g``), the D step enqueues G(z') -- with its activations kept for the backward -- on the second stream behind the fake
+# third, and the G step starts from the finished pass with D's forward.  Same kernels, same inputs, same results; PGGAN_EARLY_G=0 turns it off.
+# Same-box pairs, ms per step off | on (round 6): 1024^2 10.344 | 10.263, 10.358 | 10.242, 10.363 | 10.219; 512^2 13.52 | 13.39, 13.53 | 13.37;
+# 256^2 23.04 | 22.83; 64^2 (minibatch 16: the chip is full) 14.54 | 14.66; 16^2 5.25 | 5.34 -- on from 256^2 up (the stages whose minibatch
+# leaves the chip partly idle); PGGAN_EARLY_G=0 off, =2 at every stage.
+EARLY_G_FORWARD = os.environ.get('PGGAN_EARLY_G', '1') != '0'
+EARLY_G_MIN_RES = 4 if os.environ.get('PGGAN_EARLY_G', '1') == '2' else int(os.environ.get('PGGAN_EARLY_G_MIN_RES', '256'))
+EARLY_G_STATS = {'passes': 0, 'used': 0, 'dropped': 0}
+
+
+class EarlyG(object):
+    """A finished (enqueued) ``generator_forward(G, latents, save=True)``: output image, context, the latents tensor it was computed from
+    (identity: what the G loss will be handed), what it was computed with, and the event that closes it on the second stream."""
+    __slots__ = ('fake', 'ctx', 'latents', 'stamp', 'event')
+
+
+def request_early_g(D, G, latents):
+    """Trainer, before the D loss: the next G loss of this iteration will be ``wgan_gp_G_loss(G, D, latents)``."""
+    D._early_g_request = (G, latents)
+
+
+def _early_g_on_side(D, main, side):
+    """Inside ``d_loss_forward``, right after the fake third was queued on the second stream: the requested generator pass behind it."""
+    req = D.__dict__.pop('_early_g_request', None)
+    if req is None or not EARLY_G_FORWARD or 4 * 2 ** int(req[0].depth) < EARLY_G_MIN_RES:
+        return
+    G, z = req
+    z = _check_dev(z, 'latents')
+    with torch.cuda.stream(side):
+        probe('D.early_g_start')
+        eg = EarlyG()
+        eg.fake, eg.ctx = generator_forward(G, z, save=True)
+        eg.event = torch.cuda.Event()
+        _record_event(eg.event, side)
+        probe('D.early_g_end')
+    # allocated under the second stream's context, consumed (and eventually freed) on the main stream
+    for t in [eg.fake, eg.ctx['zn'], eg.ctx['y1'], eg.ctx['y2'], eg.ctx.get('r1'), eg.ctx.get('r2')] + \
+            [r[k] for r in eg.ctx['recs'] for k in ('a1', 'a2', 'r1', 'r2')]:
+        if torch.is_tensor(t):
+            t.record_stream(main)
+    eg.latents = z
+    eg.stamp = (G._param_version, int(G.depth), float(G.alpha))
+    G._early_fwd = eg
+    EARLY_G_STATS['passes'] += 1
+
+
+def take_early_g(G, latents):
+    """The generator pass the D step left for exactly these latents, if it is still valid (same tensor, same weights, same stage); the
+    current stream is ordered behind it.  None: the caller runs the pass itself."""
+    eg = G.__dict__.pop('_early_fwd', None)
+    if eg is None:
+        return None
+    if eg.latents is not latents or eg.stamp != (G._param_version, int(G.depth), float(G.alpha)):
+        EARLY_G_STATS['dropped'] += 1
+        return None
+    _wait_event(torch.cuda.current_stream(torch._C._cuda_getDevice()), eg.event)
+    EARLY_G_STATS['used'] += 1
+    return eg
+
+
 def d_loss_backward(state, scale=1.0):
     """``D_cost.backward()`` (trainer.py:98): tangent pass + batched [real|fake|mixed] adjoint sweep."""
     D, ctx, N = state['D'], state['ctx'], state['N']
@@ -1439,7 +1542,11 @@ def g_loss_forward(G, D, latents):
     D._sync_version()
     G._sync_version()
     probe('G.start')
-    fake, gctx = generator_forward(G, latents, save=True)
+    eg = take_early_g(G, latents)
+    if eg is not None:
+        fake, gctx = eg.fake, eg.ctx
+    else:
+        fake, gctx = generator_forward(G, latents, save=True)
     probe('G.g_fwd_end')
     s, dctx = d_forward(D, fake, 1)
     g_cost, gscore = ops.g_loss(s)

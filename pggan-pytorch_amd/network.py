@@ -305,8 +305,10 @@ class _FlatParamsMixin(object):
         d['_lin_gw'] = d['_lin_gb'] = d['_lin_layer'] = None
         d['_grad_hook'] = d['_grad_exchange'] = None
         d['_global_stddev'] = None               # (a process-group handle: a reloaded network starts in the local-shard mode)
+        d['_gs_checked'] = None
         d['_plan_unjoined'] = False
         d['_early_real'] = d['_early_buffers'] = None      # (device buffers / events of the real-third pass: rebuilt on demand)
+        d['_early_fwd'] = d['_early_g_request'] = None     # (a generator pass left for the G step / the request for one: engine.EarlyG)
         d['_plist'] = None
         d['_layer_list'] = None
         d['_derived_bwd_ev'] = None

@@ -208,6 +208,15 @@ class DataParallel(object):
     def barrier(self):
         dist.barrier()
 
+    def assert_same_on_all_ranks(self, value, what):
+        """Control plane: raises on every rank unless all ranks hold the same integer (one MAX all-reduce of (v, -v))."""
+        dev = 'cuda' if (dist.get_backend() == 'nccl' and torch.cuda.is_available()) else 'cpu'
+        t = torch.tensor([int(value), -int(value)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hi, lo = int(t[0]), -int(t[1])
+        if hi != lo:
+            raise RuntimeError('%s differs between the ranks (%d .. %d; rank %d has %d)' % (what, lo, hi, self.rank, int(value)))
+
 
 class GradExchange(object):
     """Bucketed, overlapped exchange of one network's gradients during its backward sweep.

@@ -40,6 +40,7 @@ class _Plan(object):
         self.static_in = None
         self.static_out = None
         self.dp_state = None         # (GradExchange snapshot, collectives, bytes) of the recorded step under data parallelism
+        self.early_g = None          # engine.EarlyG the recorded D step leaves for the G step (its tensors are rewritten by every replay)
         self.warm = 0
 
 
@@ -205,14 +206,22 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
         early = D.__dict__.pop('_early_real') and None
         engine.EARLY_STATS['dropped'] += 1
     dp_tag, ex = _dp_tag(D)
+    # the G step's generator pass rides in this step on the second stream (engine.request_early_g): its latents are a fourth static input
+    req = D.__dict__.get('_early_g_request') if engine.EARLY_G_FORWARD else None
+    if req is None:
+        D.__dict__.pop('_early_g_request', None)
+    zg = engine._check_dev(req[1], 'latents') if req is not None else None
     key = ('D', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(D.depth), tuple(real.shape), tuple(latents.shape), float(lam), float(eps), float(target),
-           id(early.arena) if early is not None else 0, dp_tag)
+           id(early.arena) if early is not None else 0, dp_tag, (req[0]._flat_param.data_ptr(), tuple(zg.shape)) if req is not None else 0)
     g = _CACHE.get(key)
     if g is None:
         g = _new_plan(key)
-        g.static_in = (torch.empty_like(real), torch.empty_like(latents), torch.empty_like(mix))
+        g.static_in = (torch.empty_like(real), torch.empty_like(latents), torch.empty_like(mix)) + ((torch.empty_like(zg),) if req is not None else ())
     else:
         _CACHE.move_to_end(key)
+    if req is not None:
+        g.static_in[3].copy_(zg)
+        D._early_g_request = (req[0], g.static_in[3])
     for dst, src in zip(g.static_in, (real, latents, mix)) if early is None else zip(g.static_in[1:], (latents, mix)):
         dst.copy_(src)
     if early is not None:
@@ -238,17 +247,31 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
     if D.__dict__.get('_plan_unjoined', False):     # a step whose loss never had backward() called: its weight gradients may still be in flight
         engine._join_side()
     D._plan_unjoined = True
+
+    def early_g_handover(eg):
+        # what the body (or the replay) left for the G step is keyed to the CALLER's latents tensor, not to the static copy
+        D.__dict__.pop('_early_g_request', None)         # (a body without a second-stream pass does not take the request)
+        if req is not None and eg is not None:
+            eg.latents = zg
+            eg.stamp = (req[0]._param_version, int(req[0].depth), float(req[0].alpha))
+            req[0]._early_fwd = eg
     if g.entries is None:
         if g.warm < 2:                       # eager warm-up (kernel attributes, first-request derived copies, allocator pools)
             g.warm += 1
-            return body()
+            out = body()
+            early_g_handover(req[0].__dict__.get('_early_fwd') if req is not None else None)
+            return out
         before = _dp_begin(ex)
         with _Recorder(g):
             g.static_out = body()
         _dp_recorded(g, ex, before)
+        g.early_g = req[0].__dict__.get('_early_fwd') if req is not None else None
     else:
         _replay(g)
         _dp_replayed(g, ex)
+        if g.early_g is not None:
+            engine.EARLY_G_STATS['passes'] += 1
+    early_g_handover(g.early_g)
     engine._assign_grads(D, engine.d_active_params(D, int(D.depth), 1.0), linear=True)
     # the static outputs are overwritten by the next replay: hand out copies (a plugin may keep loss tensors) -- one device copy when
     # they are views of one buffer (ops.d_loss)
@@ -262,14 +285,28 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
 def g_step(G, D, latents):
     """Plan-replayed ``g_loss_forward`` + ``g_loss_backward``.  Returns g_cost."""
     dp_tag, ex = _dp_tag(G)
-    key = ('G', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(G.depth), tuple(latents.shape), dp_tag)
+    # the generator pass may already be through (engine.EarlyG, left by the D step for exactly these latents): a plan of its own, whose
+    # body starts from that pass's tensors -- stable addresses: the D step's plan rewrites them at every replay
+    eg = G.__dict__.get('_early_fwd')
+    if eg is not None and not (eg.latents is latents and eg.stamp == (G._param_version, int(G.depth), float(G.alpha))):
+        eg = G.__dict__.pop('_early_fwd') and None
+        engine.EARLY_G_STATS['dropped'] += 1
+    key = ('G', D._flat_param.data_ptr(), G._flat_param.data_ptr(), int(G.depth), tuple(latents.shape), dp_tag, eg is not None)
     g = _CACHE.get(key)
     if g is None:
         g = _new_plan(key)
         g.static_in = (torch.empty_like(latents),)
     else:
         _CACHE.move_to_end(key)
+        if g.entries is not None and eg is not None and g.early_g is not eg.ctx:
+            # recorded against the tensors of another generator pass (the D step's plan was re-recorded): record again, now
+            g.entries, g.keep, g.warm = None, {}, 2
     g.static_in[0].copy_(latents)
+    if eg is not None:
+        eg.latents = g.static_in[0]          # (what the body hands to g_loss_forward; identity is all take_early_g compares)
+        if g.entries is not None:            # replay: the wait on the pass's event is one of the recorded entries
+            G.__dict__.pop('_early_fwd', None)
+            engine.EARLY_G_STATS['used'] += 1
     if getattr(D, '_pending', None) is None:  # (a deferred D update refreshes D's derived weights itself, on the second stream)
         _prologue(D)
     _prologue(G)
@@ -283,6 +320,7 @@ def g_step(G, D, latents):
             g.warm += 1
             return body()[0]
         before = _dp_begin(ex)
+        g.early_g = eg.ctx if eg is not None else None     # (the D plan's replays rewrite these very tensors)
         with _Recorder(g):
             g.static_out = body()
         _dp_recorded(g, ex, before)

@@ -189,6 +189,9 @@ class TimeMonitor(Plugin):
             del probe['pairs'][:]
 
 
+AbsoluteTimeMonitor = TimeMonitor      # the reference's name (plugins.py:114; train.py: ``AbsoluteTimeMonitor(params['resume_time'])``): drop-in
+
+
 class SaverPlugin(Plugin):
     """Network snapshots with the reference's file names and whole-module pickles (plugins.py:142-174):
     ``network-snapshot-{generator|discriminator}-{kimg:06}.dat`` every ``network_snapshot_ticks`` ticks and at

@@ -269,6 +269,14 @@ class Trainer(object):
         return (self.G_loss is wgan_gp_loss.wgan_gp_G_loss and hasattr(self.D, '_flat_param')
                 and not wgan_gp_loss._graphs_on(self.D) and not wgan_gp_loss._graphs_on(self.G))
 
+    def _early_g_ok(self):
+        """May the generator pass that opens the G step run inside the D step (second stream, engine.request_early_g)?  The product's G loss
+        (it is what picks the pass up), both networks on the device with flat buffers, two streams, no hipGraph capture of either step."""
+        from . import wgan_gp_loss
+        return (engine.EARLY_G_FORWARD and 4 * 2 ** int(self.G.depth) >= engine.EARLY_G_MIN_RES and engine.ASYNC_WGRAD and self.G_loss is wgan_gp_loss.wgan_gp_G_loss
+                and hasattr(self.D, '_flat_param') and hasattr(self.G, '_flat_param') and self.G._flat_param.is_cuda
+                and not wgan_gp_loss._graphs_on(self.D) and not wgan_gp_loss._graphs_on(self.G))
+
     def _draw_reals(self):
         reals = self._inputs.take(self.dataiter)                                  # :92
         if self.input_transform is not None:
@@ -321,11 +329,20 @@ class Trainer(object):
             # (the exchange is opened BEFORE the loss call: a plan-replayed loss has its backward sweep -- and the bucket collectives the
             #  sweep feeds -- inside that call; an eager forward never reports a finished block)
             self._open_exchange(self.D, engine.d_exchange_layers)
+            z_g = None
+            if last and self._early_g_ok():
+                # the latents of the G step, drawn now (the same position in the generator's sequence as trainer.py:103: nothing else is
+                # drawn in between) so that G(z_g) can run on the second stream inside the D step (engine.request_early_g)
+                z_g = _to_device(self.random_latents_generator())                 # :103
+                if getattr(z_g, 'is_cuda', False):
+                    engine.request_early_g(self.D, self.G, z_g)
             try:
                 d_losses = _as_tuple(self.D_loss(self.D, self.G, reals, latents)) # :95
             except BaseException:
                 self.D._grad_hook = None
                 raise
+            finally:
+                self.D.__dict__.pop('_early_g_request', None)                     # (a D loss that never reached the engine's second-stream pass)
             defer = last and self._can_overlap_d_update()
             self.D._skip_join = defer                # the update runs on the second stream, behind the weight gradients
             try:
@@ -349,7 +366,7 @@ class Trainer(object):
             else:
                 engine._join_side()                  # (a replayed plan leaves the weight gradients un-joined; a second join is free)
                 self._d_update()
-            latents = _to_device(self.random_latents_generator())                 # :103
+            latents = z_g if z_g is not None else _to_device(self.random_latents_generator())     # :103
         self._open_exchange(self.G, engine.g_exchange_layers)
         try:
             g_losses = _as_tuple(self.G_loss(self.G, self.D, latents))            # :105-110
@@ -362,6 +379,8 @@ class Trainer(object):
             engine._derived(self.G)                  # (the next generator pass needs them first thing; never part of a replayed plan)
             engine.probe('G.update_end')
         engine.wait_pending(self.D)                  # (a G_loss that never ran D: nothing may outlive the iteration)
+        if getattr(self.G, '__dict__', {}).pop('_early_fwd', None) is not None:   # (... nor a generator pass nobody took)
+            engine.EARLY_G_STATS['dropped'] += 1
         self.iterations += 1
         self.call_plugins('iteration', self.iterations, *(g_losses + d_losses))   # :115
         if self.prefetch_inputs and self._inputs.stream is not None and self.dataiter is not None:

@@ -167,7 +167,7 @@ def test_exact_global_stddev_with_one_rank_equals_local_mode(dp, monkeypatch):
     assert_same_contributions(gr1[0][1], gr0[0][1], tol=0.3, total=5e-2)
 
 
-def test_launch_plan_under_data_parallelism_matches_eager_twin(dp, monkeypatch):
+def test_launch_plan_under_data_parallelism_matches_eager_twin(dp, monkeypatch, deterministic_forward):
     """Round 6: ``Trainer(parallel=dp)`` no longer turns launch plans off when the data plane is the library's RCCL communicator -- the
     bucket collectives the backward sweep feeds (``GradExchange._flush`` -> ``pg_allreduce_sum_f32`` on the exchange stream, behind an edge
     from the weight-gradient stream) are recorded and replayed with the rest of the step; ``finish()`` (what is left + the join) stays eager
@@ -205,7 +205,7 @@ def test_launch_plan_under_data_parallelism_matches_eager_twin(dp, monkeypatch):
                 tr.train()
                 torch.cuda.synchronize()
                 out.append((grads_by_name(tr.D), grads_by_name(tr.G), dp.stats['collectives'] - c0, dp.stats['bytes'] - b0))
-            assert_same_contributions(out[0][0], out[1][0])
+            assert_same_contributions(out[0][0], out[1][0], tol=1e-2, total=2e-4)    # (deterministic_forward: the atomic commit order of the weight gradients only)
             assert_same_contributions(out[0][1], out[1][1], tol=0.3, total=5e-2)     # (through D after its update: sign-like Adam on round-off noise)
             assert out[0][2:] == out[1][2:] and out[0][2] > 4, (it, out[0][2:], out[1][2:])   # same collectives / bytes, several buckets per step
             per_step.append(out[0][2:])

@@ -289,6 +289,13 @@ def _global_stddev_worker(rank, world, port, out_path, depth, alpha):
     pg.trainer._to_device = lambda t: t
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dp = pg.DataParallel()
+    # the mode's contract -- equal per-rank minibatches -- is checked through the control plane (engine._mbstd_fwd, once per shape)
+    dp.assert_same_on_all_ranks(7, 'a value every rank agrees on')
+    try:
+        dp.assert_same_on_all_ranks(3 + rank, 'a value the ranks disagree on')
+        raise AssertionError('unequal values went unnoticed')
+    except RuntimeError as exc:
+        assert 'differs between the ranks' in str(exc)
     torch.manual_seed(31)
     shape = (1, 3, 16, 16)
     kw = dict(fmap_base=64, fmap_max=16)

@@ -61,6 +61,8 @@ def main():
     print('second stream, D step: starts %.0f | real third until %.0f | fake third %.0f -> %.0f | weight gradients done %.0f | update done %.0f'
           % (t.get('D.side_start', float('nan')), t.get('D.real_end', float('nan')), t.get('D.fake_start', float('nan')), t.get('D.fake_end', float('nan')),
              t.get('D.wgrad_end', float('nan')), t.get('D.update_end', float('nan'))))
+    if 'D.early_g_start' in t:
+        print('second stream, G step\'s generator pass inside the D step: %.0f -> %.0f' % (t['D.early_g_start'], t['D.early_g_end']))
     print('main stream, G step: hand-over %.0f | G fwd %.0f | D fwd %.0f | D bwd %.0f | G bwd %.0f | (wgrad done at %.0f, update done %.0f)'
           % (d('D.sweep_end', 'G.start'), d('G.start', 'G.g_fwd_end'), d('G.g_fwd_end', 'G.d_fwd_end'), d('G.d_fwd_end', 'G.d_bwd_end'),
              d('G.d_bwd_end', 'G.g_bwd_end'), t.get('G.wgrad_end', float('nan')), t.get('G.update_end', float('nan'))))
