@@ -100,7 +100,15 @@ def _derived(net):
             ops.wino_transform_weights_batched(net._flat_param if WTU_FROM_PARAM else net._flat_wt, net._flat_wtu,
                                                [(woff, uoff, m.conv.weight.shape[3], m.conv.weight.shape[2]) for m, woff, uoff in wl],
                                                transposed=WTU_FROM_PARAM)
-    one_launch = DERIVED_ONE_LAUNCH and WTU_FROM_PARAM and bool(wl) and net.__dict__.get('_bwd_wanted', False)
+    dev = torch.cuda.current_device() if net._flat_param.is_cuda else None
+    cur = torch.cuda.current_stream(torch._C._cuda_getDevice()) if dev is not None else None
+    capturing = dev is not None and torch.cuda.is_current_stream_capturing()
+    # Inside a deferred update (defer_to_side: Adam + this refresh on the second stream while the main stream waits for D's weights -- since
+    # round 6's early generator pass that wait is exposed, tools/phase_timeline.py) the forward forms go first and close the update for
+    # the waiting stream (``_pending`` = the event behind them); the backward-data forms and the flipped copies follow behind that event and
+    # are picked up through ``_await_backward_copies`` by their first reader, a forward pass later.
+    split = (SPLIT_DEFERRED_DERIVE and bool(net.__dict__.get('_defer_active')) and dev is not None and cur == _SIDE.get(dev) and not capturing)
+    one_launch = DERIVED_ONE_LAUNCH and WTU_FROM_PARAM and bool(wl) and net.__dict__.get('_bwd_wanted', False) and not split
     if one_launch:
         # forward AND backward-data Winograd forms in one launch on this stream (the two forms share a buffer, network._flat_wuu): the
         # parameter is read while it is hot, no second launch, no cross-stream hop for it at the iteration boundary
@@ -118,13 +126,24 @@ def _derived(net):
     # the weight-gradient stream, unless this already IS that stream (the deferred D update) or a hipGraph is being captured.
     # A network that has never run a backward sweep (an EMA / evaluation copy) gets none: the first request for one
     # (_wt / _wino(transposed)) invalidates the derived state.
+    # The forward forms are on ``cur`` now.  A consumer on ANOTHER stream must be ordered behind them (_await_derived): the three-pass D
+    # forward refreshes D's derived weights from inside its real-third pass on the second stream whenever the update did not come through
+    # Trainer's deferred update -- the public ``loss.backward(); optimizer.step()`` loop, a foreign optimizer, load_state_dict -- while the
+    # mixed third on the main stream was ordered behind the image copy only (docs/experiments_r6.md §1).
+    net._derived_ev = None
+    net._derived_waited = set()
+    if dev is not None and DERIVED_EVENT and not capturing:
+        ev = torch.cuda.Event()
+        _record_event(ev, cur)
+        net._derived_ev = ev
+        net._derived_waited = {cur.cuda_stream}
+        if split:
+            net._pending_ev = ev
     net._derived_bwd_ev = None
     net._derived_bwd_waited = set()
-    dev = torch.cuda.current_device() if net._flat_param.is_cuda else None
-    cur = torch.cuda.current_stream(torch._C._cuda_getDevice()) if dev is not None else None
     if not net.__dict__.get('_bwd_wanted', False):
         pass
-    elif (ASYNC_WGRAD and ASYNC_DERIVED and dev is not None and cur != _SIDE.get(dev) and not torch.cuda.is_current_stream_capturing()):
+    elif (ASYNC_WGRAD and ASYNC_DERIVED and dev is not None and cur != _SIDE.get(dev) and not capturing):
         side = _side_stream()
         _wait_stream(side, cur)
         with torch.cuda.stream(side):
@@ -136,21 +155,14 @@ def _derived(net):
                 buf.record_stream(side)
         net._derived_bwd_ev = ev
     else:
-        backward_copies()
+        backward_copies()                        # inline, on ``cur``: readers on other streams are ordered behind this event
+        if dev is not None and DERIVED_EVENT and not capturing:
+            ev = torch.cuda.Event()
+            _record_event(ev, cur)
+            net._derived_bwd_ev = ev
+            net._derived_bwd_waited = {cur.cuda_stream}
     net._derived_ver = key
     net._derived_live = live
-    # Everything above that was NOT handed to the side stream (the forward forms always; the backward copies in the inline case) was
-    # launched on ``cur``.  A consumer on ANOTHER stream must be ordered behind it (_await_derived): the three-pass D forward refreshes D's
-    # derived weights from inside its real-third pass on the second stream whenever the update did not come through Trainer's deferred
-    # update -- the public ``loss.backward(); optimizer.step()`` loop, a foreign optimizer, load_state_dict -- while the mixed third on
-    # the main stream was ordered behind the image copy only (round-5 lock-step failure, docs/experiments_r6.md §1).
-    net._derived_ev = None
-    net._derived_waited = set()
-    if dev is not None and DERIVED_EVENT and not torch.cuda.is_current_stream_capturing():
-        ev = torch.cuda.Event()
-        _record_event(ev, cur)
-        net._derived_ev = ev
-        net._derived_waited = {cur.cuda_stream}
 
 
 def _await_derived(net):
@@ -359,6 +371,7 @@ def _dgrad_pnbwd(net, gz, layer, N, H, ysaved, r, slope):
 # half-occupancy MFMA kernels share the CUs instead of running back to back.
 ASYNC_WGRAD = _os.environ.get('PGGAN_ASYNC_WGRAD', '1') != '0'
 ASYNC_DERIVED = _os.environ.get('PGGAN_ASYNC_DERIVED', '1') != '0'
+SPLIT_DEFERRED_DERIVE = _os.environ.get('PGGAN_SPLIT_DERIVE', '1') != '0'      # deferred D update: forward forms first, then release the waiting stream
 DERIVED_EVENT = _os.environ.get('PGGAN_DERIVED_EVENT', '1') != '0'    # 0: the round-5 behaviour (ablation for tests/test_e2e_gpu.py::test_derived_refresh_ordering only)
 DERIVED_ONE_LAUNCH = _os.environ.get('PGGAN_DERIVED_ONE_LAUNCH', '1') != '0'      # forward + backward-data Winograd weights of a network: one launch
 # 0: every live layer gets a flipped / transposed copy and the backward-data Winograd form is derived from that copy (round 2)
@@ -446,10 +459,16 @@ def defer_to_side(net, fn):
     main = torch.cuda.current_stream(torch._C._cuda_getDevice())
     side = _side_stream()
     side.wait_stream(main)
-    with torch.cuda.stream(side):
-        fn()
-        ev = torch.cuda.Event()
-        ev.record(side)
+    net._defer_active = True
+    try:
+        with torch.cuda.stream(side):
+            fn()
+            ev = net.__dict__.pop('_pending_ev', None)      # (_derived: the event behind Adam + the forward forms; the rest of the refresh follows it)
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(side)
+    finally:
+        net._defer_active = False
     net._pending = ev
 
 

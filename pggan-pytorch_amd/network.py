@@ -313,7 +313,8 @@ class _FlatParamsMixin(object):
         d['_layer_list'] = None
         d['_derived_bwd_ev'] = None
         d['_derived_bwd_waited'] = set()
-        d['_derived_ev'] = None
+        d['_derived_ev'] = d['_pending_ev'] = None
+        d['_defer_active'] = False
         d['_derived_waited'] = set()
         d['_bwd_wanted'] = False
         return d

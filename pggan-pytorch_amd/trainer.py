@@ -309,6 +309,9 @@ class Trainer(object):
     def train(self):
         """One iteration: ``D_training_repeats`` discriminator updates, then one generator update
         (reference trainer.py:85-115; line numbers below refer to it)."""
+        self._train_iteration()
+
+    def _train_iteration(self):
         world = 1 if self.parallel is None else self.parallel.world_size
         latents = _to_device(self.random_latents_generator())                     # :86
         d_losses = (0, 0, 0)

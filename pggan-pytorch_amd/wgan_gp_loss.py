@@ -42,13 +42,14 @@ def enable_plans(flag=True):
 
 
 _use_plans = __import__('os').environ.get('PGGAN_PLANS', '1') != '0'
+GRAPH_STAGE0 = __import__('os').environ.get('PGGAN_GRAPH_STAGE0', '1') != '0'      # 0: the 4x4 stage from a launch plan too (A/B under data parallelism)
 
 
 def _replay_mode(net):
     """'graph' | 'plan' | None (eager) for a step of ``net`` at its current growth stage (alpha == 1 is checked by the callers)."""
     if _use_graphs is False:
         return None
-    if _use_graphs is True or int(net.depth) == 0:
+    if _use_graphs is True or (int(net.depth) == 0 and GRAPH_STAGE0):
         return 'graph'
     return 'plan' if _use_plans else None
 
