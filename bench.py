@@ -725,7 +725,7 @@ def main():
         'step_issue': pg.wgan_gp_loss._replay_mode(tr.G) or 'eager',
         'd_step_gp_ms': d_gp_ms,
     }
-    out['config']['hip_graphs'] = bool((args.graphs or depth == 0) and args.alpha >= 1.0)
+    out['config']['hip_graphs'] = bool(pg.wgan_gp_loss._replay_mode(tr.G) == 'graph' and args.alpha >= 1.0)
     if args.host_data or (args.config == 5 and not args.no_configs):
         # the same step fed from pinned host memory (37.7 MB per step at 1024x1024): never "value" (inputs resident in HBM is the
         # contract), reported next to it

@@ -12,14 +12,14 @@ from . import engine
 # wgan_gp_loss.py:4-5 keeps module-global scratch; the only state kept here is the injectable RNG.
 mixing_factors = None
 _seed = None                # [seed, draws so far, torch seed it came from] of the mixing-factor stream; None: seeded from torch's RNG at first use
-_use_graphs = 'auto'        # 'auto': replay only where the step is launch-bound (the 4x4 stage); True / False force it
+_use_graphs = 'auto'        # 'auto': launch plans (hipGraphs at the 4x4 stage only with GRAPH_STAGE0); True: hipGraphs everywhere; False: eager
 
 
 def enable_graphs(flag=True):
     """How the D-step / G-step schedules are issued whenever alpha == 1:
-    ``'auto'`` (default): the launch-bound 4x4 stage is replayed from captured hipGraphs (graphs.py: ~100 launches of ~10 us, 1.44x
-    faster), every other stage from a recorded LAUNCH PLAN (plans.py: the same kernels on the same streams with the same events as
-    the eager path, minus the Python between them; ``enable_plans(False)`` turns that off);
+    ``'auto'`` (default): every stage is replayed from a recorded LAUNCH PLAN (plans.py: the same kernels on the same streams with the
+    same events as the eager path, minus the Python between them; ``enable_plans(False)`` turns that off) -- the 4x4 stage included since
+    round 6 (``GRAPH_STAGE0``: it used to replay captured hipGraphs, graphs.py);
     ``True``: hipGraph replay everywhere (measured slower from 8x8 on: the replay serialises the weight-gradient stream);
     ``False``: eager launches (per-launch instrumentation, debugging)."""
     global _use_graphs
@@ -42,7 +42,11 @@ def enable_plans(flag=True):
 
 
 _use_plans = __import__('os').environ.get('PGGAN_PLANS', '1') != '0'
-GRAPH_STAGE0 = __import__('os').environ.get('PGGAN_GRAPH_STAGE0', '1') != '0'      # 0: the 4x4 stage from a launch plan too (A/B under data parallelism)
+# The 4x4 stage used to replay captured hipGraphs in 'auto' mode (round 3: 1.44x the eager launches).  Since the launch plans exist the plan
+# is the faster form there as well (round 6, 4x4 stage, minibatch 16, ms per step graph | plan: 1.121 | 0.924; with a one-rank RCCL
+# communicator 4.09 | 1.09 -- a graph replay serialises the streams and cannot carry the bucket collectives).  PGGAN_GRAPH_STAGE0=1 restores
+# the graph at that stage; ``enable_graphs(True)`` still captures every stage.
+GRAPH_STAGE0 = __import__('os').environ.get('PGGAN_GRAPH_STAGE0', '0') == '1'
 
 
 def _replay_mode(net):

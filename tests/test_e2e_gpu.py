@@ -549,7 +549,7 @@ def test_two_d_losses_before_backward_do_not_alias():
 
 
 def test_hipgraph_replay_alternating_batch_shapes():
-    """at depth 0 (hipGraph replay by default) the three-pass forward's activations live in the network's single-slot arena,
+    """under hipGraph replay (``enable_graphs(True)``; the 4x4 stage's default until round 6) the three-pass forward's activations live in the network's single-slot arena,
     allocated outside the graph's private pool.  A D step with another batch shape replaces that arena; the graph captured for the first
     shape must keep its own alive (graphs._Graphed.keep) -- alternating two shapes, every step against an eager twin."""
     wl = pg.wgan_gp_loss
@@ -572,7 +572,7 @@ def test_hipgraph_replay_alternating_batch_shapes():
             z = torch.randn((n, 32), device=DEV, generator=gen)
             mix = torch.rand((n, 1), device=DEV, generator=gen)
             out = []
-            for (G, D), mode in (((Ga, Da), 'auto'), ((Gb, Db), False)):
+            for (G, D), mode in (((Ga, Da), True), ((Gb, Db), False)):        # (True: hipGraph replay -- 'auto' takes launch plans since round 6)
                 wl._use_graphs = mode
                 wl.set_mixing_factors(mix)
                 c = pg.wgan_gp_D_loss(D, G, real, z)[0]
