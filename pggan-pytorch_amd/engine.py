@@ -582,8 +582,9 @@ def _ones(n, device):
 # ------------------------------------------------------------------------------------------
 # Generator
 # ------------------------------------------------------------------------------------------
-def generator_forward(G, z, save=False, out=None):
-    """reference network.py:118-139.  z [N,latent] -> NCHW image [N,C,r,r] (written into ``out``)."""
+def generator_forward(G, z, save=False, out=None, pair_out=None):
+    """reference network.py:118-139.  z [N,latent] -> NCHW image [N,C,r,r] (written into ``out``).  ``pair_out`` = (outA, outB or None):
+    the two halves of the batch go to two image buffers (the paired D-step / G-step pass, ``_generator_pair``); returns (imgA, imgB)."""
     wait_pending(G)
     ops.require_gpu()
     G._sync_version()                 # also notice torch-side updates (torch.optim.*, load_state_dict) before any derived weight is used
@@ -618,9 +619,15 @@ def generator_forward(G, z, save=False, out=None):
     y1, r1 = layer(zn.view(N, 1, 1, L), b0.c1, 1)                            # 4x4 conv pad 3 on 1x1
     y2, r2 = layer(y1, b0.c2, 4)
     ctx.update(y1=y1, r1=r1, y2=y2, r2=r2)
+    def to_rgb(h, t, H, out_mul=1.0, prev=None, prev_mul=0.0):
+        if pair_out is None:
+            return ops.torgb_fwd(h, t.conv.weight.data, t.conv.bias.data, N, C, H, H, t.c, out_mul=out_mul, prev=prev, prev_mul=prev_mul, out=out)
+        n2 = N // 2
+        return tuple(ops.torgb_fwd(h[a:b], t.conv.weight.data, t.conv.bias.data, n2, C, H, H, t.c, out_mul=out_mul,
+                                   prev=prev[a:b] if prev is not None else None, prev_mul=prev_mul, out=o)
+                     for (a, b), o in zip(((0, n2), (n2, N)), pair_out))
     if depth == 0:
-        t = b0.toRGB
-        img = ops.torgb_fwd(y2, t.conv.weight.data, t.conv.bias.data, N, C, 4, 4, t.c, out=out)   # :55-56
+        img = to_rgb(y2, b0.toRGB, 4)                                          # :55-56
         return (img, ctx) if save else img
     h, H = y2, 4
     for i in range(depth):                                                    # :126-130
@@ -635,8 +642,7 @@ def generator_forward(G, z, save=False, out=None):
     if alpha < 1.0:                                                           # :131-135
         pt = G.blocks[depth - 2].toRGB if depth > 1 else b0.toRGB
         prev = ops.torgb_fwd(hprev, pt.conv.weight.data, pt.conv.bias.data, N, C, H // 2, H // 2, pt.c)
-    img = ops.torgb_fwd(h, t.conv.weight.data, t.conv.bias.data, N, C, H, H, t.c, out_mul=alpha,
-                        prev=prev, prev_mul=1.0 - alpha, out=out)             # :138
+    img = to_rgb(h, t, H, out_mul=alpha, prev=prev, prev_mul=1.0 - alpha)    # :138
     return (img, ctx) if save else img
 
 
@@ -1341,7 +1347,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     if early is not None:
         # the real third is already through D (Trainer, under the previous G step): the other two thirds follow into the same tensors
         x3 = early.x3
-        generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52  (no graph kept)
+        d_step_generator(D, G, latents, x3[N:2 * N])                        # :51-52  (no graph kept)
         ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
         if FAKE_THIRD_ON_SIDE:
             main = torch.cuda.current_stream(torch._C._cuda_getDevice())
@@ -1373,7 +1379,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
         step_start = torch.cuda.Event()
         _record_event(step_start, main)                                       # (everything the previous step left on the main stream)
         probe('D.start')
-        generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52  -- issued first: the host feeds the critical path before the side work
+        d_step_generator(D, G, latents, x3[N:2 * N])                        # :51-52  -- issued first: the host feeds the critical path before the side work
         probe('D.g_fwd_end')
         with torch.cuda.stream(side):
             _wait_event(side, step_start)
@@ -1405,7 +1411,7 @@ def d_loss_forward(D, G, real, latents, mix, iwass_lambda, iwass_epsilon, iwass_
     else:
         x3 = torch.empty((3 * N,) + tuple(real.shape[1:]), device=real.device, dtype=torch.float32)
         ops.axpby_mask(real, a=1.0, out=x3[:N])                               # device copy (plumbing; a C-ABI launch so that plans.py records it)
-        generator_forward(G, latents, out=x3[N:2 * N])                        # :51-52  (no graph kept)
+        d_step_generator(D, G, latents, x3[N:2 * N])                        # :51-52  (no graph kept)
         ops.gp_mix(x3[:N], x3[N:2 * N], mix, out=x3[2 * N:])                  # :19
         s, ctx = d_forward(D, x3, groups=3)                                   # :47,54,20
     sub = _slice_ctx(ctx, 2 * N, 3 * N, 2, 3)
@@ -1467,6 +1473,23 @@ def take_early_real(D, real):
 # leaves the chip partly idle); PGGAN_EARLY_G=0 off, =2 at every stage.
 EARLY_G_FORWARD = os.environ.get('PGGAN_EARLY_G', '1') != '0'
 EARLY_G_MIN_RES = 4 if os.environ.get('PGGAN_EARLY_G', '1') == '2' else int(os.environ.get('PGGAN_EARLY_G_MIN_RES', '256'))
+# Two forms: 'side' = on the second stream behind the fake third (the stages whose minibatch leaves the chip partly idle: from 256^2 up);
+# 'batched' = ONE generator pass over [z | z'] in place of the D step's G(z) (the launch-bound 4x4 stage: half the generator launches per
+# iteration, 1.166 -> 0.997 ms per step).  Same-box pairs, ms per step side | batched: 1024^2 10.31 | 10.55, 10.28 | 10.48, 10.33 | 10.46 (a
+# 6-image pass takes 1.50 ms against 1.02 and holds the fake third back); 512^2 13.40 | 13.51; 256^2 23.25 | 23.29; off | batched: 128^2
+# 20.05 | 20.23, 64^2 14.66 | 14.77, 16^2 5.24 | 5.42.  PGGAN_EARLY_G_MODE=side / batched forces one form wherever the pass runs at all.
+EARLY_G_MODE = os.environ.get('PGGAN_EARLY_G_MODE', 'auto')
+EARLY_G_BATCHED_MAX_RES = int(os.environ.get('PGGAN_EARLY_G_BATCHED_MAX_RES', '4'))
+
+
+def early_g_mode(depth):
+    """'side' | 'batched' | None (the G step runs its own generator pass) for a growth stage."""
+    if not EARLY_G_FORWARD:
+        return None
+    res = 4 * 2 ** int(depth)
+    if EARLY_G_MODE == 'auto':
+        return 'batched' if res <= EARLY_G_BATCHED_MAX_RES else 'side' if res >= EARLY_G_MIN_RES else None
+    return EARLY_G_MODE if (res >= EARLY_G_MIN_RES or res <= EARLY_G_BATCHED_MAX_RES) else None
 EARLY_G_STATS = {'passes': 0, 'used': 0, 'dropped': 0}
 
 
@@ -1474,6 +1497,50 @@ class EarlyG(object):
     """A finished (enqueued) ``generator_forward(G, latents, save=True)``: output image, context, the latents tensor it was computed from
     (identity: what the G loss will be handed), what it was computed with, and the event that closes it on the second stream."""
     __slots__ = ('fake', 'ctx', 'latents', 'stamp', 'event')
+
+
+def _slice_gctx(ctx, a, b):
+    """Images [a, b) of a generator context (every saved tensor is batch-major: activations [n,h,w,c], PixelNorm scales [n*h*w])."""
+    n = ctx['N']
+
+    def sl(t):
+        if t is None:
+            return None
+        per = t.shape[0] // n
+        return t[a * per:b * per]
+    out = dict(N=b - a, depth=ctx['depth'], alpha=ctx['alpha'], recs=[])
+    for k in ('zn', 'y1', 'r1', 'y2', 'r2'):
+        out[k] = sl(ctx.get(k))
+    for rec in ctx['recs']:
+        out['recs'].append(dict(blk=rec['blk'], H=rec['H'], inp=sl(rec['inp']), a1=sl(rec['a1']), r1=sl(rec['r1']), a2=sl(rec['a2']), r2=sl(rec['r2'])))
+    return out
+
+
+def d_step_generator(D, G, latents, out):
+    """The D step's generator pass G(z) -> ``out`` (wgan_gp_loss.py:51-52, no graph kept).  EARLY_G_MODE 'batched': when Trainer has
+    announced the G step's latents z' (``request_early_g``) the two passes run as ONE pass over [z | z'] -- the same weights, twice the
+    images per launch, and the <= 64x64 layers of a 3-image pass are latency-bound launches that take 6 images in nearly the same time --
+    and the second half (with its activations) is left for the G step as an ``EarlyG``."""
+    req = D.__dict__.get('_early_g_request') if early_g_mode(G.depth) == 'batched' else None
+    if req is None or req[0] is not G or tuple(req[1].shape) != tuple(latents.shape):
+        return generator_forward(G, latents, out=out)
+    D.__dict__.pop('_early_g_request', None)
+    zg = _check_dev(req[1], 'latents')
+    N = latents.shape[0]
+    z2 = torch.empty((2 * N,) + tuple(latents.shape[1:]), device=latents.device, dtype=torch.float32)
+    ops.axpby_mask(latents, a=1.0, out=z2[:N])
+    ops.axpby_mask(zg, a=1.0, out=z2[N:])
+    eg = EarlyG()
+    eg.fake = torch.empty_like(out)
+    (img, _), ctx = generator_forward(G, z2, save=True, pair_out=(out, eg.fake))
+    eg.ctx = _slice_gctx(ctx, N, 2 * N)
+    eg.event = torch.cuda.Event()
+    _record_event(eg.event, torch.cuda.current_stream(torch._C._cuda_getDevice()))
+    eg.latents = zg
+    eg.stamp = (G._param_version, int(G.depth), float(G.alpha))
+    G._early_fwd = eg
+    EARLY_G_STATS['passes'] += 1
+    return img
 
 
 def request_early_g(D, G, latents):
@@ -1484,7 +1551,7 @@ def request_early_g(D, G, latents):
 def _early_g_on_side(D, main, side):
     """Inside ``d_loss_forward``, right after the fake third was queued on the second stream: the requested generator pass behind it."""
     req = D.__dict__.pop('_early_g_request', None)
-    if req is None or not EARLY_G_FORWARD or 4 * 2 ** int(req[0].depth) < EARLY_G_MIN_RES:
+    if req is None or early_g_mode(req[0].depth) != 'side':
         return
     G, z = req
     z = _check_dev(z, 'latents')

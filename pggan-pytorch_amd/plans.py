@@ -207,7 +207,9 @@ def d_step(D, G, real, latents, mix, lam, eps, target):
         engine.EARLY_STATS['dropped'] += 1
     dp_tag, ex = _dp_tag(D)
     # the G step's generator pass rides in this step on the second stream (engine.request_early_g): its latents are a fourth static input
-    req = D.__dict__.get('_early_g_request') if engine.EARLY_G_FORWARD else None
+    req = D.__dict__.get('_early_g_request')
+    if req is not None and engine.early_g_mode(req[0].depth) is None:
+        req = None
     if req is None:
         D.__dict__.pop('_early_g_request', None)
     zg = engine._check_dev(req[1], 'latents') if req is not None else None

@@ -273,7 +273,7 @@ class Trainer(object):
         """May the generator pass that opens the G step run inside the D step (second stream, engine.request_early_g)?  The product's G loss
         (it is what picks the pass up), both networks on the device with flat buffers, two streams, no hipGraph capture of either step."""
         from . import wgan_gp_loss
-        return (engine.EARLY_G_FORWARD and 4 * 2 ** int(self.G.depth) >= engine.EARLY_G_MIN_RES and engine.ASYNC_WGRAD and self.G_loss is wgan_gp_loss.wgan_gp_G_loss
+        return (engine.early_g_mode(self.G.depth) is not None and engine.ASYNC_WGRAD and self.G_loss is wgan_gp_loss.wgan_gp_G_loss
                 and hasattr(self.D, '_flat_param') and hasattr(self.G, '_flat_param') and self.G._flat_param.is_cuda
                 and not wgan_gp_loss._graphs_on(self.D) and not wgan_gp_loss._graphs_on(self.G))
 

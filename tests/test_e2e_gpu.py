@@ -780,7 +780,8 @@ def test_three_pass_d_forward_matches_whole_batch_forward(plans_on):
         pg.plans.clear()
 
 
-def test_early_g_forward_is_the_same_pass(deterministic_forward, monkeypatch):
+@pytest.mark.parametrize('mode', ['side', 'batched'])
+def test_early_g_forward_is_the_same_pass(mode, deterministic_forward, monkeypatch):
     """engine.request_early_g (round 6): the generator pass that opens the G step, enqueued on the second stream inside the D step, must be
     the pass the G step would have run itself -- same kernels, same inputs.  Engine level, no optimizer in between: the G cost is
     bit-identical and G's gradients agree to the atomic commit order of the weight gradients; the pass is taken exactly when the latents
@@ -788,6 +789,11 @@ def test_early_g_forward_is_the_same_pass(deterministic_forward, monkeypatch):
     eng, wl = pg.engine, pg.wgan_gp_loss
     wl.enable_graphs(False)
     monkeypatch.setattr(eng, 'EARLY_G_MIN_RES', 4)                # (default: from 256x256 up, where it pays)
+    monkeypatch.setattr(eng, 'EARLY_G_MODE', mode)
+    # 'side': the very same 3-image launches on another stream -> bit-identical.  'batched': one 6-image pass [z | z'] -- other K-slice
+    # counts in the small-map Winograd launches, i.e. another (equally valid) fp32 summation order: last-bit differences in the fake images
+    # and the occasional LeakyReLU flip downstream
+    same = mode == 'side'
     torch.manual_seed(12)
     shape = (1, 3, 64, 64)
     kw = dict(fmap_base=1024, fmap_max=64)
@@ -816,22 +822,30 @@ def test_early_g_forward_is_the_same_pass(deterministic_forward, monkeypatch):
     assert base[4] == dict(passes=0, used=0, dropped=0)
     got = run(True)
     assert got[4] == dict(passes=1, used=1, dropped=0), got[4]
-    assert got[0] == base[0] and got[2] == base[2], (got[0], base[0], got[2], base[2])       # bit-identical losses
-    assert _l2(got[1], base[1].cpu()) < 2e-5 and _l2(got[3], base[3].cpu()) < 2e-5
+    if same:
+        assert got[0] == base[0] and got[2] == base[2], (got[0], base[0], got[2], base[2])   # bit-identical losses
+        assert _l2(got[1], base[1].cpu()) < 2e-5 and _l2(got[3], base[3].cpu()) < 2e-5
+    else:
+        assert abs(got[0] - base[0]) <= 2e-4 * max(1.0, abs(base[0])) and abs(got[2] - base[2]) <= 2e-4 * max(1.0, abs(base[2]))
+        assert _l2(got[1], base[1].cpu()) < 5e-3 and _l2(got[3], base[3].cpu()) < 5e-3
     miss = run(True, other_latents=True)                         # another latents tensor (equal values): the pass is not taken
     assert miss[4] == dict(passes=1, used=0, dropped=1), miss[4]
-    assert miss[2] == base[2] and _l2(miss[3], base[3].cpu()) < 2e-5
+    if same:
+        assert miss[2] == base[2] and _l2(miss[3], base[3].cpu()) < 2e-5
+    else:
+        assert abs(miss[2] - base[2]) <= 2e-4 * max(1.0, abs(base[2])) and _l2(miss[3], base[3].cpu()) < 5e-3
     assert G.__dict__.get('_early_fwd') is None and D.__dict__.get('_early_g_request') is None
 
 
-@pytest.mark.parametrize('plans_on', [False, True])
-def test_trainer_early_g_forward_matches_in_step_forward(plans_on, deterministic_forward, monkeypatch):
+@pytest.mark.parametrize('plans_on,mode', [(False, 'side'), (True, 'side'), (False, 'batched'), (True, 'batched')])
+def test_trainer_early_g_forward_matches_in_step_forward(plans_on, mode, deterministic_forward, monkeypatch):
     """The same through ``Trainer`` (which draws the G step's latents ahead of the D loss: same position in the latents sequence) with eager
     and plan-replayed steps, through a growth-stage change: a trainer with the early generator pass against a twin without it, stepped side
     by side at identical weights -- per-iteration pre-Adam gradients; the pass is really taken in every iteration (none dropped)."""
     wl, eng = pg.wgan_gp_loss, pg.engine
     before = eng.EARLY_G_FORWARD
     monkeypatch.setattr(eng, 'EARLY_G_MIN_RES', 4)                # (default: from 256x256 up, where it pays)
+    monkeypatch.setattr(eng, 'EARLY_G_MODE', mode)
 
     def build():
         torch.manual_seed(21)
@@ -862,7 +876,10 @@ def test_trainer_early_g_forward_matches_in_step_forward(plans_on, deterministic
                 tr.train()
                 torch.cuda.synchronize()
                 out.append((grads_by_name(tr.D), grads_by_name(tr.G)))
-            assert_same_contributions(out[0][0], out[1][0], tol=1e-2, total=2e-4)
+            if mode == 'side':
+                assert_same_contributions(out[0][0], out[1][0], tol=1e-2, total=2e-4)
+            else:                                              # (the batched pass: the fake images differ in the last bits -> LeakyReLU flips in D)
+                assert_same_contributions(out[0][0], out[1][0])
             assert_same_contributions(out[0][1], out[1][1], tol=0.3, total=5e-2)     # (through D after its update: sign-like Adam on round-off noise)
             for a, b in ((tra.G, trb.G), (tra.D, trb.D)):
                 assert float((a._flat_param - b._flat_param).abs().max()) <= 2 * _adam_step_bound(0.001, it + 1) + 1e-6
