@@ -135,6 +135,18 @@ int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, const unsigned
                                   float* dw, float* db, int N, int Hin, int Win, int Cin, int Cout,
                                   float scale, pg_stream_t stream);
 
+/* A DBlock's first conv with the block's fromRGB layer evaluated in its input gather (fromRGB = PGConv2d 1x1 + LeakyReLU,
+ * /root/reference/network.py:145, in front of the block's c1, network.py:33-36 / :151; the call order D.forward network.py:227-228):
+ *   x0[n][h][w][co] = lrelu(rgb_scale * sum_c rgb_w[co][c] * img[n][c][h][w] + rgb_b[co], rgb_slope)      (never materialised)
+ *   y = lrelu(scale * conv3x3(x0, w, pad 1) + bias, slope)
+ * img [N][C][H][W] fp32, rgb_w [Cmid][C], w [3][3][Cout][Cmid], y [N][H][W][Cout]; x_signs / y_signs (optional): the sign bytes
+ * [N][H][W][C/4] of x0 / y (what the masked backward-data forms and pg_fromrgb_bwd_* read).  For forward passes that are not
+ * followed by this conv's weight gradient (which needs x0 in fp32): the G step's pass through D.  Bit-identical to pg_fromrgb_fwd
+ * followed by pg_conv2d_nhwc.  Implemented for Cmid = Cout = 8, C <= 3, W % 64 == 0, H % 16 == 0 (the 1024^2 stage); PG_E_UNSUP otherwise. */
+int pg_conv2d_fromrgb_nhwc(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,
+                           unsigned char* x_signs, const float* w, const float* bias, float* y, unsigned char* y_signs,
+                           int N, int C, int H, int W, int Cmid, int Cout, float scale, float slope, pg_stream_t stream);
+
 /* Winograd F(2x2,3x3) path for the 3x3 layers (pad 1; Cin % 8 == 0; H, W powers of two >= 8): 2.25x fewer MFMAs
  * than the direct implicit GEMM, same fp32 sums re-associated (transform coefficients +-1, 1/2; ~1e-6 relative).
  *   pg_wino_transform_weights: u = G g G^T of w[3][3][Cout][Cin] (once per weight version), 16*Cout*Cin floats stored in

@@ -2175,6 +2175,19 @@ extern "C" int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, con
     return launch_wgrad_thin<64>(p, (hipStream_t)stream);
 }
 
+// A DBlock's first conv with the block's fromRGB layer evaluated in its input gather (reference network.py:145 in front of :33-36):
+//   x0 = lrelu(rgb_scale * conv1x1(img, rgb_w) + rgb_b)  (never written; its sign bytes -> x_signs),  y = lrelu(scale * conv3x3(x0, w) + bias)
+// for forward passes whose fromRGB output is not needed in fp32 afterwards (no weight gradient of this conv follows: the G step's pass
+// through D).  The 8 -> 8 layer of the 1024^2 stage (row-streaming kernel); PG_E_UNSUP otherwise.
+extern "C" int pg_conv2d_fromrgb_nhwc(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,
+                                      unsigned char* x_signs, const float* w, const float* bias, float* y, unsigned char* y_signs,
+                                      int N, int C, int H, int W, int Cmid, int Cout, float scale, float slope, pg_stream_t stream)
+{
+    if (!img || !rgb_w || !w || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cmid <= 0 || Cout <= 0) return PG_E_ARG;
+    return pgk::launch_conv_strip_fromrgb(img, rgb_w, rgb_b, rgb_scale, rgb_slope, x_signs, w, bias, y, y_signs, N, C, H, W, Cmid, Cout,
+                                          scale, slope, (hipStream_t)stream, g_last_kernel, sizeof(g_last_kernel));
+}
+
 extern "C" const char* pg_debug_last_conv_kernel(void) { return g_last_kernel; }
 #ifdef PG_WINO_TRACE
 extern "C" int pg_debug_wgrad_trace(void* buf) { g_wgrad_trace = (unsigned long long*)buf; return 0; }

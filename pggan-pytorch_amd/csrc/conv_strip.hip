@@ -64,6 +64,9 @@ struct SArgs {
     int strips, segs, seg_rows;
     // pool adjoint evaluated in the row gather (pg_conv2d_unpooled_nhwc): input[h][w][c] = gmul * x[h/2][w/2][c] * lrelu'(gbytes[h][w][c])
     const unsigned char* gbytes; float gmul, gslope;
+    // fromRGB evaluated in the row gather (pg_conv2d_fromrgb_nhwc): x is the IMAGE [N][rgbC][H][W]; the conv's input
+    //   x0[h][w][co] = lrelu(rgb_scale * sum_c rgb_w[co][c] * img[c][h][w] + rgb_b[co])   (never written), sign bytes of x0 -> xsigns
+    const float* rgb_w; const float* rgb_b; float rgb_scale, rgb_slope; int rgbC; unsigned char* xsigns;
 };
 
 template <int CIN> struct Blk {
@@ -89,11 +92,16 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
                                            r, (int)voff, 0, 0);
 }
 
-// GATH: the input rows are not copied but COMPUTED (pool adjoint of a coarser gradient x sign bytes of the finer activation): they
+// GM 1 (GATH): the input rows are not copied but COMPUTED (pool adjoint of a coarser gradient x sign bytes of the finer activation): they
 // are fetched into registers one block ahead (under the MFMAs of the step), multiplied and written to the ring with ds_write_b128.
-template <int COUT, int CIN, int EPI, bool WREG, bool GATH>
-__global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_kernel(SArgs p)
+// GM 2 (round 6): the same ring filled with the output of the block's fromRGB layer, computed from the image (reference
+// network.py:145 in front of :33-36): the 1x1 conv + LeakyReLU of a pixel's four channels per slot, in fromrgb_fwd_pix_kernel's
+// order of operations (bit-identical x0); 12 B of image per pixel instead of a 32 B activation written by one launch and read by this one.
+constexpr int RGB_MAXC = 3;
+template <int COUT, int CIN, int EPI, bool WREG, int GM>
+__device__ __forceinline__ void conv_strip_body(const SArgs& p)
 {
+    constexpr bool GATH = GM != 0;
     using B = Blk<CIN>;
     constexpr int C4 = B::C4;
     constexpr int QO = COUT / 4, QP = 16 / QO, PXG = 4 * QP;             // pixels per MFMA group: 32 (8 couts)
@@ -158,7 +166,36 @@ __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_ker
     float4 gxr[NG];
     unsigned gbr[NG];
     __amdgpu_buffer_rsrc_t rgx = pg_make_rsrc(p.x + (size_t)n * ximg, (unsigned)(ximg * 4)), rgb = rgx;
-    if constexpr (GATH) {
+    // GM 2: the lane's pixel of every slot (plane-0 byte offset inside the image, running row), the fromRGB weights of the slot's channel quad
+    constexpr int NR = GM == 2 ? NG : 1;
+    int rrow[NR];
+    float rw[NR][4][RGB_MAXC], rb[NR][4], rpx[NR][RGB_MAXC];
+    if constexpr (GM == 2) {
+        rgx = pg_make_rsrc(p.x + (size_t)n * npix * p.rgbC, npix * (unsigned)p.rgbC * 4u);
+        rgb = pg_make_rsrc(p.xsigns + (size_t)n * npix * C4, npix * C4);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int sl = i * 256 + tid;
+            const int q = sl / (RB * RP), rem = sl - q * (RB * RP);
+            const int m = rem / RP, px = rem - m * RP;
+            const int col = ow0 - 1 + px;
+            const bool ok = sl < B::USED && (unsigned)col < (unsigned)p.W;
+            rrow[i] = ok ? r0 - 1 + m : -(1 << 28);                    // (a row that never enters the image)
+            cvo[i] = ok ? 4u * (unsigned)((r0 - 1 + m) * p.W + col) : PG_OOB;       // (row -1: wraps, never fetched -- the row test below)
+            cvs[i] = ok ? 4u * (unsigned)(RB * p.W) : 0u;
+            // sign byte of the slot: interior columns of the strip only (the halo columns belong to the neighbours)
+            bvo[i] = (ok && px >= 1 && px <= SW) ? (unsigned)((r0 - 1 + m) * p.W + col) * C4 + q : PG_OOB;
+            bvs[i] = (ok && px >= 1 && px <= SW) ? (unsigned)(RB * p.W * C4) : 0u;
+            const int qq = sl < B::USED ? q : 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < RGB_MAXC; ++c) rw[i][k][c] = c < p.rgbC ? p.rgb_w[(4 * qq + k) * p.rgbC + c] : 0.f;
+                rb[i][k] = p.rgb_b ? p.rgb_b[4 * qq + k] : 0.f;
+            }
+        }
+    }
+    if constexpr (GM == 1) {
         rgb = pg_make_rsrc(p.gbytes + (size_t)n * npix * C4, npix * C4);
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
@@ -174,6 +211,17 @@ __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_ker
         }
     }
     auto gather_load = [&]() {                                // the next block of four fine rows: coarse values + sign bytes -> registers
+        if constexpr (GM == 2) {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const bool in = (unsigned)rrow[i] < (unsigned)p.H;
+#pragma unroll
+                for (int c = 0; c < RGB_MAXC; ++c)
+                    rpx[i][c] = c < p.rgbC ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgx, in ? (int)(cvo[i] + (unsigned)c * npix * 4u) : (int)PG_OOB, 0, 0)) : 0.f;
+                cvo[i] += cvs[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             gxr[i] = pg_buf_load4(rgx, cvo[i], 0);
@@ -182,6 +230,30 @@ __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_ker
         }
     };
     auto gather_store = [&](int pos) {                        // x (gmul x LeakyReLU' factor), into ring position pos
+        if constexpr (GM == 2) {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int sl = i * 256 + tid;
+                const bool in = (unsigned)rrow[i] < (unsigned)p.H;              // rows above / below the image: the conv's zero padding
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int c = 0; c < RGB_MAXC; ++c) if (c < p.rgbC) a = fmaf(rpx[i][c], rw[i][k][c], a);
+                    const float v = __fadd_rn(__fmul_rn(a, p.rgb_scale), rb[i][k]);      // (two roundings, as fromrgb_fwd_pix_kernel: no contraction)
+                    o[k] = in ? (v > 0.f ? v : v * p.rgb_slope) : 0.f;
+                }
+                const float4 v4 = make_float4(o[0], o[1], o[2], o[3]);
+                if (sl < B::SLOTS) *reinterpret_cast<float4*>(lds + (pos * B::SLOTS + sl) * 4) = (cvs[i] ? v4 : make_float4(0.f, 0.f, 0.f, 0.f));
+                // the sign bytes of x0 (what fromRGB's backward and this conv's masked backward-data form read), rows of this segment only
+                if (p.xsigns && in && rrow[i] >= r0 && rrow[i] < r0 + p.seg_rows && bvs[i])
+                    __builtin_amdgcn_raw_buffer_store_b8(pg_sign_byte(v4), rgb, (int)bvo[i], 0, 0);
+                bvo[i] += bvs[i];
+                rrow[i] += RB;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int sl = i * 256 + tid;
@@ -419,6 +491,19 @@ __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_ker
         if (it + 1 < niter) step(it + 1, std::integral_constant<int, 1>{});
         if (it + 2 < niter) step(it + 2, std::integral_constant<int, 2>{});
     }
+}
+
+template <int COUT, int CIN, int EPI, bool WREG, bool GATH>
+__global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_kernel(SArgs p)
+{
+    conv_strip_body<COUT, CIN, EPI, WREG, GATH ? 1 : 0>(p);
+}
+
+// 8 -> 8 with the block's fromRGB layer in the gather (GM 2)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv_strip_rgb_kernel(SArgs p)
+{
+    conv_strip_body<8, 8, EPI, false, 2>(p);
 }
 
 // Dynamic LDS above 48 KB needs the function attribute; it is a per-device property of the loaded code object, so it is set on
@@ -716,6 +801,29 @@ int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
     if (p.Cin == 8) return wreg_env ? launch_strip_epi<8, 8, true>(a, epi, p.N, s, name, name_len)
                                     : launch_strip_epi<8, 8, false>(a, epi, p.N, s, name, name_len);
     return launch_strip_epi<8, 16, false>(a, epi, p.N, s, name, name_len);
+}
+
+int pgk::launch_conv_strip_fromrgb(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,
+                                   unsigned char* x_signs, const float* w, const float* bias, float* y, unsigned char* y_signs,
+                                   int N, int C, int H, int W, int Cmid, int Cout, float scale, float slope,
+                                   hipStream_t s, char* name, size_t name_len)
+{
+    if (C > RGB_MAXC || Cmid != 8 || Cout != 8 || (W % SW) || (H % 16)) return PG_E_UNSUP;
+    if ((long long)H * W * 16 * 4 >= (1ll << 31)) return PG_E_UNSUP;            // 32-bit byte offsets inside an image
+    int seg = 64;                                                                // (as launch_conv_strip)
+    while (seg > 16 && ((long long)N * (W / SW) * (H / seg) < 768 || (H % seg))) seg >>= 1;
+    if (seg < 16 || (seg % RB) || (H % seg)) return PG_E_UNSUP;
+    SArgs a{};
+    a.x = img; a.w = w; a.bias = bias; a.y = y; a.ysigns = y_signs;
+    a.scale = scale; a.slope = slope; a.mask_slope = 1.f; a.pool_a = 1.f;
+    a.H = H; a.W = W; a.strips = W / SW; a.segs = H / seg; a.seg_rows = seg;
+    a.rgb_w = rgb_w; a.rgb_b = rgb_b; a.rgb_scale = rgb_scale; a.rgb_slope = rgb_slope; a.rgbC = C; a.xsigns = x_signs;
+    const size_t smem = (size_t)NBLK * Blk<8>::SLOTS * 16 + (size_t)9 * 8 * 8 * 4;
+    auto kern = conv_strip_rgb_kernel<EPI_FWD>;
+    if (int rc = strip_set_smem(reinterpret_cast<const void*>(kern), smem); rc) return rc;
+    snprintf(name, name_len, "conv_strip_rgb_kernel<%d>", (int)EPI_FWD);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
+    return (int)hipGetLastError();
 }
 
 int pgk::launch_wgrad_strip(WgP& p, hipStream_t s, char* name, size_t name_len)

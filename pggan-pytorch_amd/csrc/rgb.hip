@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void fromrgb_fwd_kernel(
             float a = 0.f;
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) if (c < C) a = fmaf(xin[c], wr[c], a);
-            o[j] = a * scale;
+            o[j] = __fmul_rn(a, scale);          // (explicit roundings, as in fromrgb_fwd_pix_kernel)
         }
         const size_t off = pix * Cout + 4 * c4;
         if (mask) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void fromrgb_fwd_kernel(
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = o[j] + (bias ? bias[4 * c4 + j] : 0.f);
+                float v = __fadd_rn(o[j], bias ? bias[4 * c4 + j] : 0.f);
                 o[j] = v > 0.f ? v : v * slope;
             }
             if (ysigns) ysigns[off >> 2] = (unsigned char)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void fromrgb_fwd_pix_kernel(
                 float a = 0.f;
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c) if (c < C) a = fmaf(xin[c], wr[c], a);
-                o[j] = a * scale;
+                o[j] = __fmul_rn(a, scale);      // (explicit roundings here and at the bias: conv_strip_rgb_kernel restates this pixel bit for bit)
             }
             if (mask) {
                 if (mbytes) {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void fromrgb_fwd_pix_kernel(
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float v = o[j] + (bias ? bias[4 * c4 + j] : 0.f);
+                    const float v = __fadd_rn(o[j], bias ? bias[4 * c4 + j] : 0.f);
                     o[j] = v > 0.f ? v : v * slope;
                 }
                 if (ysigns) ysigns[(off >> 2) + c4] = (unsigned char)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));

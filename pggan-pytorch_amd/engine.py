@@ -320,6 +320,8 @@ def _dgrad(net, gz, layer, N, Hout, mask=None, mask_slope=0.2):
                 return run(mb)
             except ops.Unsupported:
                 FALLBACKS['dgrad masked %dx%d %s' % (Hout, Hout, tuple(layer.conv.weight.shape))] += 1
+                if m32 is None:                    # (d_forward(keep_input=False) kept the sign bytes only: expand them)
+                    m32 = _mask32(mb)
         return run(m32)
     return run(mask)
 
@@ -758,9 +760,17 @@ def _mbstd_bwd(D, gy, x, stats, cp, apply_mask, mask_slope, tx=None, tstats=None
 # ------------------------------------------------------------------------------------------
 # Discriminator
 # ------------------------------------------------------------------------------------------
-def d_forward(D, x, groups=1):
+# The G step's pass through D is followed by a backward-data sweep only (no weight gradients of D): the fp32 output of the entry block's
+# fromRGB layer is then needed by nobody but the block's first conv, which evaluates it in its gather from the image
+# (ops.conv2d_fromrgb: 12 B of image per pixel instead of 32 B written by one launch and read by the next; the 1024^2 stage).
+FUSE_FROMRGB = _os.environ.get('PGGAN_FUSE_FROMRGB', '1') != '0'
+
+
+def d_forward(D, x, groups=1, keep_input=True):
     """reference network.py:225-240 on a batch of ``groups`` independent minibatches stacked along
-    N (minibatch-stddev is evaluated per group).  Returns (scores [NB], ctx with every activation)."""
+    N (minibatch-stddev is evaluated per group).  Returns (scores [NB], ctx with every activation).
+    ``keep_input=False``: the caller will not ask for D's weight gradients (``d_backward(full=False)``) -- the entry block's fromRGB
+    output may stay unmaterialised (``rec['inp']`` is None then; its sign bytes ``rec['inpb']`` are always there)."""
     wait_pending(D)
     D._sync_version()
     NB, C, r, _ = x.shape
@@ -775,7 +785,19 @@ def d_forward(D, x, groups=1):
     fr = D.blocks[e].fromRGB
     sb = USE_SIGN_BYTES and not pn                                            # byte copies of the fp32 activations (masks)
     curb = None
-    if sb and r >= SIGN_BYTES_MIN_H:
+    fused = None                                 # (a1, a1b) of the entry block when its c1 ran with fromRGB in the gather
+    if not keep_input and FUSE_FROMRGB and sb and r >= SIGN_BYTES_MIN_H and e < nb - 1 and x.is_cuda:
+        c1 = D.blocks[e].c1
+        if c1.ksize == 3 and c1.pad == 1 and _wino(c1, NB, r, c1.conv.weight.shape[2]) is None:
+            try:
+                a1, a1b, curb = ops.conv2d_fromrgb(x, fr.conv.weight.data, fr.conv.bias.data, fr.c, fr.slope, c1.conv.weight.data,
+                                                   c1.conv.bias.data, NB, C, r, r, c1.c, c1.slope)
+                fused, cur = (a1, a1b), None
+            except ops.Unsupported:
+                FALLBACKS['fromRGB in the gather %dx%d' % (r, r)] += 1
+    if fused is not None:
+        pass
+    elif sb and r >= SIGN_BYTES_MIN_H:
         cur, curb = ops.fromrgb_fwd(x, fr.conv.weight.data, fr.conv.bias.data, NB, C, r, r, fr.c, fr.slope, signs_out=True)
     else:
         cur = ops.fromrgb_fwd(x, fr.conv.weight.data, fr.conv.bias.data, NB, C, r, r, fr.c, fr.slope)
@@ -797,7 +819,9 @@ def d_forward(D, x, groups=1):
                 a2, rec['r2'] = ops.pixelnorm_fwd(a2, inplace=True)
             rec.update(mb=mb, stats=stats, a1=a1, a2=a2)
         else:
-            if sb and H >= SIGN_BYTES_MIN_H:
+            if k == 0 and fused is not None:
+                a1, rec['a1b'] = fused
+            elif sb and H >= SIGN_BYTES_MIN_H:
                 a1, a1b = _conv(cur, blk.c1, NB, H, signs_out=True)
                 if a1b is not None:
                     rec['a1b'] = a1b
@@ -1634,7 +1658,7 @@ def g_loss_forward(G, D, latents):
     else:
         fake, gctx = generator_forward(G, latents, save=True)
     probe('G.g_fwd_end')
-    s, dctx = d_forward(D, fake, 1)
+    s, dctx = d_forward(D, fake, 1, keep_input=False)
     g_cost, gscore = ops.g_loss(s)
     probe('G.d_fwd_end')
     return g_cost, dict(G=G, D=D, gctx=gctx, dctx=dctx, gscore=gscore)

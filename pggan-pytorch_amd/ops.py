@@ -342,6 +342,19 @@ def conv2d_unpooled(g, w, gbytes, gmul, gslope, N, Hin, Win, scale, mask=None, m
     return y
 
 
+def conv2d_fromrgb(img, rgb_w, rgb_b, rgb_scale, rgb_slope, w, bias, N, C, H, W, scale, slope, signs_out=True):
+    """c1(fromRGB(img)) of a DBlock in one launch, fromRGB evaluated in the conv's gather (its fp32 output is never written).
+    img [N,C,H,W], rgb_w [Cmid,C,1,1] / [Cmid,C], w packed [3,3,Cout,Cmid].  Returns (y, sign bytes of y, sign bytes of fromRGB's
+    output); raises ops.Unsupported outside the 8 -> 8 layer of the 1024^2 stage."""
+    cout, cmid = w.shape[2], w.shape[3]
+    y = _empty((N, H, W, cout), device=img.device, dtype=torch.float32)
+    yb = _empty((N, H, W, cout // 4), device=img.device, dtype=torch.uint8) if signs_out else None
+    xb = _empty((N, H, W, cmid // 4), device=img.device, dtype=torch.uint8)
+    _lib.call('pg_conv2d_fromrgb_nhwc', _p(img), _p(rgb_w), _p(rgb_b), rgb_scale, rgb_slope, _p(xb), _p(w), _p(bias), _p(y), _p(yb),
+              N, C, H, W, cmid, cout, scale, slope, _stream())
+    return y, yb, xb
+
+
 def conv2d_wgrad_unpooled(x, g, gbytes, gmul, gslope, dw, db, N, Hin, Win, scale):
     """Weight gradient with gz = pool adjoint of ``g`` evaluated in the gather (see conv2d_unpooled)."""
     cout, cin = dw.shape[2], dw.shape[3]

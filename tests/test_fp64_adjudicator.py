@@ -51,7 +51,7 @@ def _d_signs(ctx, a, b, ch_last):
     out = []
     for k, rec in enumerate(ctx['recs']):
         if k == 0:
-            out.append(_nchw(rec['inp'][a:b]))
+            out.append(_nchw((rec['inp'] if rec['inp'] is not None else rec['inpb'])[a:b]))      # (the G step's pass keeps fromRGB's sign bytes only)
         a1 = _nchw(rec['a1'][a:b])
         out.append(a1)
         a2 = rec['a2'][a:b]

@@ -217,3 +217,35 @@ def test_strip_pool_adjoint_in_the_gather(case):
         ops.conv2d_wgrad_unpooled(a1.cuda(), gd, gb, 0.25 * 0.7, 0.2, tdw, tdb, N, H, H, 0.41)
         assert last_kernel().startswith('conv_wgrad_thin_kernel'), last_kernel()
     assert rel_err(dw, tdw) < 1e-5 and rel_err(db, tdb) < 1e-5
+
+
+@pytest.mark.parametrize('N,H,W,C', [(3, 64, 64, 3), (2, 128, 256, 3), (1, 1024, 1024, 3), (9, 32, 128, 1), (1, 16, 64, 2), (5, 32, 256, 3), (2, 16, 512, 2)])
+def test_conv_with_fromrgb_in_the_gather(N, H, W, C):
+    """pg_conv2d_fromrgb_nhwc (conv_strip_rgb_kernel): c1(fromRGB(img)) of a DBlock in one launch -- the 1x1 conv + LeakyReLU of
+    reference network.py:145 evaluated in the row gather of the 3x3 conv (network.py:33-36), its output never written.  Against the
+    torch statement of the two layers, and against pg_fromrgb_fwd followed by pg_conv2d_nhwc (same order of operations per pixel: the
+    sign bytes of fromRGB's output are identical; same MFMA order: the conv output agrees to the last bits).  Image borders on all four
+    sides of a strip / segment, one to three image channels, segments of 16 / 32 / 64 rows."""
+    img = rnd(N, C, H, W, seed=1)
+    rw, rb = rnd(8, C, seed=2) * 0.7, rnd(8, seed=3) * 0.3
+    w, b = rnd(3, 3, 8, 8, seed=4) * 0.2, rnd(8, seed=5) * 0.1
+    d = lambda t: t.cuda()
+    x0, x0b = ops.fromrgb_fwd(d(img), d(rw), d(rb), N, C, H, W, 0.61, 0.2, signs_out=True)
+    want, wantb = ops.conv2d(x0, d(w), d(b), N, H, W, 3, 1, 0.37, 0.2, signs_out=True)
+    assert last_kernel().startswith('conv_strip_kernel'), last_kernel()
+    y, yb, xb = ops.conv2d_fromrgb(d(img), d(rw), d(rb), 0.61, 0.2, d(w), d(b), N, C, H, W, 0.37, 0.2)
+    assert last_kernel().startswith('conv_strip_rgb_kernel'), last_kernel()
+    torch.cuda.synchronize()
+    assert torch.equal(xb, x0b)                                # fromRGB's output: bit-identical (explicit roundings in both kernels)
+    assert same(y, want) and same(yb, wantb)                   # (the conv: same MFMA order; see ``same`` for the one free contraction)
+    ex0 = E.fromrgb_fwd(img, rw, rb, N, C, H, W, 0.61, 0.2)
+    assert rel_err(y, E.conv2d(ex0, w, b, N, H, W, 3, 1, 0.37, slope=0.2)) < 2e-5
+    assert bool((xb.cpu() == E.signbytes_of(x0.cpu())).all())
+
+
+def test_conv_with_fromrgb_unsupported_shapes():
+    """Outside the 8 -> 8 layer on strip-sized maps the entry point refuses (ops.Unsupported: the caller keeps the two launches)."""
+    d = lambda t: t.cuda()
+    for (N, H, W, C, cm) in [(1, 32, 32, 3, 8), (1, 64, 64, 4, 8), (1, 64, 64, 3, 16)]:
+        with pytest.raises(ops.Unsupported):
+            ops.conv2d_fromrgb(d(rnd(N, C, H, W)), d(rnd(cm, C)), d(rnd(cm)), 1.0, 0.2, d(rnd(3, 3, 8, cm)), d(rnd(8)), N, C, H, W, 1.0, 0.2)

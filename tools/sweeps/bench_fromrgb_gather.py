@@ -1,0 +1,41 @@
+"""c1(fromRGB(img)) of the 1024^2 entry block: two launches (pg_fromrgb_fwd + pg_conv2d_nhwc) against one (pg_conv2d_fromrgb_nhwc,
+fromRGB in the conv's gather).   python tools/sweeps/bench_fromrgb_gather.py [reps]"""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+pg = importlib.import_module('pggan-pytorch_amd')
+ops, lib = pg.ops, pg._lib.load()
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+
+
+def timed(fn):
+    for _ in range(5):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(REPS):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / REPS * 1e3
+
+
+for N, H, C in [(3, 1024, 3), (6, 1024, 3), (9, 1024, 3), (3, 512, 3), (8, 256, 1)]:
+    img = torch.randn(N, C, H, H, device='cuda')
+    rw, rb = torch.randn(8, C, device='cuda'), torch.randn(8, device='cuda')
+    w, b = torch.randn(3, 3, 8, 8, device='cuda') * 0.2, torch.randn(8, device='cuda')
+    t_rgb = timed(lambda: ops.fromrgb_fwd(img, rw, rb, N, C, H, H, 0.6, 0.2, signs_out=True))
+    x0, _ = ops.fromrgb_fwd(img, rw, rb, N, C, H, H, 0.6, 0.2, signs_out=True)
+    t_conv = timed(lambda: ops.conv2d(x0, w, b, N, H, H, 3, 1, 0.4, 0.2, signs_out=True))
+    k1 = lib.pg_debug_last_conv_kernel().decode()
+    t_two = timed(lambda: ops.conv2d(ops.fromrgb_fwd(img, rw, rb, N, C, H, H, 0.6, 0.2, signs_out=True)[0], w, b, N, H, H, 3, 1, 0.4, 0.2, signs_out=True))
+    t_one = timed(lambda: ops.conv2d_fromrgb(img, rw, rb, 0.6, 0.2, w, b, N, C, H, H, 0.4, 0.2))
+    k2 = lib.pg_debug_last_conv_kernel().decode()
+    px = N * H * H
+    print('n%d @%d C%d: fromRGB %6.1f us (%.2f TB/s) + conv %6.1f us (%.2f TB/s, %s) = %6.1f back to back | fused %6.1f us (%.2f TB/s, %s)'
+          % (N, H, C, t_rgb, px * (4 * C + 34) / t_rgb * 1e-6, t_conv, px * 66 / t_conv * 1e-6, k1[:34], t_two, t_one, px * (4 * C + 36) / t_one * 1e-6, k2), flush=True)
