@@ -143,6 +143,16 @@ int pg_conv2d_wgrad_unpooled_nhwc(const float* x, const float* g, const unsigned
  * [N][H][W][C/4] of x0 / y (what the masked backward-data forms and pg_fromrgb_bwd_* read).  For forward passes that are not
  * followed by this conv's weight gradient (which needs x0 in fp32): the G step's pass through D.  Bit-identical to pg_fromrgb_fwd
  * followed by pg_conv2d_nhwc.  Implemented for Cmid = Cout = 8, C <= 3, W % 64 == 0, H % 16 == 0 (the 1024^2 stage); PG_E_UNSUP otherwise. */
+/* The generator's last conv with the block's toRGB layer in its epilogue (PGConv2d + PixelNorm /root/reference/network.py:33-41,
+ * toRGB network.py:49, applied at network.py:138 with alpha = 1):
+ *   y = pixelnorm(lrelu(scale * conv3x3(x, w, pad 1) + bias, slope)), r[pixel] = the normalisation factor        (as pg_conv2d_pixelnorm_nhwc)
+ *   img[n][c][h][w] = t_scale * sum_co t_w[c][co] * y[n][h][w][co] + t_b[c]                                     (as pg_torgb_fwd)
+ * t_w [C][Cout], img [N][C][H][W].  Implemented for Cin = Cout = 8, C <= 3, W % 64 == 0, H % 16 == 0; PG_E_UNSUP otherwise.   */
+int pg_conv2d_pixelnorm_torgb_nhwc(const float* x, const float* w, const float* bias, float* y, float* r,
+                                   const float* t_w, const float* t_b, float t_scale, float* img,
+                                   int N, int C, int H, int W, int Cin, int Cout, float scale, float slope, float eps,
+                                   pg_stream_t stream);
+
 int pg_conv2d_fromrgb_nhwc(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,
                            unsigned char* x_signs, const float* w, const float* bias, float* y, unsigned char* y_signs,
                            int N, int C, int H, int W, int Cmid, int Cout, float scale, float slope, pg_stream_t stream);

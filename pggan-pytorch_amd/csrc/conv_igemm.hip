@@ -2188,6 +2188,20 @@ extern "C" int pg_conv2d_fromrgb_nhwc(const float* img, const float* rgb_w, cons
                                           scale, slope, (hipStream_t)stream, g_last_kernel, sizeof(g_last_kernel));
 }
 
+// The generator's last conv (+ bias + LeakyReLU + PixelNorm, network.py:33-41) with the block's toRGB layer (network.py:49, :138 at
+// alpha = 1) in the same epilogue: the normalised activation is written for the backward pass as before and the image
+//   img[n][c][h][w] = t_scale * sum_co t_w[c][co] * y[n][h][w][co] + t_b[c]
+// leaves with it, instead of a second launch that reads y back.  8 -> 8 on strip-sized maps (the 1024^2 stage); PG_E_UNSUP otherwise.
+extern "C" int pg_conv2d_pixelnorm_torgb_nhwc(const float* x, const float* w, const float* bias, float* y, float* r,
+                                              const float* t_w, const float* t_b, float t_scale, float* img,
+                                              int N, int C, int H, int W, int Cin, int Cout, float scale, float slope, float eps,
+                                              pg_stream_t stream)
+{
+    if (!x || !w || !y || !r || !t_w || !img || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
+    return pgk::launch_conv_strip_pn_torgb(x, w, bias, y, r, t_w, t_b, t_scale, img, N, C, H, W, Cin, Cout, scale, slope, eps,
+                                           (hipStream_t)stream, g_last_kernel, sizeof(g_last_kernel));
+}
+
 extern "C" const char* pg_debug_last_conv_kernel(void) { return g_last_kernel; }
 #ifdef PG_WINO_TRACE
 extern "C" int pg_debug_wgrad_trace(void* buf) { g_wgrad_trace = (unsigned long long*)buf; return 0; }

@@ -67,6 +67,8 @@ struct SArgs {
     // fromRGB evaluated in the row gather (pg_conv2d_fromrgb_nhwc): x is the IMAGE [N][rgbC][H][W]; the conv's input
     //   x0[h][w][co] = lrelu(rgb_scale * sum_c rgb_w[co][c] * img[c][h][w] + rgb_b[co])   (never written), sign bytes of x0 -> xsigns
     const float* rgb_w; const float* rgb_b; float rgb_scale, rgb_slope; int rgbC; unsigned char* xsigns;
+    // toRGB on top of the PixelNorm epilogue (pg_conv2d_pixelnorm_torgb_nhwc): t_out[n][c][h][w] = t_scale * sum_co t_w[c][co] * y[h][w][co] + t_b[c]
+    float* t_out; const float* t_w; const float* t_b; float t_scale; int tC;
 };
 
 template <int CIN> struct Blk {
@@ -315,6 +317,19 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     const unsigned pix0 = (unsigned)((r0 + 2 * rp) * p.W + ow0 + col0 + 4 * qp + j);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!has_mask && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + 4 * qo);
+    // toRGB behind the PixelNorm (round 6): the lane's four couts x the image channels; the QO lanes of a pixel add their partial sums
+    const bool has_trgb = EPI == EPI_PN && p.t_out != nullptr;
+    float tw[RGB_MAXC][4], tb[RGB_MAXC];
+    __amdgpu_buffer_rsrc_t rtout = ry;
+    if (has_trgb) {
+        rtout = pg_make_rsrc(p.t_out + (size_t)n * npix * p.tC, npix * (unsigned)p.tC * 4u);
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tw[c][k] = c < p.tC ? p.t_w[c * COUT + 4 * qo + k] : 0.f;
+            tb[c] = (c < p.tC && p.t_b) ? p.t_b[c] : 0.f;
+        }
+    }
 
     f32x4 acc[G], acc2[G];
     // MFMAs of one step: ring phase PH (block of the step at ring position PH) and row pair RPAIR are compile-time, so every LDS
@@ -413,6 +428,16 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
                 const float rr = rsqrtf(ssq / (float)COUT + p.pn_eps);
                 o.x *= rr; o.y *= rr; o.z *= rr; o.w *= rr;
                 if (qo == 0 && !(PG_STRIP_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rr), rpnr, (int)(pg_ * 4u), 0, 0);
+                if (has_trgb) {                          // (workgroup-uniform)
+#pragma unroll
+                    for (int c = 0; c < RGB_MAXC; ++c) {
+                        if (c >= p.tC) break;
+                        float a = fmaf(o.w, tw[c][3], fmaf(o.z, tw[c][2], fmaf(o.y, tw[c][1], o.x * tw[c][0])));
+                        a += __shfl_xor(a, 4, 64);
+                        if (QO >= 4) a += __shfl_xor(a, 8, 64);
+                        if (qo == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(a, p.t_scale, tb[c])), rtout, (int)(((unsigned)c * npix + pg_) * 4u), 0, 0);
+                    }
+                }
             }
             if (!(PG_STRIP_ABL & 2)) {
                 if (y_bytes) __builtin_amdgcn_raw_buffer_store_b8(pg_sign_byte(o), ry, (int)(off >> 2), 0, 0);
@@ -455,7 +480,13 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     nstores = __builtin_amdgcn_readfirstlane(nstores);
     auto wait_dma = [&]() {
         if constexpr (EPI == EPI_MASK || EPI == EPI_PNB) { static_assert(G == 2, ""); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-        else if constexpr (EPI == EPI_PN) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr (EPI == EPI_PN) {
+            static_assert(G == 2, "");
+            if (!has_trgb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  // (+ G stores per image channel of the toRGB output)
+            else if (p.tC == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (p.tC == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
         else switch (nstores) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -775,7 +806,7 @@ int pgk::launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len)
     int seg = seg_env > 0 ? seg_env : 64;
     while (seg > 16 && ((long long)p.N * (p.Wout / SW) * (p.Hout / seg) < 768 || (p.Hout % seg))) seg >>= 1;
     if (seg < 16 || (seg % RB) || (p.Hout % seg)) return PG_E_UNSUP;
-    SArgs a;
+    SArgs a{};                                   // (the fields this entry does not use -- fromRGB gather, toRGB epilogue -- must read as "off")
     a.x = p.x; a.w = p.w; a.bias = p.bias; a.mask = p.mask; a.y = p.y;
     a.ysigns = p.ysigns; a.pn_r = p.pn_r; a.pnb_y = p.pnb_y; a.pnb_r = p.pnb_r; a.ypool = p.ypool; a.pool_other = p.pool_other;
     a.scale = p.scale; a.slope = p.slope; a.mask_slope = p.mask_slope; a.pn_eps = p.pn_eps; a.pool_a = p.pool_a; a.pool_b = p.pool_b;
@@ -824,6 +855,25 @@ int pgk::launch_conv_strip_fromrgb(const float* img, const float* rgb_w, const f
     snprintf(name, name_len, "conv_strip_rgb_kernel<%d>", (int)EPI_FWD);
     hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
     return (int)hipGetLastError();
+}
+
+int pgk::launch_conv_strip_pn_torgb(const float* x, const float* w, const float* bias, float* y, float* r,
+                                    const float* t_w, const float* t_b, float t_scale, float* img,
+                                    int N, int C, int H, int W, int Cin, int Cout, float scale, float slope, float eps,
+                                    hipStream_t s, char* name, size_t name_len)
+{
+    static const int wreg_env = getenv("PG_STRIP_WREG") ? atoi(getenv("PG_STRIP_WREG")) : 1;
+    if (C < 1 || C > RGB_MAXC || Cin != 8 || Cout != 8 || (W % SW) || (H % 16)) return PG_E_UNSUP;
+    if ((long long)H * W * 16 * 4 >= (1ll << 31)) return PG_E_UNSUP;
+    int seg = 64;                                                                // (as launch_conv_strip)
+    while (seg > 16 && ((long long)N * (W / SW) * (H / seg) < 768 || (H % seg))) seg >>= 1;
+    if (seg < 16 || (seg % RB) || (H % seg)) return PG_E_UNSUP;
+    SArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.pn_r = r; a.pn_eps = eps;
+    a.scale = scale; a.slope = slope; a.mask_slope = 1.f; a.pool_a = 1.f;
+    a.H = H; a.W = W; a.strips = W / SW; a.segs = H / seg; a.seg_rows = seg;
+    a.t_out = img; a.t_w = t_w; a.t_b = t_b; a.t_scale = t_scale; a.tC = C;
+    return wreg_env ? launch_strip<8, 8, EPI_PN, true>(a, N, s, name, name_len) : launch_strip<8, 8, EPI_PN, false>(a, N, s, name, name_len);
 }
 
 int pgk::launch_wgrad_strip(WgP& p, hipStream_t s, char* name, size_t name_len)

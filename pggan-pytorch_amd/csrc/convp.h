@@ -64,6 +64,10 @@ bool find_workspace(hipStream_t s, Workspace& out);
 // kernel symbol for pg_debug_last_conv_kernel.
 int launch_conv_strip(ConvP& p, hipStream_t s, char* name, size_t name_len);
 int launch_wgrad_strip(WgP& p, hipStream_t s, char* name, size_t name_len);
+int launch_conv_strip_pn_torgb(const float* x, const float* w, const float* bias, float* y, float* r,
+                               const float* t_w, const float* t_b, float t_scale, float* img,
+                               int N, int C, int H, int W, int Cin, int Cout, float scale, float slope, float eps,
+                               hipStream_t s, char* name, size_t name_len);
 int launch_conv_strip_fromrgb(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,
                               unsigned char* x_signs, const float* w, const float* bias, float* y, unsigned char* y_signs,
                               int N, int C, int H, int W, int Cmid, int Cout, float scale, float slope,

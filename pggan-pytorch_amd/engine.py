@@ -636,9 +636,22 @@ def generator_forward(G, z, save=False, out=None, pair_out=None):
         blk = G.blocks[i]
         H *= 2
         a1, ra1 = layer(h, blk.c1, H, ups=True)                               # upsample fused into the conv
-        a2, ra2 = layer(a1, blk.c2, H)
+        img = None
+        if (i == depth - 1 and FUSE_TORGB and alpha >= 1.0 and pair_out is None and blk.c2.pixelnorm and blk.c2.ksize == 3 and a1.is_cuda
+                and _wino(blk.c2, N, H, blk.c2.conv.weight.shape[2]) is None):
+            t = blk.toRGB                          # the last conv writes the image too (toRGB in its epilogue: the 1024^2 stage)
+            try:
+                a2, ra2, img = ops.conv2d_pixelnorm_torgb(a1, blk.c2.conv.weight.data, blk.c2.conv.bias.data, t.conv.weight.data, t.conv.bias.data,
+                                                          N, C, H, H, blk.c2.c, blk.c2.slope, t.c, blk.c2.eps, out=out)
+            except ops.Unsupported:
+                FALLBACKS['toRGB in the epilogue %dx%d' % (H, H)] += 1
+                img = None
+        if img is None:
+            a2, ra2 = layer(a1, blk.c2, H)
         ctx['recs'].append(dict(blk=blk, inp=h, a1=a1, r1=ra1, a2=a2, r2=ra2, H=H))
         hprev, h = h, a2
+    if img is not None:
+        return (img, ctx) if save else img
     t = G.blocks[depth - 1].toRGB
     prev = None
     if alpha < 1.0:                                                           # :131-135
@@ -764,6 +777,7 @@ def _mbstd_bwd(D, gy, x, stats, cp, apply_mask, mask_slope, tx=None, tstats=None
 # fromRGB layer is then needed by nobody but the block's first conv, which evaluates it in its gather from the image
 # (ops.conv2d_fromrgb: 12 B of image per pixel instead of 32 B written by one launch and read by the next; the 1024^2 stage).
 FUSE_FROMRGB = _os.environ.get('PGGAN_FUSE_FROMRGB', '1') != '0'
+FUSE_TORGB = _os.environ.get('PGGAN_FUSE_TORGB', '1') != '0'     # the generator's last conv writes the image in its epilogue (ops.conv2d_pixelnorm_torgb)
 
 
 def d_forward(D, x, groups=1, keep_input=True):

@@ -311,6 +311,19 @@ def conv2d_pixelnorm(x, w, bias, N, Hin, Win, ks, pad, scale, slope, eps=1e-8, u
     return y, r
 
 
+def conv2d_pixelnorm_torgb(x, w, bias, t_w, t_b, N, C, H, W, scale, slope, t_scale, eps=1e-8, out=None):
+    """conv2d_pixelnorm (3x3 pad 1) with the block's toRGB layer in the same epilogue.  t_w [C,Cout(,1,1)].  Returns (y, r, img
+    [N,C,H,W]); raises ops.Unsupported outside the 8 -> 8 layer of the 1024^2 stage."""
+    cout, cin = w.shape[2], w.shape[3]
+    y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    r = torch.empty((N * H * W,), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+    _lib.call('pg_conv2d_pixelnorm_torgb_nhwc', _p(x), _p(w), _p(bias), _p(y), _p(r), _p(t_w), _p(t_b), t_scale, _p(out),
+              N, C, H, W, cin, cout, scale, slope, eps, _stream())
+    return y, r, out
+
+
 def conv2d_pnbwd(x, w, ysaved, r, N, Hin, Win, ks, pad, scale, slope):
     """Backward-data conv + adjoint of the previous layer's (LeakyReLU -> PixelNorm) in one launch where possible."""
     cout, cin = w.shape[2], w.shape[3]

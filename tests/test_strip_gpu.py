@@ -249,3 +249,26 @@ def test_conv_with_fromrgb_unsupported_shapes():
     for (N, H, W, C, cm) in [(1, 32, 32, 3, 8), (1, 64, 64, 4, 8), (1, 64, 64, 3, 16)]:
         with pytest.raises(ops.Unsupported):
             ops.conv2d_fromrgb(d(rnd(N, C, H, W)), d(rnd(cm, C)), d(rnd(cm)), 1.0, 0.2, d(rnd(3, 3, 8, cm)), d(rnd(8)), N, C, H, W, 1.0, 0.2)
+
+
+@pytest.mark.parametrize('N,H,W,C', [(3, 64, 64, 3), (2, 128, 256, 3), (1, 1024, 1024, 3), (9, 32, 128, 1), (1, 16, 64, 2)])
+def test_pixelnorm_conv_with_torgb_in_the_epilogue(N, H, W, C):
+    """pg_conv2d_pixelnorm_torgb_nhwc: the generator's last conv (+ bias + LeakyReLU + PixelNorm, reference network.py:33-41) with the
+    block's toRGB layer (network.py:49, :138) in the same epilogue.  y and r exactly as pg_conv2d_pixelnorm_nhwc writes them (the same
+    kernel instantiation), the image against pg_torgb_fwd on that y (the two lanes of a pixel add their partial sums: another order of the
+    eight products, 1e-6) and against the torch statement of the three layers; the image written into a caller's buffer."""
+    x, w, b = rnd(N, H, W, 8, seed=1), rnd(3, 3, 8, 8, seed=2) * 0.2, rnd(8, seed=3) * 0.1
+    tw, tb = rnd(C, 8, seed=4) * 0.5, rnd(C, seed=5) * 0.2
+    d = lambda t: t.cuda()
+    y0, r0 = ops.conv2d_pixelnorm(d(x), d(w), d(b), N, H, W, 3, 1, 0.37, 0.2, 1e-8)
+    assert last_kernel().startswith('conv_strip_kernel<8, 8, 3'), last_kernel()
+    img0 = ops.torgb_fwd(y0, d(tw), d(tb), N, C, H, W, 0.71)
+    buf = torch.full((N + 1, C, H, W), float('nan'), device='cuda')
+    y, r, img = ops.conv2d_pixelnorm_torgb(d(x), d(w), d(b), d(tw), d(tb), N, C, H, W, 0.37, 0.2, 0.71, 1e-8, out=buf[1:])
+    assert last_kernel().startswith('conv_strip_kernel<8, 8, 3'), last_kernel()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0) and torch.equal(r, r0)
+    assert img.data_ptr() == buf[1:].data_ptr() and bool(torch.isnan(buf[0]).all())
+    assert rel_err(img, img0) < 1e-6
+    ey, er = E.conv2d_pixelnorm(x, w, b, N, H, W, 3, 1, 0.37, 0.2, 1e-8)
+    assert rel_err(img, E.torgb_fwd(ey, tw, tb, N, C, H, W, 0.71)) < 2e-5
