@@ -153,6 +153,16 @@ int pg_conv2d_pixelnorm_torgb_nhwc(const float* x, const float* w, const float* 
                                    int N, int C, int H, int W, int Cin, int Cout, float scale, float slope, float eps,
                                    pg_stream_t stream);
 
+/* The entry block's backward-data conv with fromRGB's backward-data in its epilogue (the adjoint of /root/reference/network.py:228
+ * `h = self.blocks[...](self.blocks[...].fromRGB(x))` down to the image, autograd in the reference: wgan_gp_loss.py:25-28, trainer.py:111):
+ *   gf[n][h][w][ci] = scale * conv3x3(gz, wt, pad 1) * (bit ci of mask_bytes[n][h][w] ? 1 : mask_slope)     (wt: the flipped / transposed weights of
+ *   pg_pack_dgrad_weights; written to y unless y == NULL)
+ *   gimg[n][c][h][w] = rgb_scale * sum_co rgb_w[co][c] * gf[n][h][w][co]                                      (as pg_fromrgb_bwd_data)
+ * Implemented for Cin = Cout = 8, C <= 3, W % 64 == 0, H % 16 == 0 (the 1024^2 stage); PG_E_UNSUP otherwise.                              */
+int pg_conv2d_masked_fromrgb_bwd_nhwc(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
+                                      const float* rgb_w, float rgb_scale, float* gimg,
+                                      int N, int C, int H, int W, int Cin, int Cout, float scale, pg_stream_t stream);
+
 int pg_conv2d_fromrgb_nhwc(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,
                            unsigned char* x_signs, const float* w, const float* bias, float* y, unsigned char* y_signs,
                            int N, int C, int H, int W, int Cmid, int Cout, float scale, float slope, pg_stream_t stream);

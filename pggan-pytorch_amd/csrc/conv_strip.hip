@@ -68,7 +68,9 @@ struct SArgs {
     //   x0[h][w][co] = lrelu(rgb_scale * sum_c rgb_w[co][c] * img[c][h][w] + rgb_b[co])   (never written), sign bytes of x0 -> xsigns
     const float* rgb_w; const float* rgb_b; float rgb_scale, rgb_slope; int rgbC; unsigned char* xsigns;
     // toRGB on top of the PixelNorm epilogue (pg_conv2d_pixelnorm_torgb_nhwc): t_out[n][c][h][w] = t_scale * sum_co t_w[c][co] * y[h][w][co] + t_b[c]
-    float* t_out; const float* t_w; const float* t_b; float t_scale; int tC;
+    // ... or, on top of the masked form (pg_conv2d_masked_fromrgb_bwd_nhwc: the entry block's backward-data conv), fromRGB's backward-data:
+    //   t_out[n][c][h][w] = t_scale * sum_co t_w[co][c] * y[h][w][co];  element (c, co) of t_w at t_w[c * t_sc + co * t_sco]; t_only: y itself is not written
+    float* t_out; const float* t_w; const float* t_b; float t_scale; int tC, t_sc, t_sco, t_only;
 };
 
 template <int CIN> struct Blk {
@@ -302,7 +304,8 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     const bool has_signs = (GEN || EPI == EPI_FWD) && p.ysigns;
     const bool has_pool = GEN && p.ypool;
     const bool y_bytes = GEN && p.y_bytes;
-    const bool y_store = !(has_pool && p.pool_only) && !y_bytes;
+    const bool has_trgb = (EPI == EPI_PN || EPI == EPI_MASK) && p.t_out != nullptr;
+    const bool y_store = !(has_pool && p.pool_only) && !y_bytes && !(has_trgb && p.t_only);
     const __amdgpu_buffer_rsrc_t ry = y_bytes ? pg_make_rsrc((const unsigned char*)p.y + (size_t)n * npix * (COUT / 4), npix * (COUT / 4))
                                               : pg_make_rsrc(p.y + (size_t)n * npix * COUT, npix * COUT * 4u);
     __amdgpu_buffer_rsrc_t rmask = ry, rsig = ry, rpnr = ry, rpnby = ry, rpnbr = ry;
@@ -318,7 +321,6 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!has_mask && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + 4 * qo);
     // toRGB behind the PixelNorm (round 6): the lane's four couts x the image channels; the QO lanes of a pixel add their partial sums
-    const bool has_trgb = EPI == EPI_PN && p.t_out != nullptr;
     float tw[RGB_MAXC][4], tb[RGB_MAXC];
     __amdgpu_buffer_rsrc_t rtout = ry;
     if (has_trgb) {
@@ -326,7 +328,7 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
 #pragma unroll
         for (int c = 0; c < RGB_MAXC; ++c) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tw[c][k] = c < p.tC ? p.t_w[c * COUT + 4 * qo + k] : 0.f;
+            for (int k = 0; k < 4; ++k) tw[c][k] = c < p.tC ? p.t_w[c * p.t_sc + (4 * qo + k) * p.t_sco] : 0.f;
             tb[c] = (c < p.tC && p.t_b) ? p.t_b[c] : 0.f;
         }
     }
@@ -428,15 +430,15 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
                 const float rr = rsqrtf(ssq / (float)COUT + p.pn_eps);
                 o.x *= rr; o.y *= rr; o.z *= rr; o.w *= rr;
                 if (qo == 0 && !(PG_STRIP_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rr), rpnr, (int)(pg_ * 4u), 0, 0);
-                if (has_trgb) {                          // (workgroup-uniform)
+            }
+            if (has_trgb) {                              // (workgroup-uniform) the 1x1 RGB layer on the finished value: toRGB / fromRGB's backward-data
 #pragma unroll
-                    for (int c = 0; c < RGB_MAXC; ++c) {
-                        if (c >= p.tC) break;
-                        float a = fmaf(o.w, tw[c][3], fmaf(o.z, tw[c][2], fmaf(o.y, tw[c][1], o.x * tw[c][0])));
-                        a += __shfl_xor(a, 4, 64);
-                        if (QO >= 4) a += __shfl_xor(a, 8, 64);
-                        if (qo == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(a, p.t_scale, tb[c])), rtout, (int)(((unsigned)c * npix + pg_) * 4u), 0, 0);
-                    }
+                for (int c = 0; c < RGB_MAXC; ++c) {
+                    if (c >= p.tC) break;
+                    float a = fmaf(o.w, tw[c][3], fmaf(o.z, tw[c][2], fmaf(o.y, tw[c][1], o.x * tw[c][0])));
+                    a += __shfl_xor(a, 4, 64);
+                    if (QO >= 4) a += __shfl_xor(a, 8, 64);
+                    if (qo == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(a, p.t_scale, tb[c])), rtout, (int)(((unsigned)c * npix + pg_) * 4u), 0, 0);
                 }
             }
             if (!(PG_STRIP_ABL & 2)) {
@@ -476,16 +478,23 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     if (has_signs) nstores += G;
     if (has_pn) nstores += G;
     if (has_pool) nstores += GPR;
+    if (has_trgb) nstores += G * p.tC;
     if (PG_STRIP_ABL & 2) nstores = 0;
     nstores = __builtin_amdgcn_readfirstlane(nstores);
     auto wait_dma = [&]() {
-        if constexpr (EPI == EPI_MASK || EPI == EPI_PNB) { static_assert(G == 2, ""); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-        else if constexpr (EPI == EPI_PN) {
+        if constexpr (EPI == EPI_MASK || EPI == EPI_PNB || EPI == EPI_PN) {
             static_assert(G == 2, "");
-            if (!has_trgb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  // (+ G stores per image channel of the toRGB output)
-            else if (p.tC == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (p.tC == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (!has_trgb) {
+                if constexpr (EPI == EPI_PN) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else switch (nstores) {                      // (+ G stores per image channel of the RGB output, - G when y itself stays unwritten)
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
         }
         else switch (nstores) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -872,8 +881,27 @@ int pgk::launch_conv_strip_pn_torgb(const float* x, const float* w, const float*
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.pn_r = r; a.pn_eps = eps;
     a.scale = scale; a.slope = slope; a.mask_slope = 1.f; a.pool_a = 1.f;
     a.H = H; a.W = W; a.strips = W / SW; a.segs = H / seg; a.seg_rows = seg;
-    a.t_out = img; a.t_w = t_w; a.t_b = t_b; a.t_scale = t_scale; a.tC = C;
+    a.t_out = img; a.t_w = t_w; a.t_b = t_b; a.t_scale = t_scale; a.tC = C; a.t_sc = Cout; a.t_sco = 1;
     return wreg_env ? launch_strip<8, 8, EPI_PN, true>(a, N, s, name, name_len) : launch_strip<8, 8, EPI_PN, false>(a, N, s, name, name_len);
+}
+
+int pgk::launch_conv_strip_masked_rgb_bwd(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
+                                          const float* rgb_w, float rgb_scale, float* gimg,
+                                          int N, int C, int H, int W, int Cin, int Cout, float scale,
+                                          hipStream_t s, char* name, size_t name_len)
+{
+    static const int wreg_env = getenv("PG_STRIP_WREG") ? atoi(getenv("PG_STRIP_WREG")) : 1;
+    if (C < 1 || C > RGB_MAXC || Cin != 8 || Cout != 8 || (W % SW) || (H % 16)) return PG_E_UNSUP;
+    if ((long long)H * W * 16 * 4 >= (1ll << 31)) return PG_E_UNSUP;
+    int seg = 64;                                                                // (as launch_conv_strip)
+    while (seg > 16 && ((long long)N * (W / SW) * (H / seg) < 768 || (H % seg))) seg >>= 1;
+    if (seg < 16 || (seg % RB) || (H % seg)) return PG_E_UNSUP;
+    SArgs a{};
+    a.x = gz; a.w = wt; a.mask = mask_bytes; a.mask_bytes = 1; a.y = y;
+    a.scale = scale; a.slope = 1.f; a.mask_slope = mask_slope; a.pool_a = 1.f;
+    a.H = H; a.W = W; a.strips = W / SW; a.segs = H / seg; a.seg_rows = seg;
+    a.t_out = gimg; a.t_w = rgb_w; a.t_b = nullptr; a.t_scale = rgb_scale; a.tC = C; a.t_sc = 1; a.t_sco = C; a.t_only = y ? 0 : 1;
+    return wreg_env ? launch_strip<8, 8, EPI_MASK, true>(a, N, s, name, name_len) : launch_strip<8, 8, EPI_MASK, false>(a, N, s, name, name_len);
 }
 
 int pgk::launch_wgrad_strip(WgP& p, hipStream_t s, char* name, size_t name_len)

@@ -68,6 +68,10 @@ int launch_conv_strip_pn_torgb(const float* x, const float* w, const float* bias
                                const float* t_w, const float* t_b, float t_scale, float* img,
                                int N, int C, int H, int W, int Cin, int Cout, float scale, float slope, float eps,
                                hipStream_t s, char* name, size_t name_len);
+int launch_conv_strip_masked_rgb_bwd(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
+                                     const float* rgb_w, float rgb_scale, float* gimg,
+                                     int N, int C, int H, int W, int Cin, int Cout, float scale,
+                                     hipStream_t s, char* name, size_t name_len);
 int launch_conv_strip_fromrgb(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,
                               unsigned char* x_signs, const float* w, const float* bias, float* y, unsigned char* y_signs,
                               int N, int C, int H, int W, int Cmid, int Cout, float scale, float slope,

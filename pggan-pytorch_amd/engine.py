@@ -777,6 +777,7 @@ def _mbstd_bwd(D, gy, x, stats, cp, apply_mask, mask_slope, tx=None, tstats=None
 # fromRGB layer is then needed by nobody but the block's first conv, which evaluates it in its gather from the image
 # (ops.conv2d_fromrgb: 12 B of image per pixel instead of 32 B written by one launch and read by the next; the 1024^2 stage).
 FUSE_FROMRGB = _os.environ.get('PGGAN_FUSE_FROMRGB', '1') != '0'
+FUSE_FROMRGB_BWD = _os.environ.get('PGGAN_FUSE_FROMRGB_BWD', '1') != '0'      # fromRGB's backward-data in the epilogue of the entry block's backward-data conv (ops.conv2d_masked_fromrgb_bwd)
 FUSE_TORGB = _os.environ.get('PGGAN_FUSE_TORGB', '1') != '0'     # the generator's last conv writes the image in its epilogue (ops.conv2d_pixelnorm_torgb)
 
 
@@ -1002,6 +1003,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
         ops.linear1_wgrad(gscore, a2[:nh], D._lin_gw, D._lin_gb)
     g = ops.linear1_bwd_data(gscore, D.linear.weight.data, a2[:nh], (nh,) + tuple(a2.shape[1:]), lc2.slope)
     gimg = None
+    gimg_fused = False                           # the entry block's backward-data conv wrote the image gradient itself
     pending_prev = None
     carry = None
     for idx in range(len(recs) - 1, -1, -1):
@@ -1067,7 +1069,19 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                     g_fused = _dgrad_unpool(D, gz1, c1, NB, H, pv['a2'], 1.0, pv['blk'].c2.slope)
                 gin = None
             else:
-                gin = _dgrad(D, gz1, c1, NB, H, mask=(rec['inp'], rec.get('inpb')) if rec['first'] else None, mask_slope=fr_slope)
+                gin = None
+                if (rec['first'] and want_gimg and FUSE_FROMRGB_BWD and rec.get('inpb') is not None and x.is_cuda and c1.ksize == 3 and c1.pad == 1
+                        and _wino(c1, NB, H, c1.conv.weight.shape[3], transposed=True) is None):
+                    # the entry block's backward-data conv hands the IMAGE gradient on as well (fromRGB's backward-data in its epilogue); the
+                    # 8-channel gradient itself is written only when somebody reads it afterwards (fromRGB's weight gradient, the tangent term)
+                    try:
+                        gin, gimg = ops.conv2d_masked_fromrgb_bwd(gz1, _wt(D, c1), rec['inpb'], fr_slope, blk.fromRGB.conv.weight.data,
+                                                                  blk.fromRGB.c, NB, C, H, H, c1.c, keep_gf=full or save_adjoints)
+                        gimg_fused = True
+                    except ops.Unsupported:
+                        FALLBACKS['fromRGB adjoint in the epilogue %dx%d' % (H, H)] += 1
+                if not gimg_fused:
+                    gin = _dgrad(D, gz1, c1, NB, H, mask=(rec['inp'], rec.get('inpb')) if rec['first'] else None, mask_slope=fr_slope)
             if save_adjoints:
                 adj[idx].update(gz2=gz2, gz1=gz1)
         if rec['first']:
@@ -1079,8 +1093,9 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                 with (_on_main if tail >= 1 else _on_side)(gf, x):
                     ops.fromrgb_wgrad(gf, x, fr._gw, fr._gb, NB, C, H, H, fr.c)
             if want_gimg:
-                gimg = torch.empty_like(x)
-                ops.fromrgb_bwd_data(gf, fr.conv.weight.data, gimg, NB, C, H, H, fr.c)
+                if not gimg_fused:
+                    gimg = torch.empty_like(x)
+                    ops.fromrgb_bwd_data(gf, fr.conv.weight.data, gimg, NB, C, H, H, fr.c)
                 if pending_prev is not None:
                     gpf, pfr = pending_prev
                     ops.fromrgb_bwd_data(gpf, pfr.conv.weight.data, gimg, NB, C, H // 2, H // 2, pfr.c,

@@ -272,3 +272,32 @@ def test_pixelnorm_conv_with_torgb_in_the_epilogue(N, H, W, C):
     assert rel_err(img, img0) < 1e-6
     ey, er = E.conv2d_pixelnorm(x, w, b, N, H, W, 3, 1, 0.37, 0.2, 1e-8)
     assert rel_err(img, E.torgb_fwd(ey, tw, tb, N, C, H, W, 0.71)) < 2e-5
+
+
+@pytest.mark.parametrize('N,H,W,C', [(3, 64, 64, 3), (2, 128, 256, 3), (1, 1024, 1024, 3), (9, 32, 128, 1), (1, 16, 64, 2)])
+@pytest.mark.parametrize('keep', [True, False])
+def test_masked_backward_conv_with_fromrgb_adjoint_in_the_epilogue(N, H, W, C, keep):
+    """pg_conv2d_masked_fromrgb_bwd_nhwc: the entry block's backward-data conv (x LeakyReLU' from sign bytes) with fromRGB's backward-data
+    (the adjoint of reference network.py:145) in the same epilogue.  The 8-channel gradient exactly as pg_conv2d_nhwc writes it (same
+    kernel instantiation) -- or not written at all (``keep=False``) --, the image gradient against pg_fromrgb_bwd_data on it and against
+    the torch statement of the two steps."""
+    gz, wt = rnd(N, H, W, 8, seed=1), rnd(3, 3, 8, 8, seed=2) * 0.2
+    m = rnd(N, H, W, 8, seed=3)
+    rw = rnd(8, C, seed=4) * 0.5
+    d = lambda t: t.cuda()
+    mb = E.signbytes_of(m)
+    gf0 = ops.conv2d(d(gz), d(wt), None, N, H, W, 3, 1, 0.37, 1.0, mask=d(mb), mask_slope=0.2)
+    assert last_kernel().startswith('conv_strip_kernel<8, 8, 2'), last_kernel()
+    gi0 = torch.empty(N, C, H, W, device='cuda')
+    ops.fromrgb_bwd_data(gf0, d(rw), gi0, N, C, H, W, 0.61)
+    gf, gi = ops.conv2d_masked_fromrgb_bwd(d(gz), d(wt), d(mb), 0.2, d(rw), 0.61, N, C, H, W, 0.37, keep_gf=keep)
+    assert last_kernel().startswith('conv_strip_kernel<8, 8, 2'), last_kernel()
+    torch.cuda.synchronize()
+    assert (gf is None) == (not keep)
+    if keep:
+        assert torch.equal(gf, gf0)
+    assert rel_err(gi, gi0) < 1e-6
+    egf = E.conv2d(gz, wt, None, N, H, W, 3, 1, 0.37, mask=m, mask_slope=0.2)
+    egi = torch.zeros(N, C, H, W)
+    E.fromrgb_bwd_data(egf, rw, egi, N, C, H, W, 0.61)
+    assert rel_err(gi, egi) < 2e-5
