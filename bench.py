@@ -158,7 +158,7 @@ CONV_ENTRY = {
     'pg_conv2d_unpooled_nhwc': (7, 8, 9, 10, 11, None, None, 'conv', 'pool adjoint in the gather'),
     'pg_conv2d_wgrad_unpooled_nhwc': (7, 8, 9, 10, 11, None, None, 'conv', 'wgrad, pool adjoint in the gather'),
     'pg_conv2d_pixelnorm_torgb_nhwc': (9, 11, 12, 13, 14, None, None, 'conv', '+pixelnorm +toRGB'),
-    'pg_conv2d_masked_fromrgb_bwd_nhwc': (8, 10, 11, 12, 13, None, None, 'conv', 'masked +fromRGB adjoint'),
+    'pg_conv2d_masked_fromrgb_bwd_nhwc': (11, 13, 14, 15, 16, None, None, 'conv', 'masked +fromRGB adjoint / wgrad'),
     'pg_conv2d_fromrgb_nhwc': (10, 12, 13, 14, 15, None, None, 'conv', 'fromRGB in the gather'),
     'pg_conv2d_wino_nhwc': (13, 14, 15, 16, 17, None, None, 'wino', 'winograd'),
     'pg_conv2d_wino_pixelnorm_nhwc': (5, 6, 7, 8, 9, None, None, 'wino', 'winograd +pixelnorm'),

@@ -157,10 +157,13 @@ int pg_conv2d_pixelnorm_torgb_nhwc(const float* x, const float* w, const float* 
  * `h = self.blocks[...](self.blocks[...].fromRGB(x))` down to the image, autograd in the reference: wgan_gp_loss.py:25-28, trainer.py:111):
  *   gf[n][h][w][ci] = scale * conv3x3(gz, wt, pad 1) * (bit ci of mask_bytes[n][h][w] ? 1 : mask_slope)     (wt: the flipped / transposed weights of
  *   pg_pack_dgrad_weights; written to y unless y == NULL)
- *   gimg[n][c][h][w] = rgb_scale * sum_co rgb_w[co][c] * gf[n][h][w][co]                                      (as pg_fromrgb_bwd_data)
- * Implemented for Cin = Cout = 8, C <= 3, W % 64 == 0, H % 16 == 0 (the 1024^2 stage); PG_E_UNSUP otherwise.                              */
+ *   gimg[n][c][h][w] = rgb_scale * sum_co rgb_w[co][c] * gf[n][h][w][co]                 (gimg != NULL; as pg_fromrgb_bwd_data)
+ *   rgb_dw[co][c] += rgb_scale * sum_{n,h,w} gf[n][h][w][co] * img[n][c][h][w],  rgb_db[co] += sum gf   (rgb_dw != NULL; as pg_fromrgb_wgrad:
+ *   fromRGB's weight gradient of trainer.py:98, one commit of atomics per workgroup)
+ * At least one of gimg / rgb_dw.  Implemented for Cin = Cout = 8, C <= 3, W % 64 == 0, H % 16 == 0 (the 1024^2 stage); PG_E_UNSUP otherwise. */
 int pg_conv2d_masked_fromrgb_bwd_nhwc(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
                                       const float* rgb_w, float rgb_scale, float* gimg,
+                                      const float* img, float* rgb_dw, float* rgb_db,
                                       int N, int C, int H, int W, int Cin, int Cout, float scale, pg_stream_t stream);
 
 int pg_conv2d_fromrgb_nhwc(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,

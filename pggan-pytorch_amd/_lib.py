@@ -34,7 +34,7 @@ SIGNATURES = {
     'pg_conv2d_unpooled_nhwc': [P, P, P, F, F, P, P, I, I, I, I, I, I, F, F, P],
     'pg_conv2d_wgrad_unpooled_nhwc': [P, P, P, F, F, P, P, I, I, I, I, I, F, P],
     'pg_conv2d_pixelnorm_torgb_nhwc': [P, P, P, P, P, P, P, F, P, I, I, I, I, I, I, F, F, F, P],
-    'pg_conv2d_masked_fromrgb_bwd_nhwc': [P, P, P, F, P, P, F, P, I, I, I, I, I, I, F, P],
+    'pg_conv2d_masked_fromrgb_bwd_nhwc': [P, P, P, F, P, P, F, P, P, P, P, I, I, I, I, I, I, F, P],
     'pg_conv2d_fromrgb_nhwc': [P, P, P, F, F, P, P, P, P, P, I, I, I, I, I, I, F, F, P],
     'pg_wino_transform_weights': [P, P, I, I, P],
     'pg_wino_transform_weights_batched': [P, P, I, P, P, P, P, P, P],

@@ -2205,13 +2205,17 @@ extern "C" int pg_conv2d_pixelnorm_torgb_nhwc(const float* x, const float* w, co
 // The entry block's backward-data conv (adjoint of c1, x LeakyReLU' of fromRGB's output from its sign bytes) with fromRGB's own
 // backward-data (the adjoint of the 1x1 conv of network.py:145) in the same epilogue: the gradient with respect to the IMAGE leaves
 // with -- or, y == NULL, instead of -- the 8-channel gradient gf, which only fromRGB's weight gradient reads afterwards.
+// Also (img, rgb_dw[, rgb_db] given): fromRGB's WEIGHT gradient accumulated in the same epilogue (one commit per workgroup) -- in the batched
+// adjoint sweep nobody else reads the 8-channel gradient, so it is not written at all there (y == NULL).
 extern "C" int pg_conv2d_masked_fromrgb_bwd_nhwc(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
                                                  const float* rgb_w, float rgb_scale, float* gimg,
+                                                 const float* img, float* rgb_dw, float* rgb_db,
                                                  int N, int C, int H, int W, int Cin, int Cout, float scale, pg_stream_t stream)
 {
-    if (!gz || !wt || !mask_bytes || !rgb_w || !gimg || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
-    return pgk::launch_conv_strip_masked_rgb_bwd(gz, wt, mask_bytes, mask_slope, y, rgb_w, rgb_scale, gimg, N, C, H, W, Cin, Cout, scale,
-                                                 (hipStream_t)stream, g_last_kernel, sizeof(g_last_kernel));
+    if (!gz || !wt || !mask_bytes || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return PG_E_ARG;
+    if ((!gimg && !rgb_dw) || (gimg && !rgb_w) || (rgb_dw && !img) || (rgb_db && !rgb_dw)) return PG_E_ARG;
+    return pgk::launch_conv_strip_masked_rgb_bwd(gz, wt, mask_bytes, mask_slope, y, rgb_w, rgb_scale, gimg, img, rgb_dw, rgb_db,
+                                                 N, C, H, W, Cin, Cout, scale, (hipStream_t)stream, g_last_kernel, sizeof(g_last_kernel));
 }
 
 extern "C" const char* pg_debug_last_conv_kernel(void) { return g_last_kernel; }

@@ -71,6 +71,9 @@ struct SArgs {
     // ... or, on top of the masked form (pg_conv2d_masked_fromrgb_bwd_nhwc: the entry block's backward-data conv), fromRGB's backward-data:
     //   t_out[n][c][h][w] = t_scale * sum_co t_w[co][c] * y[h][w][co];  element (c, co) of t_w at t_w[c * t_sc + co * t_sco]; t_only: y itself is not written
     float* t_out; const float* t_w; const float* t_b; float t_scale; int tC, t_sc, t_sco, t_only;
+    // ... and fromRGB's WEIGHT gradient accumulated over the workgroup's pixels (one commit of 8 x (C + 1) atomics per workgroup):
+    //   fw_dw[co][c] += fw_scale * sum_pixels y[co] * fw_img[c],  fw_db[co] += sum_pixels y[co]      (y = the masked result, as above)
+    const float* fw_img; float* fw_dw; float* fw_db; float fw_scale;
 };
 
 template <int CIN> struct Blk {
@@ -305,7 +308,8 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     const bool has_pool = GEN && p.ypool;
     const bool y_bytes = GEN && p.y_bytes;
     const bool has_trgb = (EPI == EPI_PN || EPI == EPI_MASK) && p.t_out != nullptr;
-    const bool y_store = !(has_pool && p.pool_only) && !y_bytes && !(has_trgb && p.t_only);
+    const bool has_fw = EPI == EPI_MASK && COUT == 8 && p.fw_dw != nullptr;
+    const bool y_store = !(has_pool && p.pool_only) && !y_bytes && !((has_trgb || has_fw) && p.t_only);
     const __amdgpu_buffer_rsrc_t ry = y_bytes ? pg_make_rsrc((const unsigned char*)p.y + (size_t)n * npix * (COUT / 4), npix * (COUT / 4))
                                               : pg_make_rsrc(p.y + (size_t)n * npix * COUT, npix * COUT * 4u);
     __amdgpu_buffer_rsrc_t rmask = ry, rsig = ry, rpnr = ry, rpnby = ry, rpnbr = ry;
@@ -322,6 +326,15 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     if (!has_mask && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + 4 * qo);
     // toRGB behind the PixelNorm (round 6): the lane's four couts x the image channels; the QO lanes of a pixel add their partial sums
     float tw[RGB_MAXC][4], tb[RGB_MAXC];
+    float aw[4][RGB_MAXC], ab[4], fi[G][RGB_MAXC];               // fromRGB weight gradient: this lane's four couts x image channels, bias sums; the step's image values
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ab[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c) aw[k][c] = 0.f;
+    }
+    __amdgpu_buffer_rsrc_t rfimg = ry;
+    if (has_fw) rfimg = pg_make_rsrc(p.fw_img + (size_t)n * npix * p.tC, npix * (unsigned)p.tC * 4u);
     __amdgpu_buffer_rsrc_t rtout = ry;
     if (has_trgb) {
         rtout = pg_make_rsrc(p.t_out + (size_t)n * npix * p.tC, npix * (unsigned)p.tC * 4u);
@@ -379,6 +392,11 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const unsigned pg_ = pix + (unsigned)((g / GPR) * p.W + (g % GPR) * PXG);
+            if (has_fw) {
+#pragma unroll
+                for (int c = 0; c < RGB_MAXC; ++c)
+                    fi[g][c] = c < p.tC ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rfimg, (int)(((unsigned)c * npix + pg_) * 4u), 0, 0)) : 0.f;
+            }
             if (has_mask) {
                 if (mask_bytes) pmb[g] = __builtin_amdgcn_raw_buffer_load_b8(rmask, (int)(pg_ * (COUT / 4) + qo), 0, 0);
                 else pm[g] = pg_buf_load4(rmask, (pg_ * COUT + 4 * qo) * 4u, 0);
@@ -430,6 +448,15 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
                 const float rr = rsqrtf(ssq / (float)COUT + p.pn_eps);
                 o.x *= rr; o.y *= rr; o.z *= rr; o.w *= rr;
                 if (qo == 0 && !(PG_STRIP_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rr), rpnr, (int)(pg_ * 4u), 0, 0);
+            }
+            if (has_fw) {                                // (workgroup-uniform) fromRGB's weight / bias gradient: partial sums over this lane's pixels
+                const float ov4[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ab[k] += ov4[k];
+#pragma unroll
+                    for (int c = 0; c < RGB_MAXC; ++c) aw[k][c] = fmaf(ov4[k], fi[g][c], aw[k][c]);
+                }
             }
             if (has_trgb) {                              // (workgroup-uniform) the 1x1 RGB layer on the finished value: toRGB / fromRGB's backward-data
 #pragma unroll
@@ -484,7 +511,7 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     auto wait_dma = [&]() {
         if constexpr (EPI == EPI_MASK || EPI == EPI_PNB || EPI == EPI_PN) {
             static_assert(G == 2, "");
-            if (!has_trgb) {
+            if (!has_trgb && !has_fw) {
                 if constexpr (EPI == EPI_PN) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else switch (nstores) {                      // (+ G stores per image channel of the RGB output, - G when y itself stays unwritten)
@@ -530,6 +557,37 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
         step(it, std::integral_constant<int, 0>{});
         if (it + 1 < niter) step(it + 1, std::integral_constant<int, 1>{});
         if (it + 2 < niter) step(it + 2, std::integral_constant<int, 2>{});
+    }
+    if (has_fw) {
+        // lane = [qp : 3][qo : 1][j : 2] (QO = 2): fold the lanes of one cout quad (bits 0-1, 3-5), then the four waves through LDS (the ring is
+        // free after the barrier), one atomic per output and workgroup (as fromrgb_wgrad_small_kernel)
+        static_assert(COUT != 8 || QO == 2, "");
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int c = 0; c < RGB_MAXC; ++c) v[4 * k + c] = aw[k][c];
+            v[4 * k + 3] = ab[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float a = v[i];
+            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            v[i] = a;
+        }
+        __syncthreads();
+        if ((lane & ~4) == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds[(wave * 2 + (lane >> 2)) * 16 + i] = v[i];
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int q2 = tid >> 4, i = tid & 15, k = i >> 2, c = i & 3;
+            const float a = (lds[(0 * 2 + q2) * 16 + i] + lds[(1 * 2 + q2) * 16 + i]) + (lds[(2 * 2 + q2) * 16 + i] + lds[(3 * 2 + q2) * 16 + i]);
+            const int co = 4 * q2 + k;
+            if (c < 3) { if (c < p.tC) atomicAdd(p.fw_dw + co * p.tC + c, a * p.fw_scale); }
+            else if (p.fw_db) atomicAdd(p.fw_db + co, a);
+        }
     }
 }
 
@@ -887,10 +945,13 @@ int pgk::launch_conv_strip_pn_torgb(const float* x, const float* w, const float*
 
 int pgk::launch_conv_strip_masked_rgb_bwd(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
                                           const float* rgb_w, float rgb_scale, float* gimg,
+                                          const float* img, float* rgb_dw, float* rgb_db,
                                           int N, int C, int H, int W, int Cin, int Cout, float scale,
                                           hipStream_t s, char* name, size_t name_len)
 {
-    static const int wreg_env = getenv("PG_STRIP_WREG") ? atoi(getenv("PG_STRIP_WREG")) : 1;
+    // (with the weight gradient's 16 accumulators the register-weights form would drop to two waves per SIMD: weights in LDS then)
+    static const int wreg_env0 = getenv("PG_STRIP_WREG") ? atoi(getenv("PG_STRIP_WREG")) : 1;
+    const int wreg_env = rgb_dw ? 0 : wreg_env0;
     if (C < 1 || C > RGB_MAXC || Cin != 8 || Cout != 8 || (W % SW) || (H % 16)) return PG_E_UNSUP;
     if ((long long)H * W * 16 * 4 >= (1ll << 31)) return PG_E_UNSUP;
     int seg = 64;                                                                // (as launch_conv_strip)
@@ -901,6 +962,7 @@ int pgk::launch_conv_strip_masked_rgb_bwd(const float* gz, const float* wt, cons
     a.scale = scale; a.slope = 1.f; a.mask_slope = mask_slope; a.pool_a = 1.f;
     a.H = H; a.W = W; a.strips = W / SW; a.segs = H / seg; a.seg_rows = seg;
     a.t_out = gimg; a.t_w = rgb_w; a.t_b = nullptr; a.t_scale = rgb_scale; a.tC = C; a.t_sc = 1; a.t_sco = C; a.t_only = y ? 0 : 1;
+    a.fw_img = img; a.fw_dw = rgb_dw; a.fw_db = rgb_db; a.fw_scale = rgb_scale;
     return wreg_env ? launch_strip<8, 8, EPI_MASK, true>(a, N, s, name, name_len) : launch_strip<8, 8, EPI_MASK, false>(a, N, s, name, name_len);
 }
 

@@ -70,6 +70,7 @@ int launch_conv_strip_pn_torgb(const float* x, const float* w, const float* bias
                                hipStream_t s, char* name, size_t name_len);
 int launch_conv_strip_masked_rgb_bwd(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
                                      const float* rgb_w, float rgb_scale, float* gimg,
+                                     const float* img, float* rgb_dw, float* rgb_db,
                                      int N, int C, int H, int W, int Cin, int Cout, float scale,
                                      hipStream_t s, char* name, size_t name_len);
 int launch_conv_strip_fromrgb(const float* img, const float* rgb_w, const float* rgb_b, float rgb_scale, float rgb_slope,

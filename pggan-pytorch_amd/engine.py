@@ -778,6 +778,7 @@ def _mbstd_bwd(D, gy, x, stats, cp, apply_mask, mask_slope, tx=None, tstats=None
 # (ops.conv2d_fromrgb: 12 B of image per pixel instead of 32 B written by one launch and read by the next; the 1024^2 stage).
 FUSE_FROMRGB = _os.environ.get('PGGAN_FUSE_FROMRGB', '1') != '0'
 FUSE_FROMRGB_BWD = _os.environ.get('PGGAN_FUSE_FROMRGB_BWD', '1') != '0'      # fromRGB's backward-data in the epilogue of the entry block's backward-data conv (ops.conv2d_masked_fromrgb_bwd)
+FUSE_FROMRGB_WGRAD = _os.environ.get('PGGAN_FUSE_FROMRGB_WGRAD', '1') != '0'  # ... and fromRGB's weight gradient (the batched adjoint sweep: the 8-channel gradient is then never written)
 FUSE_TORGB = _os.environ.get('PGGAN_FUSE_TORGB', '1') != '0'     # the generator's last conv writes the image in its epilogue (ops.conv2d_pixelnorm_torgb)
 
 
@@ -1003,7 +1004,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
         ops.linear1_wgrad(gscore, a2[:nh], D._lin_gw, D._lin_gb)
     g = ops.linear1_bwd_data(gscore, D.linear.weight.data, a2[:nh], (nh,) + tuple(a2.shape[1:]), lc2.slope)
     gimg = None
-    gimg_fused = False                           # the entry block's backward-data conv wrote the image gradient itself
+    gimg_fused = fw_fused = False                # the entry block's backward-data conv wrote the image gradient / accumulated fromRGB's weight gradient itself
     pending_prev = None
     carry = None
     for idx in range(len(recs) - 1, -1, -1):
@@ -1070,14 +1071,21 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
                 gin = None
             else:
                 gin = None
-                if (rec['first'] and want_gimg and FUSE_FROMRGB_BWD and rec.get('inpb') is not None and x.is_cuda and c1.ksize == 3 and c1.pad == 1
+                # fromRGB's weight gradient rides in the same epilogue when the sweep asks for weight gradients -- not under a bucketed
+                # gradient exchange, whose flushes wait for the weight-gradient stream only (as the tail launches on the main stream)
+                fw = full and FUSE_FROMRGB_WGRAD and getattr(D, '_grad_hook', None) is None
+                if (rec['first'] and (want_gimg or fw) and FUSE_FROMRGB_BWD and rec.get('inpb') is not None and x.is_cuda and c1.ksize == 3 and c1.pad == 1
                         and _wino(c1, NB, H, c1.conv.weight.shape[3], transposed=True) is None):
                     # the entry block's backward-data conv hands the IMAGE gradient on as well (fromRGB's backward-data in its epilogue); the
-                    # 8-channel gradient itself is written only when somebody reads it afterwards (fromRGB's weight gradient, the tangent term)
+                    # 8-channel gradient itself is written only when somebody reads it afterwards (the tangent term of the gradient penalty)
+                    fr0 = blk.fromRGB
                     try:
-                        gin, gimg = ops.conv2d_masked_fromrgb_bwd(gz1, _wt(D, c1), rec['inpb'], fr_slope, blk.fromRGB.conv.weight.data,
-                                                                  blk.fromRGB.c, NB, C, H, H, c1.c, keep_gf=full or save_adjoints)
-                        gimg_fused = True
+                        gin, gi = ops.conv2d_masked_fromrgb_bwd(gz1, _wt(D, c1), rec['inpb'], fr_slope, fr0.conv.weight.data, fr0.c, NB, C, H, H, c1.c,
+                                                                keep_gf=save_adjoints or (full and not fw), want_gimg=want_gimg,
+                                                                img=x if fw else None, rgb_dw=fr0._gw if fw else None, rgb_db=fr0._gb if fw else None)
+                        if want_gimg:
+                            gimg = gi
+                        gimg_fused, fw_fused = True, fw
                     except ops.Unsupported:
                         FALLBACKS['fromRGB adjoint in the epilogue %dx%d' % (H, H)] += 1
                 if not gimg_fused:
@@ -1089,7 +1097,7 @@ def d_backward(D, ctx, gscore, full, want_gimg, save_adjoints=False, hvp=None):
             fr = blk.fromRGB
             if save_adjoints:
                 adj[idx]['gf'] = gf
-            if full:
+            if full and not fw_fused:
                 with (_on_main if tail >= 1 else _on_side)(gf, x):
                     ops.fromrgb_wgrad(gf, x, fr._gw, fr._gb, NB, C, H, H, fr.c)
             if want_gimg:

@@ -368,16 +368,18 @@ def conv2d_fromrgb(img, rgb_w, rgb_b, rgb_scale, rgb_slope, w, bias, N, C, H, W,
     return y, yb, xb
 
 
-def conv2d_masked_fromrgb_bwd(gz, wt, mask_bytes, mask_slope, rgb_w, rgb_scale, N, C, H, W, scale, keep_gf=True, gimg=None):
-    """Backward-data conv of a DBlock's c1 (x LeakyReLU' from the sign bytes of fromRGB's output) with fromRGB's backward-data in the
-    epilogue.  wt: flipped / transposed weights [3,3,Cin',Cout'].  Returns (gf [N,H,W,8] or None, gimg [N,C,H,W]); raises
-    ops.Unsupported outside the 8 -> 8 layer of the 1024^2 stage."""
+def conv2d_masked_fromrgb_bwd(gz, wt, mask_bytes, mask_slope, rgb_w, rgb_scale, N, C, H, W, scale, keep_gf=True, gimg=None, want_gimg=True,
+                              img=None, rgb_dw=None, rgb_db=None):
+    """Backward-data conv of a DBlock's c1 (x LeakyReLU' from the sign bytes of fromRGB's output) with fromRGB's backward-data
+    (``want_gimg``) and / or fromRGB's weight + bias gradient (``img``, ``rgb_dw``, ``rgb_db``: accumulated into) in the epilogue.
+    wt: flipped / transposed weights [3,3,Cin',Cout'].  Returns (gf [N,H,W,8] or None, gimg [N,C,H,W] or None); raises ops.Unsupported
+    outside the 8 -> 8 layer of the 1024^2 stage."""
     cout, cin = wt.shape[2], wt.shape[3]
     gf = _empty((N, H, W, cout), device=gz.device, dtype=torch.float32) if keep_gf else None
-    if gimg is None:
+    if gimg is None and want_gimg:
         gimg = torch.empty((N, C, H, W), device=gz.device, dtype=torch.float32)
     _lib.call('pg_conv2d_masked_fromrgb_bwd_nhwc', _p(gz), _p(wt), _p(mask_bytes), mask_slope, _p(gf), _p(rgb_w), rgb_scale, _p(gimg),
-              N, C, H, W, cin, cout, scale, _stream())
+              _p(img), _p(rgb_dw), _p(rgb_db), N, C, H, W, cin, cout, scale, _stream())
     return gf, gimg
 
 

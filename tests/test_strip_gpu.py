@@ -301,3 +301,37 @@ def test_masked_backward_conv_with_fromrgb_adjoint_in_the_epilogue(N, H, W, C, k
     egi = torch.zeros(N, C, H, W)
     E.fromrgb_bwd_data(egf, rw, egi, N, C, H, W, 0.61)
     assert rel_err(gi, egi) < 2e-5
+
+
+@pytest.mark.parametrize('N,H,W,C', [(3, 64, 64, 3), (2, 128, 256, 3), (1, 1024, 1024, 3), (9, 32, 128, 1), (1, 16, 64, 2)])
+@pytest.mark.parametrize('keep,want_gimg', [(False, False), (True, True), (False, True)])
+def test_masked_backward_conv_with_fromrgb_weight_gradient_in_the_epilogue(N, H, W, C, keep, want_gimg):
+    """pg_conv2d_masked_fromrgb_bwd_nhwc with (img, rgb_dw, rgb_db): fromRGB's weight and bias gradient (reference: autograd of network.py:145
+    under trainer.py:98) accumulated in the epilogue of the entry block's backward-data conv, one commit per workgroup -- against
+    pg_fromrgb_wgrad on the 8-channel gradient pg_conv2d_nhwc writes and against the torch statement; accumulates INTO dw / db; alone (the
+    batched sweep: nothing else is written), with the image gradient, with the 8-channel gradient."""
+    gz, wt = rnd(N, H, W, 8, seed=1), rnd(3, 3, 8, 8, seed=2) * 0.2
+    m, img = rnd(N, H, W, 8, seed=3), rnd(N, C, H, W, seed=6)
+    rw = rnd(8, C, seed=4) * 0.5
+    d = lambda t: t.cuda()
+    mb = E.signbytes_of(m)
+    gf0 = ops.conv2d(d(gz), d(wt), None, N, H, W, 3, 1, 0.37, 1.0, mask=d(mb), mask_slope=0.2)
+    dw0, db0 = torch.full((8, C, 1, 1), 0.25, device='cuda'), torch.full((8,), -0.5, device='cuda')
+    dw, db = dw0.clone(), db0.clone()
+    ops.fromrgb_wgrad(gf0, d(img), dw0, db0, N, C, H, W, 0.61)
+    gf, gi = ops.conv2d_masked_fromrgb_bwd(d(gz), d(wt), d(mb), 0.2, d(rw), 0.61, N, C, H, W, 0.37, keep_gf=keep, want_gimg=want_gimg,
+                                           img=d(img), rgb_dw=dw, rgb_db=db)
+    assert last_kernel().startswith('conv_strip_kernel<8, 8, 2, false'), last_kernel()
+    torch.cuda.synchronize()
+    assert (gf is None) == (not keep) and (gi is None) == (not want_gimg)
+    if keep:
+        assert same(gf, gf0)
+    assert rel_err(dw, dw0) < 2e-5 and rel_err(db, db0) < 2e-5
+    egf = E.conv2d(gz, wt, None, N, H, W, 3, 1, 0.37, mask=m, mask_slope=0.2)
+    edw, edb = torch.full((8, C), 0.25), torch.full((8,), -0.5)
+    E.fromrgb_wgrad(egf, img, edw, edb, N, C, H, W, 0.61)
+    assert rel_err(dw.view(8, C), edw) < 5e-5 and rel_err(db, edb) < 5e-5
+    if want_gimg:
+        egi = torch.zeros(N, C, H, W)
+        E.fromrgb_bwd_data(egf, rw, egi, N, C, H, W, 0.61)
+        assert rel_err(gi, egi) < 2e-5
