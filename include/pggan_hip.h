@@ -159,7 +159,7 @@ int pg_conv2d_pixelnorm_torgb_nhwc(const float* x, const float* w, const float* 
  *   pg_pack_dgrad_weights; written to y unless y == NULL)
  *   gimg[n][c][h][w] = rgb_scale * sum_co rgb_w[co][c] * gf[n][h][w][co]                 (gimg != NULL; as pg_fromrgb_bwd_data)
  *   rgb_dw[co][c] += rgb_scale * sum_{n,h,w} gf[n][h][w][co] * img[n][c][h][w],  rgb_db[co] += sum gf   (rgb_dw != NULL; as pg_fromrgb_wgrad:
- *   fromRGB's weight gradient of trainer.py:98, one commit of atomics per workgroup)
+ *   fromRGB's weight gradient of trainer.py:98, one commit of 8 * (C + 1) atomics per workgroup)
  * At least one of gimg / rgb_dw.  Implemented for Cin = Cout = 8, C <= 3, W % 64 == 0, H % 16 == 0 (the 1024^2 stage); PG_E_UNSUP otherwise. */
 int pg_conv2d_masked_fromrgb_bwd_nhwc(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
                                       const float* rgb_w, float rgb_scale, float* gimg,

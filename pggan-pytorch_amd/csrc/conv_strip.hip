@@ -105,7 +105,10 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // network.py:145 in front of :33-36): the 1x1 conv + LeakyReLU of a pixel's four channels per slot, in fromrgb_fwd_pix_kernel's
 // order of operations (bit-identical x0); 12 B of image per pixel instead of a 32 B activation written by one launch and read by this one.
 constexpr int RGB_MAXC = 3;
-template <int COUT, int CIN, int EPI, bool WREG, int GM>
+// XM: the RGB-side extras of the epilogue, compiled in only where asked for (their registers -- 12 weights, 16 + 6 for the weight gradient --
+// made the plain masked kernel spill 62 VGPRs when they were run-time options of one instantiation): bit 0 the 1x1 RGB layer on the finished
+// value (toRGB / fromRGB's backward-data), bit 1 fromRGB's weight gradient.
+template <int COUT, int CIN, int EPI, bool WREG, int GM, int XM = 0>
 __device__ __forceinline__ void conv_strip_body(const SArgs& p)
 {
     constexpr bool GATH = GM != 0;
@@ -307,8 +310,8 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
     const bool has_signs = (GEN || EPI == EPI_FWD) && p.ysigns;
     const bool has_pool = GEN && p.ypool;
     const bool y_bytes = GEN && p.y_bytes;
-    const bool has_trgb = (EPI == EPI_PN || EPI == EPI_MASK) && p.t_out != nullptr;
-    const bool has_fw = EPI == EPI_MASK && COUT == 8 && p.fw_dw != nullptr;
+    const bool has_trgb = (XM & 1) != 0 && (EPI == EPI_PN || EPI == EPI_MASK) && p.t_out != nullptr;
+    const bool has_fw = (XM & 2) != 0 && EPI == EPI_MASK && COUT == 8 && p.fw_dw != nullptr;
     const bool y_store = !(has_pool && p.pool_only) && !y_bytes && !((has_trgb || has_fw) && p.t_only);
     const __amdgpu_buffer_rsrc_t ry = y_bytes ? pg_make_rsrc((const unsigned char*)p.y + (size_t)n * npix * (COUT / 4), npix * (COUT / 4))
                                               : pg_make_rsrc(p.y + (size_t)n * npix * COUT, npix * COUT * 4u);
@@ -581,13 +584,16 @@ __device__ __forceinline__ void conv_strip_body(const SArgs& p)
             for (int i = 0; i < 16; ++i) lds[(wave * 2 + (lane >> 2)) * 16 + i] = v[i];
         }
         __syncthreads();
-        if (tid < 32) {
-            const int q2 = tid >> 4, i = tid & 15, k = i >> 2, c = i & 3;
-            const float a = (lds[(0 * 2 + q2) * 16 + i] + lds[(1 * 2 + q2) * 16 + i]) + (lds[(2 * 2 + q2) * 16 + i] + lds[(3 * 2 + q2) * 16 + i]);
-            const int co = 4 * q2 + k;
+        const int q2 = (tid >> 4) & 1, i = tid & 15, k = i >> 2, c = i & 3, co = 4 * q2 + k;
+        auto commit = [&](float a) {
             if (c < 3) { if (c < p.tC) atomicAdd(p.fw_dw + co * p.tC + c, a * p.fw_scale); }
             else if (p.fw_db) atomicAdd(p.fw_db + co, a);
-        }
+        };
+        float a = 0.f;
+        if (tid < 32) a = (lds[(0 * 2 + q2) * 16 + i] + lds[(1 * 2 + q2) * 16 + i]) + (lds[(2 * 2 + q2) * 16 + i] + lds[(3 * 2 + q2) * 16 + i]);
+        // (32 replicas of the sums folded by the last workgroup to arrive -- 2304 workgroups commit to ONE 128-byte line -- were built and
+        //  measured: 10.027 vs 10.009 ms per step with the plain commit, docs/experiments_r6.md §7)
+        if (tid < 32) commit(a);
     }
 }
 
@@ -595,6 +601,13 @@ template <int COUT, int CIN, int EPI, bool WREG, bool GATH>
 __global__ __launch_bounds__(256, GATH ? 2 : (WREG ? 3 : 4)) void conv_strip_kernel(SArgs p)
 {
     conv_strip_body<COUT, CIN, EPI, WREG, GATH ? 1 : 0>(p);
+}
+
+// 8 -> 8 with the RGB-side extras in the epilogue (XM above): XM 1 keeps the weights in registers, XM 3 (weight gradient) in LDS
+template <int EPI, bool WREG, int XM>
+__global__ __launch_bounds__(256, 3) void conv_strip_x_kernel(SArgs p)
+{
+    conv_strip_body<8, 8, EPI, WREG, 0, XM>(p);
 }
 
 // 8 -> 8 with the block's fromRGB layer in the gather (GM 2)
@@ -621,6 +634,17 @@ int launch_strip(const SArgs& a, int N, hipStream_t s, char* name, size_t name_l
     auto kern = conv_strip_kernel<COUT, CIN, EPI, WREG, GATH>;
     if (int rc = strip_set_smem(reinterpret_cast<const void*>(kern), smem); rc) return rc;
     snprintf(name, name_len, "conv_strip_kernel<%d, %d, %d, %s, %s>", COUT, CIN, EPI, WREG ? "true" : "false", GATH ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
+    return (int)hipGetLastError();
+}
+
+template <int EPI, bool WREG, int XM>
+int launch_strip_x(const SArgs& a, int N, hipStream_t s, char* name, size_t name_len)
+{
+    const size_t smem = (size_t)NBLK * Blk<8>::SLOTS * 16 + (WREG ? 0 : (size_t)9 * 8 * 8 * 4);
+    auto kern = conv_strip_x_kernel<EPI, WREG, XM>;
+    if (int rc = strip_set_smem(reinterpret_cast<const void*>(kern), smem); rc) return rc;
+    snprintf(name, name_len, "conv_strip_x_kernel<%d, %s, %d>", EPI, WREG ? "true" : "false", XM);
     hipLaunchKernelGGL(kern, dim3((unsigned)(N * a.strips * a.segs)), dim3(256), smem, s, a);
     return (int)hipGetLastError();
 }
@@ -940,7 +964,7 @@ int pgk::launch_conv_strip_pn_torgb(const float* x, const float* w, const float*
     a.scale = scale; a.slope = slope; a.mask_slope = 1.f; a.pool_a = 1.f;
     a.H = H; a.W = W; a.strips = W / SW; a.segs = H / seg; a.seg_rows = seg;
     a.t_out = img; a.t_w = t_w; a.t_b = t_b; a.t_scale = t_scale; a.tC = C; a.t_sc = Cout; a.t_sco = 1;
-    return wreg_env ? launch_strip<8, 8, EPI_PN, true>(a, N, s, name, name_len) : launch_strip<8, 8, EPI_PN, false>(a, N, s, name, name_len);
+    return wreg_env ? launch_strip_x<EPI_PN, true, 1>(a, N, s, name, name_len) : launch_strip_x<EPI_PN, false, 1>(a, N, s, name, name_len);
 }
 
 int pgk::launch_conv_strip_masked_rgb_bwd(const float* gz, const float* wt, const unsigned char* mask_bytes, float mask_slope, float* y,
@@ -963,7 +987,9 @@ int pgk::launch_conv_strip_masked_rgb_bwd(const float* gz, const float* wt, cons
     a.H = H; a.W = W; a.strips = W / SW; a.segs = H / seg; a.seg_rows = seg;
     a.t_out = gimg; a.t_w = rgb_w; a.t_b = nullptr; a.t_scale = rgb_scale; a.tC = C; a.t_sc = 1; a.t_sco = C; a.t_only = y ? 0 : 1;
     a.fw_img = img; a.fw_dw = rgb_dw; a.fw_db = rgb_db; a.fw_scale = rgb_scale;
-    return wreg_env ? launch_strip<8, 8, EPI_MASK, true>(a, N, s, name, name_len) : launch_strip<8, 8, EPI_MASK, false>(a, N, s, name, name_len);
+    if (rgb_dw) return launch_strip_x<EPI_MASK, false, 3>(a, N, s, name, name_len);
+    (void)wreg_env;                              // (the register-weights form of this one sits at the 168-VGPR cap of three waves per SIMD and spills)
+    return launch_strip_x<EPI_MASK, false, 1>(a, N, s, name, name_len);
 }
 
 int pgk::launch_wgrad_strip(WgP& p, hipStream_t s, char* name, size_t name_len)

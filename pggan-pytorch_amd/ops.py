@@ -383,6 +383,7 @@ def conv2d_masked_fromrgb_bwd(gz, wt, mask_bytes, mask_slope, rgb_w, rgb_scale, 
     return gf, gimg
 
 
+
 def conv2d_wgrad_unpooled(x, g, gbytes, gmul, gslope, dw, db, N, Hin, Win, scale):
     """Weight gradient with gz = pool adjoint of ``g`` evaluated in the gather (see conv2d_unpooled)."""
     cout, cin = dw.shape[2], dw.shape[3]

@@ -255,7 +255,7 @@ def test_conv_with_fromrgb_unsupported_shapes():
 def test_pixelnorm_conv_with_torgb_in_the_epilogue(N, H, W, C):
     """pg_conv2d_pixelnorm_torgb_nhwc: the generator's last conv (+ bias + LeakyReLU + PixelNorm, reference network.py:33-41) with the
     block's toRGB layer (network.py:49, :138) in the same epilogue.  y and r exactly as pg_conv2d_pixelnorm_nhwc writes them (the same
-    kernel instantiation), the image against pg_torgb_fwd on that y (the two lanes of a pixel add their partial sums: another order of the
+    kernel body), the image against pg_torgb_fwd on that y (the two lanes of a pixel add their partial sums: another order of the
     eight products, 1e-6) and against the torch statement of the three layers; the image written into a caller's buffer."""
     x, w, b = rnd(N, H, W, 8, seed=1), rnd(3, 3, 8, 8, seed=2) * 0.2, rnd(8, seed=3) * 0.1
     tw, tb = rnd(C, 8, seed=4) * 0.5, rnd(C, seed=5) * 0.2
@@ -265,7 +265,7 @@ def test_pixelnorm_conv_with_torgb_in_the_epilogue(N, H, W, C):
     img0 = ops.torgb_fwd(y0, d(tw), d(tb), N, C, H, W, 0.71)
     buf = torch.full((N + 1, C, H, W), float('nan'), device='cuda')
     y, r, img = ops.conv2d_pixelnorm_torgb(d(x), d(w), d(b), d(tw), d(tb), N, C, H, W, 0.37, 0.2, 0.71, 1e-8, out=buf[1:])
-    assert last_kernel().startswith('conv_strip_kernel<8, 8, 3'), last_kernel()
+    assert last_kernel().startswith('conv_strip_x_kernel<3, '), last_kernel()
     torch.cuda.synchronize()
     assert torch.equal(y, y0) and torch.equal(r, r0)
     assert img.data_ptr() == buf[1:].data_ptr() and bool(torch.isnan(buf[0]).all())
@@ -279,7 +279,7 @@ def test_pixelnorm_conv_with_torgb_in_the_epilogue(N, H, W, C):
 def test_masked_backward_conv_with_fromrgb_adjoint_in_the_epilogue(N, H, W, C, keep):
     """pg_conv2d_masked_fromrgb_bwd_nhwc: the entry block's backward-data conv (x LeakyReLU' from sign bytes) with fromRGB's backward-data
     (the adjoint of reference network.py:145) in the same epilogue.  The 8-channel gradient exactly as pg_conv2d_nhwc writes it (same
-    kernel instantiation) -- or not written at all (``keep=False``) --, the image gradient against pg_fromrgb_bwd_data on it and against
+    kernel body) -- or not written at all (``keep=False``) --, the image gradient against pg_fromrgb_bwd_data on it and against
     the torch statement of the two steps."""
     gz, wt = rnd(N, H, W, 8, seed=1), rnd(3, 3, 8, 8, seed=2) * 0.2
     m = rnd(N, H, W, 8, seed=3)
@@ -291,7 +291,7 @@ def test_masked_backward_conv_with_fromrgb_adjoint_in_the_epilogue(N, H, W, C, k
     gi0 = torch.empty(N, C, H, W, device='cuda')
     ops.fromrgb_bwd_data(gf0, d(rw), gi0, N, C, H, W, 0.61)
     gf, gi = ops.conv2d_masked_fromrgb_bwd(d(gz), d(wt), d(mb), 0.2, d(rw), 0.61, N, C, H, W, 0.37, keep_gf=keep)
-    assert last_kernel().startswith('conv_strip_kernel<8, 8, 2'), last_kernel()
+    assert last_kernel().startswith('conv_strip_x_kernel<2, '), last_kernel()
     torch.cuda.synchronize()
     assert (gf is None) == (not keep)
     if keep:
@@ -319,9 +319,11 @@ def test_masked_backward_conv_with_fromrgb_weight_gradient_in_the_epilogue(N, H,
     dw0, db0 = torch.full((8, C, 1, 1), 0.25, device='cuda'), torch.full((8,), -0.5, device='cuda')
     dw, db = dw0.clone(), db0.clone()
     ops.fromrgb_wgrad(gf0, d(img), dw0, db0, N, C, H, W, 0.61)
-    gf, gi = ops.conv2d_masked_fromrgb_bwd(d(gz), d(wt), d(mb), 0.2, d(rw), 0.61, N, C, H, W, 0.37, keep_gf=keep, want_gimg=want_gimg,
-                                           img=d(img), rgb_dw=dw, rgb_db=db)
-    assert last_kernel().startswith('conv_strip_kernel<8, 8, 2, false'), last_kernel()
+    ops.fromrgb_wgrad(gf0, d(img), dw0, db0, N, C, H, W, 0.61)
+    for _ in range(2):                                      # (accumulates: twice the sums)
+        gf, gi = ops.conv2d_masked_fromrgb_bwd(d(gz), d(wt), d(mb), 0.2, d(rw), 0.61, N, C, H, W, 0.37, keep_gf=keep, want_gimg=want_gimg,
+                                               img=d(img), rgb_dw=dw, rgb_db=db)
+    assert last_kernel() == 'conv_strip_x_kernel<2, false, 3>', last_kernel()
     torch.cuda.synchronize()
     assert (gf is None) == (not keep) and (gi is None) == (not want_gimg)
     if keep:
@@ -329,6 +331,7 @@ def test_masked_backward_conv_with_fromrgb_weight_gradient_in_the_epilogue(N, H,
     assert rel_err(dw, dw0) < 2e-5 and rel_err(db, db0) < 2e-5
     egf = E.conv2d(gz, wt, None, N, H, W, 3, 1, 0.37, mask=m, mask_slope=0.2)
     edw, edb = torch.full((8, C), 0.25), torch.full((8,), -0.5)
+    E.fromrgb_wgrad(egf, img, edw, edb, N, C, H, W, 0.61)
     E.fromrgb_wgrad(egf, img, edw, edb, N, C, H, W, 0.61)
     assert rel_err(dw.view(8, C), edw) < 5e-5 and rel_err(db, edb) < 5e-5
     if want_gimg:
